@@ -1,0 +1,126 @@
+/*
+ * nsr.h -- C ABI of libnsr.so, the MI355X-native NICE-SLAM render hot path.
+ *
+ * Every entry point replaces a piece of the reference's *Python* interface (the reference has no
+ * native code).  Citations are relative to the reference tree:
+ *
+ *   nsr_get_samples      <- src/common.py:125-134  get_samples (after the torch.randint draw)
+ *   nsr_pack_params      <- (none) operand re-layout of src/conv_onet/models/decoder.py parameters
+ *   nsr_render_fwd       <- src/utils/Renderer.py:63-198  Renderer.render_batch_ray  (forward)
+ *                           incl. eval_points (:23-61), NICE.forward (decoder.py:312-342),
+ *                           raw2outputs_nerf_color (src/common.py:204-245)
+ *   nsr_render_bwd       <- the autograd backward of the above (src/Mapper.py:503, src/Tracker.py:125)
+ *   nsr_eval_points_fwd  <- src/utils/Renderer.py:23-61   Renderer.eval_points (forward only)
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers owned by the caller (PyTorch); the library never frees or
+ *     retains them beyond the call.  No torch types cross this boundary.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises.
+ *   - every function returns 0 on success; on failure a non-zero code and nsr_last_error()
+ *     (thread-local, valid until the next failing call on that thread) describes it.
+ *   - feature grids are fp32, 32 channels, CHANNELS-LAST: element (z,y,x,c) at ((z*Y+y)*X+x)*32+c.
+ *     This is the physical layout of a torch tensor of logical shape [1,32,Z,Y,X] in
+ *     torch.channels_last_3d memory format (reference logical shape: src/NICE_SLAM.py:218-222).
+ *   - decoder parameters are ONE flat fp32 blob per decoder in the order of the reference module's
+ *     named_parameters() (decoder.py:124-159 / :235-245), see nsr_param_count().
+ */
+#ifndef NSR_H_
+#define NSR_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSR_VERSION 1
+
+/* stages of NICE.forward (decoder.py:312-342) */
+enum { NSR_STAGE_COARSE = 0, NSR_STAGE_MIDDLE = 1, NSR_STAGE_FINE = 2, NSR_STAGE_COLOR = 3 };
+/* decoder / grid slots */
+enum { NSR_COARSE = 0, NSR_MIDDLE = 1, NSR_FINE = 2, NSR_COLOR = 3 };
+
+#define NSR_MAX_SAMPLES 64
+
+typedef struct nsr_grid {
+    const float *feat;   /* [Z][Y][X][32] */
+    float *dfeat;        /* gradient accumulator, same layout, caller-zeroed; NULL = not needed */
+    int32_t Z, Y, X;
+    int32_t pad_;
+    double lo[3];        /* normalisation box of the decoder reading this grid, xyz order          */
+    double hi[3];        /* (decoder .bound, src/NICE_SLAM.py:152-157; coarse = scene bound * 2)   */
+} nsr_grid;
+
+typedef struct nsr_decoder {
+    const float *params; /* flat blob, nsr_param_count(slot) floats                                */
+    const float *packed; /* MFMA operand stream written by nsr_pack_params, nsr_packed_count(slot) */
+    float *dparams;      /* flat gradient blob (caller-zeroed) or NULL                             */
+} nsr_decoder;
+
+typedef struct nsr_render_args {
+    int32_t stage;            /* NSR_STAGE_*                                                        */
+    int32_t n_samples;        /* uniform samples per ray  (cfg rendering.N_samples)                 */
+    int32_t n_surface;        /* near-surface samples; forced to 0 when gt_depth == NULL or coarse  */
+    int32_t pad_;
+    int64_t n_rays;
+    const float *rays_o;      /* [N][3] */
+    const float *rays_d;      /* [N][3] */
+    const float *gt_depth;    /* [N] or NULL (Renderer.py:88-96)                                    */
+    const float *gt_max;      /* device scalar: max over the WHOLE batch of gt_depth (Renderer.py:109,144);
+                                 required when gt_depth != NULL.  Kept on device: no host sync.     */
+    double bound_lo[3];       /* Renderer.bound (un-enlarged): far_bb and the in-bound test         */
+    double bound_hi[3];
+    float t_uniform[NSR_MAX_SAMPLES];   /* torch.linspace(0,1,n_samples) fp32 (Renderer.py:152)     */
+    double t_surface[NSR_MAX_SAMPLES];  /* torch.linspace(0,1,n_surface).double() (Renderer.py:132) */
+    nsr_grid grid[4];         /* slots NSR_COARSE..NSR_COLOR; unused slots may be zeroed            */
+    nsr_decoder dec[4];
+    /* outputs */
+    double *depth;            /* [N]    */
+    double *var;              /* [N]    */
+    float *rgb;               /* [N][3] */
+    float *raw;               /* [N][S][4] decoder output after the out-of-bound override, S = n_samples+n_surface;
+                                 written by fwd, read by bwd.  May be NULL for a forward-only call.  */
+} nsr_render_args;
+
+typedef struct nsr_bwd_args {
+    const double *d_depth;    /* [N]    dL/d depth   */
+    const double *d_var;      /* [N]    dL/d var, may be NULL (== 0)  */
+    const float *d_rgb;       /* [N][3] dL/d rgb, may be NULL (== 0)  */
+    const double *depth;      /* [N]    forward result (needed for the variance term) */
+    float *d_rays_o;          /* [N][3] caller-zeroed, or NULL */
+    float *d_rays_d;          /* [N][3] caller-zeroed, or NULL */
+    float *workspace;         /* nsr_bwd_workspace_floats() floats, contents undefined */
+    int64_t workspace_floats;
+    int32_t max_blocks;       /* persistent-grid cap used to size the workspace (0 = library default) */
+    int32_t pad_;
+} nsr_bwd_args;
+
+int nsr_version(void);
+const char *nsr_last_error(void);
+
+/* number of fp32 parameters of decoder slot `slot` (coarse 6 337 / middle 15 800 / fine 20 920 / color 15 899) */
+int64_t nsr_param_count(int slot);
+/* number of floats of the packed operand stream for decoder slot `slot` */
+int64_t nsr_packed_count(int slot);
+/* floats of scratch nsr_render_bwd needs for (stage, n_rays, max_blocks) */
+int64_t nsr_bwd_workspace_floats(int stage, int64_t n_rays, int n_samples_total, int max_blocks);
+
+int nsr_pack_params(int slot, const float *params, float *packed, void *stream);
+
+int nsr_render_fwd(const nsr_render_args *a, void *stream);
+int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream);
+
+/* Renderer.eval_points forward: p [M][3] fp64 world points -> out [M][4] fp32 (rgb, occ) */
+int nsr_eval_points_fwd(const nsr_render_args *a, const double *points, int64_t n_points, float *out, void *stream);
+
+/* get_samples after the index draw: flat indices into the crop [H0,H1)x[W0,W1) (row-major) ->
+ * rays + gathered depth/colour.  c2w is a row-major 3x4 (or 4x4) fp32 matrix with row stride c2w_stride. */
+int nsr_get_samples(const int64_t *indices, int64_t n, int32_t H0, int32_t H1, int32_t W0, int32_t W1,
+                    int32_t W_full, float fx, float fy, float cx, float cy,
+                    const float *c2w, int32_t c2w_stride, const float *depth, const float *color,
+                    float *rays_o, float *rays_d, float *out_depth, float *out_color, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSR_H_ */

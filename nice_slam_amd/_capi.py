@@ -1,0 +1,101 @@
+"""ctypes binding of the C ABI declared in include/nsr.h.
+
+The product loads ``nice_slam_amd/libnsr.so`` (built by ``nice_slam_amd.build`` /
+``__graft_entry__.build()`` with hipcc for gfx950) and fails loudly when it is missing: there is
+no CPU or PyTorch fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+MAX_SAMPLES = 64
+STAGE_ID = {"coarse": 0, "middle": 1, "fine": 2, "color": 3}
+SLOT_NAMES = ("coarse", "middle", "fine", "color")
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnsr.so")
+
+
+class NsrGrid(C.Structure):
+    _fields_ = [("feat", C.c_void_p), ("dfeat", C.c_void_p),
+                ("Z", C.c_int32), ("Y", C.c_int32), ("X", C.c_int32), ("pad_", C.c_int32),
+                ("lo", C.c_double * 3), ("hi", C.c_double * 3)]
+
+
+class NsrDecoder(C.Structure):
+    _fields_ = [("params", C.c_void_p), ("packed", C.c_void_p), ("dparams", C.c_void_p)]
+
+
+class NsrRenderArgs(C.Structure):
+    _fields_ = [("stage", C.c_int32), ("n_samples", C.c_int32), ("n_surface", C.c_int32), ("pad_", C.c_int32),
+                ("n_rays", C.c_int64),
+                ("rays_o", C.c_void_p), ("rays_d", C.c_void_p), ("gt_depth", C.c_void_p), ("gt_max", C.c_void_p),
+                ("bound_lo", C.c_double * 3), ("bound_hi", C.c_double * 3),
+                ("t_uniform", C.c_float * MAX_SAMPLES), ("t_surface", C.c_double * MAX_SAMPLES),
+                ("grid", NsrGrid * 4), ("dec", NsrDecoder * 4),
+                ("depth", C.c_void_p), ("var", C.c_void_p), ("rgb", C.c_void_p), ("raw", C.c_void_p)]
+
+
+class NsrBwdArgs(C.Structure):
+    _fields_ = [("d_depth", C.c_void_p), ("d_var", C.c_void_p), ("d_rgb", C.c_void_p), ("depth", C.c_void_p),
+                ("d_rays_o", C.c_void_p), ("d_rays_d", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
+                ("max_blocks", C.c_int32), ("pad_", C.c_int32)]
+
+
+# every symbol include/nsr.h declares: (name, restype, argtypes)
+SYMBOLS = (
+    ("nsr_version", C.c_int, []),
+    ("nsr_last_error", C.c_char_p, []),
+    ("nsr_param_count", C.c_int64, [C.c_int]),
+    ("nsr_packed_count", C.c_int64, [C.c_int]),
+    ("nsr_bwd_workspace_floats", C.c_int64, [C.c_int, C.c_int64, C.c_int, C.c_int]),
+    ("nsr_pack_params", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("nsr_render_fwd", C.c_int, [C.POINTER(NsrRenderArgs), C.c_void_p]),
+    ("nsr_render_bwd", C.c_int, [C.POINTER(NsrRenderArgs), C.POINTER(NsrBwdArgs), C.c_void_p]),
+    ("nsr_eval_points_fwd", C.c_int, [C.POINTER(NsrRenderArgs), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("nsr_get_samples", C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+)
+
+
+class NsrError(RuntimeError):
+    pass
+
+
+class Lib:
+    """A loaded libnsr with typed entry points; ``check`` turns error codes into exceptions."""
+
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise NsrError(
+                f"{path} not found: the HIP extension has not been built. Run "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc); there is no fallback path.")
+        self.path = path
+        self.cdll = C.CDLL(path)
+        for name, res, args in SYMBOLS:
+            fn = getattr(self.cdll, name)      # AttributeError here = ABI drift
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+        if self.nsr_version() != 1:
+            raise NsrError(f"{path}: ABI version {self.nsr_version()} != 1")
+
+    def check(self, rc: int, what: str = "nsr"):
+        if rc != 0:
+            msg = self.nsr_last_error()
+            raise NsrError(f"{what} failed: {msg.decode() if msg else rc}")
+
+
+_lib = None
+
+
+def get_lib() -> Lib:
+    """The product library (lazy: Renderer objects are pickled into spawned processes before first use,
+    reference src/NICE_SLAM.py:91,296-301)."""
+    global _lib
+    if _lib is None:
+        _lib = Lib(LIB_PATH)
+    return _lib

@@ -1,0 +1,245 @@
+// nsr_api.cpp -- the C ABI of libnsr.so (see include/nsr.h).  Compiled as HIP for gfx950.
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "nsr_rt.h"
+#include "nsr_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string &msg) {
+    g_err = msg;
+    return 1;
+}
+
+constexpr int kMaxTiles = 12;            // 12 waves = 768 threads per block
+constexpr int kDefaultBwdBlocks = 512;   // persistent-grid cap of the backward kernel
+constexpr int kLdsLimit = 160 * 1024;
+
+inline int round16(int bytes) { return (bytes + 15) & ~15; }
+
+int rays_per_block(int S) {
+    int rb = (kMaxTiles * nsr::kTile) / S;
+    return rb < 1 ? 1 : rb;
+}
+
+int stage_passes(int stage) { return stage == NSR_STAGE_COARSE ? 1 : 3; }
+
+int max_param_count(int stage) {
+    return stage == NSR_STAGE_COARSE ? nsr::param_total(0) : nsr::param_total(2);
+}
+
+int bwd_blocks(long long n_groups, int max_blocks) {
+    long long cap = max_blocks > 0 ? max_blocks : kDefaultBwdBlocks;
+    return (int)(n_groups < cap ? n_groups : cap);
+}
+
+// validate + translate the public argument block
+int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays) {
+    if (!a) return fail("nsr: null argument block");
+    if (a->stage < 0 || a->stage > 3) return fail("nsr: stage out of range");
+    std::memset(&P, 0, sizeof(P));
+    P.stage = a->stage;
+    P.n_samples = a->n_samples;
+    const bool guided = a->gt_depth != nullptr && a->stage != NSR_STAGE_COARSE;
+    P.n_surface = guided ? a->n_surface : 0;
+    P.S = P.n_samples + P.n_surface;
+    if (P.n_samples < 1 || P.n_surface < 0 || P.S > NSR_MAX_SAMPLES)
+        return fail("nsr: n_samples + n_surface must be in [1, 64]");
+    if (guided && !a->gt_max) return fail("nsr: gt_max is required when gt_depth is given");
+    P.n_rays = a->n_rays;
+    if (need_rays) {
+        if (a->n_rays < 0) return fail("nsr: negative ray count");
+        if (a->n_rays > 0 && (!a->rays_o || !a->rays_d)) return fail("nsr: null ray pointers");
+    }
+    P.rays_per_block = rays_per_block(P.S);
+    P.tiles_per_block = (P.rays_per_block * P.S + nsr::kTile - 1) / nsr::kTile;
+    P.n_groups = (P.n_rays + P.rays_per_block - 1) / P.rays_per_block;
+    P.rays_o = a->rays_o;
+    P.rays_d = a->rays_d;
+    P.gt_depth = guided ? a->gt_depth : nullptr;
+    P.gt_max = a->gt_max;
+    for (int i = 0; i < 3; ++i) { P.blo[i] = a->bound_lo[i]; P.bhi[i] = a->bound_hi[i]; }
+    std::memcpy(P.t_uniform, a->t_uniform, sizeof(P.t_uniform));
+    std::memcpy(P.t_surface, a->t_surface, sizeof(P.t_surface));
+    const int first = a->stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE;
+    const int last = a->stage == NSR_STAGE_COARSE ? NSR_COARSE : a->stage;
+    for (int s = first; s <= last; ++s) {
+        const nsr_grid &g = a->grid[s];
+        if (!g.feat) return fail("nsr: missing feature grid for this stage");
+        if (g.Z < 1 || g.Y < 1 || g.X < 1) return fail("nsr: bad grid shape");
+        if ((long long)g.Z * g.Y * g.X >= (1ll << 26)) return fail("nsr: grid too large for 32-bit voxel indexing");
+        nsr::GridDev &G = P.grid[s];
+        G.feat = g.feat; G.dfeat = g.dfeat; G.Z = g.Z; G.Y = g.Y; G.X = g.X;
+        for (int i = 0; i < 3; ++i) {
+            if (!(g.hi[i] > g.lo[i])) return fail("nsr: empty normalisation box");
+            G.lo[i] = g.lo[i];
+            G.inv[i] = 1.0 / (g.hi[i] - g.lo[i]);
+        }
+        const nsr_decoder &d = a->dec[s];
+        if (!d.params || !d.packed) return fail("nsr: missing decoder parameters / packed stream for this stage");
+        P.dec[s].params = d.params; P.dec[s].packed = d.packed; P.dec[s].dparams = d.dparams;
+    }
+    P.depth = a->depth; P.var = a->var; P.rgb = a->rgb; P.raw = a->raw;
+    return 0;
+}
+
+int finish(const char *what) {
+    if (const char *e = nsr::rt_check_last()) return fail(std::string(what) + ": " + e);
+    return 0;
+}
+
+template <typename K>
+int launch_cfg(K kernel, int lds_bytes, const char *what) {
+    if (lds_bytes > kLdsLimit) return fail(std::string(what) + ": LDS budget exceeded");
+    if (lds_bytes > 48 * 1024)
+        if (const char *e = nsr::rt_allow_lds(kernel, lds_bytes)) return fail(std::string(what) + ": " + e);
+    return 0;
+}
+
+int fwd_lds_bytes(int npts) { return round16(3 * nsr::AUX_FLOATS * 4) + npts * (8 + 8 + 16); }
+
+int bwd_lds_bytes(int stage, int npts, int tiles) {
+    const int npar = max_param_count(stage);
+    const int head = (nsr::AUX_FLOATS + npar + 3) & ~3;
+    return round16(head * 4 + npts * (8 + 8 + 16 + 24)) + tiles * (2 * nsr::kTile * nsr::kTxS * 4);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nsr_version(void) { return NSR_VERSION; }
+const char *nsr_last_error(void) { return g_err.c_str(); }
+
+int64_t nsr_param_count(int slot) { return (slot < 0 || slot > 3) ? -1 : nsr::param_total(slot); }
+int64_t nsr_packed_count(int slot) { return (slot < 0 || slot > 3) ? -1 : nsr::packed_total(slot); }
+
+int64_t nsr_bwd_workspace_floats(int stage, int64_t n_rays, int n_samples_total, int max_blocks) {
+    if (stage < 0 || stage > 3 || n_samples_total < 1 || n_samples_total > NSR_MAX_SAMPLES) return -1;
+    const int rb = rays_per_block(n_samples_total);
+    const long long groups = (n_rays + rb - 1) / rb;
+    const long long blocks = bwd_blocks(groups, max_blocks);
+    return (int64_t)stage_passes(stage) * (blocks > 0 ? blocks : 1) * max_param_count(stage);
+}
+
+int nsr_pack_params(int slot, const float *params, float *packed, void *stream) {
+    if (slot < 0 || slot > 3) return fail("nsr_pack_params: slot out of range");
+    if (!params || !packed) return fail("nsr_pack_params: null pointer");
+    const int n = nsr::packed_total(slot), tb = 256, nb = (n + tb - 1) / tb;
+    switch (slot) {
+        case 0: NSR_LAUNCH(nsr::pack_kernel<0>, dim3(nb), dim3(tb), 0, stream, params, packed); break;
+        case 1: NSR_LAUNCH(nsr::pack_kernel<1>, dim3(nb), dim3(tb), 0, stream, params, packed); break;
+        case 2: NSR_LAUNCH(nsr::pack_kernel<2>, dim3(nb), dim3(tb), 0, stream, params, packed); break;
+        default: NSR_LAUNCH(nsr::pack_kernel<3>, dim3(nb), dim3(tb), 0, stream, params, packed); break;
+    }
+    return finish("nsr_pack_params");
+}
+
+int nsr_render_fwd(const nsr_render_args *a, void *stream) {
+    nsr::RenderParams P;
+    if (int rc = build_params(a, P, true)) return rc;
+    if (!a->depth || !a->var || !a->rgb) return fail("nsr_render_fwd: null output pointer");
+    if (P.n_rays == 0) return 0;
+    const int npts = P.rays_per_block * P.S;
+    const int lds = fwd_lds_bytes(npts);
+    const dim3 grid((unsigned)(P.n_groups < (1 << 20) ? P.n_groups : (1 << 20))), block(64 * P.tiles_per_block);
+#define NSR_FWD(ST)                                                                              \
+    case ST:                                                                                     \
+        if (int rc = launch_cfg(nsr::render_fwd_kernel<ST>, lds, "nsr_render_fwd")) return rc;    \
+        NSR_LAUNCH(nsr::render_fwd_kernel<ST>, grid, block, lds, stream, P);                      \
+        break;
+    switch (P.stage) { NSR_FWD(0) NSR_FWD(1) NSR_FWD(2) NSR_FWD(3) }
+#undef NSR_FWD
+    return finish("nsr_render_fwd");
+}
+
+int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream) {
+    nsr::RenderParams P;
+    if (int rc = build_params(a, P, true)) return rc;
+    if (!b) return fail("nsr_render_bwd: null backward block");
+    if (!a->raw) return fail("nsr_render_bwd: the forward pass must have saved `raw`");
+    if (!b->d_depth && !b->d_var && !b->d_rgb) return fail("nsr_render_bwd: no output gradient given");
+    if (!b->depth) return fail("nsr_render_bwd: forward depth is required");
+    if ((b->d_rays_o == nullptr) != (b->d_rays_d == nullptr)) return fail("nsr_render_bwd: d_rays_o / d_rays_d must be given together");
+    if (P.n_rays == 0) return 0;
+    P.d_depth = b->d_depth; P.d_var = b->d_var; P.d_rgb = b->d_rgb; P.g_depth = b->depth;
+    P.d_rays_o = b->d_rays_o; P.d_rays_d = b->d_rays_d;
+    const int passes = stage_passes(P.stage);
+    const int nblk = bwd_blocks(P.n_groups, b->max_blocks);
+    bool any_params = false;
+    for (int s = 0; s < 4; ++s) any_params |= P.dec[s].dparams != nullptr;
+    P.partial_stride = max_param_count(P.stage);
+    if (any_params) {
+        const long long need = (long long)passes * nblk * P.partial_stride;
+        if (!b->workspace || b->workspace_floats < need) return fail("nsr_render_bwd: workspace too small");
+        P.partials = b->workspace;
+    }
+    const int npts = P.rays_per_block * P.S;
+    const int lds = bwd_lds_bytes(P.stage, npts, P.tiles_per_block);
+    const dim3 grid(nblk, passes), block(64 * P.tiles_per_block);
+#define NSR_BWD(ST)                                                                              \
+    case ST:                                                                                     \
+        if (int rc = launch_cfg(nsr::render_bwd_kernel<ST>, lds, "nsr_render_bwd")) return rc;    \
+        NSR_LAUNCH(nsr::render_bwd_kernel<ST>, grid, block, lds, stream, P);                      \
+        break;
+    switch (P.stage) { NSR_BWD(0) NSR_BWD(1) NSR_BWD(2) NSR_BWD(3) }
+#undef NSR_BWD
+    if (int rc = finish("nsr_render_bwd")) return rc;
+    if (any_params) {
+        const int first = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE;
+        const int last = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : P.stage;
+        for (int s = first; s <= last; ++s) {
+            if (!P.dec[s].dparams) continue;
+            const int pass = P.stage == NSR_STAGE_COARSE ? 0 : s - NSR_MIDDLE;
+            const int n = nsr::param_total(s), tb = 256;
+            NSR_LAUNCH(nsr::reduce_partials_kernel, dim3((n + tb - 1) / tb), dim3(tb), 0, stream,
+                       (const float *)(P.partials + (long long)pass * nblk * P.partial_stride), nblk, P.partial_stride, n,
+                       P.dec[s].dparams);
+        }
+        if (int rc = finish("nsr_render_bwd(reduce)")) return rc;
+    }
+    return 0;
+}
+
+int nsr_eval_points_fwd(const nsr_render_args *a, const double *points, int64_t n_points, float *out, void *stream) {
+    nsr::RenderParams P;
+    if (int rc = build_params(a, P, false)) return rc;
+    if (n_points < 0 || (n_points > 0 && (!points || !out))) return fail("nsr_eval_points_fwd: bad points / out");
+    if (n_points == 0) return 0;
+    P.points = points; P.n_points = n_points; P.out_points = out;
+    const int waves = 8, lds = round16(3 * nsr::AUX_FLOATS * 4);
+    const long long tiles = (n_points + nsr::kTile - 1) / nsr::kTile;
+    long long nb = (tiles + waves - 1) / waves;
+    if (nb > 4096) nb = 4096;
+    const dim3 grid((unsigned)nb), block(64 * waves);
+#define NSR_EVP(ST)                                                                              \
+    case ST: NSR_LAUNCH(nsr::eval_points_kernel<ST>, grid, block, lds, stream, P); break;
+    switch (P.stage) { NSR_EVP(0) NSR_EVP(1) NSR_EVP(2) NSR_EVP(3) }
+#undef NSR_EVP
+    return finish("nsr_eval_points_fwd");
+}
+
+int nsr_get_samples(const int64_t *indices, int64_t n, int32_t H0, int32_t H1, int32_t W0, int32_t W1,
+                    int32_t W_full, float fx, float fy, float cx, float cy,
+                    const float *c2w, int32_t c2w_stride, const float *depth, const float *color,
+                    float *rays_o, float *rays_d, float *out_depth, float *out_color, void *stream) {
+    if (n < 0 || H1 <= H0 || W1 <= W0 || W_full < W1) return fail("nsr_get_samples: bad crop");
+    if (n == 0) return 0;
+    if (!indices || !c2w || !depth || !color || !rays_o || !rays_d || !out_depth || !out_color)
+        return fail("nsr_get_samples: null pointer");
+    nsr::SampleParams S;
+    S.indices = reinterpret_cast<const long long *>(indices);
+    S.n = n; S.H0 = H0; S.W0 = W0; S.crop_w = W1 - W0; S.W_full = W_full;
+    S.fx = fx; S.fy = fy; S.cx = cx; S.cy = cy;
+    S.c2w = c2w; S.c2w_stride = c2w_stride; S.depth = depth; S.color = color;
+    S.rays_o = rays_o; S.rays_d = rays_d; S.out_depth = out_depth; S.out_color = out_color;
+    const int tb = 256;
+    NSR_LAUNCH(nsr::get_samples_kernel, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, stream, S);
+    return finish("nsr_get_samples");
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// nsr_dev.h -- device-side primitives for gfx950 (CDNA4).  Pure HIP; the only build target.
+// (tests/emu/ shadows this header with a host re-implementation of the same names so that the
+//  kernel sources can be executed lane-by-lane on a CPU in the unit tests; that shim is test
+//  infrastructure and is never part of libnsr.so.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NSR_DEV __device__ __forceinline__
+#define NSR_KERNEL __global__
+#define NSR_BOUNDS(n) __launch_bounds__(n)
+
+namespace nsr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct F4 { float x, y, z, w; };   // plain 16-byte POD used for vector loads/stores
+
+// D = A(16x4) * B(4x16) + C, exact fp32 fma chain.  Lane l supplies A[i=l&15][k=l>>4] and
+// B[k=l>>4][j=l&15]; holds D[i=4*(l>>4)+r][j=l&15] in element r.  (v_mfma_f32_16x16x4_f32)
+NSR_DEV f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+NSR_DEV int tid() { return (int)threadIdx.x; }
+NSR_DEV int nthreads() { return (int)blockDim.x; }
+NSR_DEV int bid_x() { return (int)blockIdx.x; }
+NSR_DEV int bid_y() { return (int)blockIdx.y; }
+NSR_DEV int nblk_x() { return (int)gridDim.x; }
+
+NSR_DEV float shfl(float v, int src) { return __shfl(v, src, 64); }
+NSR_DEV int shfl_i(int v, int src) { return __shfl(v, src, 64); }
+NSR_DEV double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+NSR_DEV float shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
+NSR_DEV double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
+NSR_DEV float shfl_up(float v, int d) { return __shfl_up(v, (unsigned)d, 64); }
+NSR_DEV float shfl_down(float v, int d) { return __shfl_down(v, (unsigned)d, 64); }
+
+// make this wave's earlier LDS writes visible to its own later LDS reads (other lanes)
+NSR_DEV void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// keep the instruction scheduler from hoisting the next operand stream above this point
+NSR_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// compiler-only memory clobber: stops loop-invariant code motion of loads across loop iterations
+NSR_DEV void loop_fence() { asm volatile("" ::: "memory"); }
+NSR_DEV void block_sync() { __syncthreads(); }
+
+NSR_DEV void atomic_add_global(float *p, float v) { unsafeAtomicAdd(p, v); }
+NSR_DEV void atomic_add_lds(float *p, float v) { atomicAdd(p, v); }
+
+NSR_DEV char *lds_base() {
+    extern __shared__ __attribute__((aligned(16))) char nsr_lds_[];
+    return nsr_lds_;
+}
+
+// Operand streams (packed weights / flat parameter blob) are read with buffer loads: the 128-bit
+// descriptor and the per-load offset live in SGPRs, the lane offset is ONE shared VGPR -- the
+// 64-bit per-row address pairs a plain pointer walk needs would otherwise eat >150 VGPRs.
+struct Stream { __amdgpu_buffer_rsrc_t rsrc; };
+NSR_DEV Stream make_stream(const float *base) {
+    Stream s;
+    s.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
+    return s;
+}
+// value at base[lane_off + const_off]   (offsets in floats; const_off is wave-uniform)
+NSR_DEV float stream_ld(const Stream &s, int lane_off, int const_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, lane_off * 4, const_off * 4, 0));
+}
+
+NSR_DEV F4 ld4(const float *p) { float4 v = *reinterpret_cast<const float4 *>(p); return F4{v.x, v.y, v.z, v.w}; }
+NSR_DEV void st4(float *p, F4 v) { *reinterpret_cast<float4 *>(p) = make_float4(v.x, v.y, v.z, v.w); }
+
+}  // namespace nsr
+
+#define NSR_LAUNCH(kernel, grid, block, lds_bytes, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, lds_bytes, (hipStream_t)(stream), __VA_ARGS__)

@@ -1,0 +1,1174 @@
+// nsr_kernels.h -- fused render kernels for the NICE-SLAM hot path on gfx950.
+//
+// One wave = one tile of 16 sample points.  Lane l = (pt = l & 15, g = l >> 4).  Every activation
+// vector of a point (features c, embedding e, hidden h, and their gradients) is held "CL":
+// for k-tile T the lane owns channels 16T + 4g + r, r = 0..3, as one f32x4.  With that layout
+//   * the trilinear gather of a channels-last voxel (32 ch = 128 B) is two 16-B loads per corner per
+//     lane and lands directly in MFMA operand position -- no LDS transposition,
+//   * y = W x is a chain of v_mfma_f32_16x16x4_f32 with A = packed weights (one coalesced dword per
+//     lane per MFMA) and B = the register that already holds x, output again CL,
+//   * dx = W^T dy uses A = W read row-major (64-B runs) and B = dy registers,
+//   * dW = dy^T x contracts over the 16 points of the tile; both operands go through a 2.3 KB
+//     per-wave LDS transposition buffer, results are summed into a per-block LDS image of the flat
+//     parameter-gradient blob and flushed once per block.
+// References: Renderer.render_batch_ray (src/utils/Renderer.py:63-198), eval_points (:23-61),
+// NICE/MLP/MLP_no_xyz forward (src/conv_onet/models/decoder.py:168-203,254-274,312-342),
+// raw2outputs_nerf_color (src/common.py:204-245), ATen grid_sampler_3d (GridSampler.h).
+#pragma once
+#include "nsr_dev.h"
+#include "nsr_layout.h"
+#include "../../include/nsr.h"
+
+namespace nsr {
+
+template <int NT>
+struct Act { f32x4 t[NT]; };
+
+NSR_DEV f32x4 f4zero() { f32x4 v = {0.f, 0.f, 0.f, 0.f}; return v; }
+NSR_DEV f32x4 to_v(F4 a) { f32x4 v = {a.x, a.y, a.z, a.w}; return v; }
+NSR_DEV F4 to_F4(f32x4 v) { return F4{v[0], v[1], v[2], v[3]}; }
+template <int NT> NSR_DEV void act_zero(Act<NT> &a) {
+#pragma unroll
+    for (int T = 0; T < NT; ++T) a.t[T] = f4zero();
+}
+
+// NaN-propagating min/max (torch.max / torch.min semantics, Renderer.py:102)
+NSR_DEV double tmax(double a, double b) { return (a > b || a != a) ? a : b; }
+NSR_DEV double tmin(double a, double b) { return (a < b || a != a) ? a : b; }
+
+// ------------------------------------------------------------------------------------------------
+// kernel parameter blocks
+// ------------------------------------------------------------------------------------------------
+struct GridDev {
+    const float *feat;
+    float *dfeat;
+    int Z, Y, X;
+    double lo[3];
+    double inv[3];      // 1 / (hi - lo)
+};
+
+struct DecDev {
+    const float *params;
+    const float *packed;
+    float *dparams;
+};
+
+struct RenderParams {
+    int stage, n_samples, n_surface, S;     // S = n_samples + n_surface
+    long long n_rays;
+    int rays_per_block, tiles_per_block;    // tiles = ceil(rays_per_block * S / 16)
+    long long n_groups;
+    const float *rays_o, *rays_d, *gt_depth, *gt_max;
+    double blo[3], bhi[3];
+    float t_uniform[NSR_MAX_SAMPLES];
+    double t_surface[NSR_MAX_SAMPLES];
+    GridDev grid[4];
+    DecDev dec[4];
+    double *depth, *var;
+    float *rgb, *raw;
+    // backward only
+    const double *d_depth, *d_var, *g_depth;
+    const float *d_rgb;
+    float *d_rays_o, *d_rays_d;
+    float *partials;          // [3 passes][gridDim.x][max param count]
+    int partial_stride;       // floats between two blocks' partial images
+    // eval_points only
+    const double *points;
+    long long n_points;
+    float *out_points;
+};
+
+// ------------------------------------------------------------------------------------------------
+// parameter packing: flat blob -> forward operand stream
+//   packed[m.pk + ((T*4 + r)*2 + Tp)*64 + lane] = W[16*Tp + (lane&15)][kbeg + 16T + 4(lane>>4) + r]
+// ------------------------------------------------------------------------------------------------
+template <int KIND>
+NSR_KERNEL void pack_kernel(const float *__restrict__ flat, float *__restrict__ packed) {
+    const int idx = bid_x() * nthreads() + tid();
+    if (idx >= packed_total(KIND)) return;
+    float v = 0.f;
+#pragma unroll
+    for (int id = 0; id < nmat_of(KIND); ++id) {
+        const Mat m = mat_of(KIND, id);
+        const int rel = idx - m.pk;
+        if (rel >= 0 && rel < m.nt * 512) {
+            const int lane = rel & 63, row = rel >> 6;
+            const int Tp = row & 1, r = (row >> 1) & 3, T = row >> 3;
+            const int o = 16 * Tp + (lane & 15);
+            const int k = 16 * T + 4 * (lane >> 4) + r;
+            if (k < m.kcols) v = flat[m.off + o * m.stride + m.kbeg + k];
+        }
+    }
+    packed[idx] = v;
+}
+
+// stage the small per-decoder tables into LDS (all threads of the block)
+template <int KIND>
+NSR_DEV void load_aux(float *aux, const float *__restrict__ flat) {
+    for (int idx = tid(); idx < AUX_FLOATS; idx += nthreads()) {
+        float v = 0.f;
+        if (idx < AUX_V) {
+            const int i = idx >> 5, o = idx & 31;
+            v = flat[bias_off(KIND, i) + o];
+        } else if (idx < AUX_WO) {
+            if (is_xyz(KIND)) { const int i = (idx - AUX_V) >> 5, o = idx & 31; v = flat[fcb_off(KIND, i) + o]; }
+        } else if (idx < AUX_BO) {
+            const int n = (idx - AUX_WO) >> 5, k = idx & 31;
+            if (n < nout_of(KIND)) v = flat[wo_off(KIND) + n * 32 + k];
+        } else if (idx < AUX_BM) {
+            const int n = idx - AUX_BO;
+            if (n < nout_of(KIND)) v = flat[bo_off(KIND) + n];
+        } else if (is_xyz(KIND)) {
+            const int ch = (idx - AUX_BM) >> 2, d = idx & 3;
+            if (ch < kE && d < 3) v = flat[B_off(KIND) + d * kE + ch];
+        }
+        aux[idx] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sample placement along the rays of one block  (Renderer.py:88-170)
+// ------------------------------------------------------------------------------------------------
+NSR_DEV double ray_far_bb(const RenderParams &P, long long ray) {
+    double far = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double o = (double)P.rays_o[ray * 3 + a], d = (double)P.rays_d[ray * 3 + a];
+        const double t0 = (P.blo[a] - o) / d, t1 = (P.bhi[a] - o) / d;
+        const double m = tmax(t0, t1);
+        far = (a == 0) ? m : tmin(far, m);
+    }
+    return far + 0.01;
+}
+
+// Fills zbuf[rays_per_block][S] (sorted ascending per ray).  ztmp is scratch of the same size.
+NSR_DEV void compute_z(const RenderParams &P, long long ray0, double *ztmp, double *zbuf) {
+    const int S = P.S, npts = P.rays_per_block * S;
+    const bool guided = (P.gt_depth != nullptr) && (P.stage != NSR_STAGE_COARSE);
+    for (int t = tid(); t < npts; t += nthreads()) {
+        const int r = t / S, k = t - r * S;
+        const long long ray = ray0 + r;
+        double z = 0.0;
+        if (ray < P.n_rays) {
+            const double far_bb = ray_far_bb(P, ray);
+            if (!guided) {
+                const float tk = P.t_uniform[k];
+                const float near_part = 0.01f * (1.f - tk);
+                z = (double)near_part + far_bb * (double)tk;
+            } else {
+                const float g = P.gt_depth[ray];
+                const float gmax = P.gt_max[0];
+                if (k < P.n_samples) {
+                    const float tk = P.t_uniform[k];
+                    const double cap = (double)(gmax * 1.2f);
+                    const double far = tmin(tmax(far_bb, 0.0), cap);
+                    const float near = g * 0.01f;
+                    z = (double)(near * (1.f - tk)) + far * (double)tk;
+                } else {
+                    const double s = P.t_surface[k - P.n_samples];
+                    if (g > 0.f) {
+                        const double e0 = (double)(0.95f * g), e1 = (double)(1.05f * g);
+                        z = e0 * (1.0 - s) + e1 * s;
+                    } else {
+                        z = 0.001 * (1.0 - s) + (double)gmax * s;
+                    }
+                }
+            }
+        }
+        ztmp[t] = z;
+    }
+    block_sync();
+    if (P.n_surface > 0 && guided) {
+        // rank sort of the S candidates of each ray (torch.sort, Renderer.py:168-170)
+        for (int t = tid(); t < npts; t += nthreads()) {
+            const int r = t / S, k = t - r * S;
+            const double v = ztmp[t];
+            int rank = 0;
+            for (int j = 0; j < S; ++j) {
+                const double u = ztmp[r * S + j];
+                rank += (u < v || (u == v && j < k)) ? 1 : 0;
+            }
+            zbuf[r * S + rank] = v;
+        }
+    } else {
+        for (int t = tid(); t < npts; t += nthreads()) zbuf[t] = ztmp[t];
+    }
+    block_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// trilinear lookup  (decoder.py:168-175, common.py:269-284, ATen GridSampler.h:27-85)
+// ------------------------------------------------------------------------------------------------
+struct Lvl {
+    int vox;            // linear voxel index of the (z0,y0,x0) corner
+    int sx, sy, sz;     // voxel-index step to the +1 neighbour (0 when the axis has one cell)
+    float fx, fy, fz;   // weight of the +1 neighbour
+    float gx, gy, gz;   // weight of the base corner ((i0+1) - u, the ATen form)
+    float mx, my, mz;   // d u / d g_normalised, 0 when the coordinate was clipped
+};
+
+NSR_DEV void axis_setup(double p, double lo, double inv, int n, int &i0, float &w0, float &w1, float &mult) {
+    const double gn = ((p - lo) * inv) * 2.0 - 1.0;      // fp64 normalisation, then one rounding
+    const float gf = (float)gn;
+    const float nm1 = (float)(n - 1);
+    float u = ((gf + 1.f) / 2.f) * nm1;
+    mult = (u <= 0.f || u >= nm1) ? 0.f : nm1 / 2.f;
+    u = fminf(nm1, fmaxf(u, 0.f));
+    int i = (int)floorf(u);
+    const int lim = n > 1 ? n - 2 : 0;
+    if (i > lim) i = lim;
+    i0 = i;
+    w0 = ((float)i + 1.f) - u;
+    w1 = u - (float)i;
+    if (n == 1) { w0 = 1.f; w1 = 0.f; }
+}
+
+NSR_DEV Lvl make_level(const GridDev &G, double px, double py, double pz) {
+    Lvl L;
+    int x0, y0, z0;
+    axis_setup(px, G.lo[0], G.inv[0], G.X, x0, L.gx, L.fx, L.mx);
+    axis_setup(py, G.lo[1], G.inv[1], G.Y, y0, L.gy, L.fy, L.my);
+    axis_setup(pz, G.lo[2], G.inv[2], G.Z, z0, L.gz, L.fz, L.mz);
+    L.vox = (z0 * G.Y + y0) * G.X + x0;
+    L.sx = G.X > 1 ? 1 : 0;
+    L.sy = G.Y > 1 ? G.X : 0;
+    L.sz = G.Z > 1 ? G.X * G.Y : 0;
+    return L;
+}
+
+NSR_DEV float corner_w(const Lvl &L, int c) {       // c = dz*4 + dy*2 + dx ; ((wx*wy)*wz)
+    const float wx = (c & 1) ? L.fx : L.gx, wy = (c & 2) ? L.fy : L.gy, wz = (c & 4) ? L.fz : L.gz;
+    return (wx * wy) * wz;
+}
+NSR_DEV int corner_vox(const Lvl &L, int c) {
+    return L.vox + ((c & 1) ? L.sx : 0) + ((c & 2) ? L.sy : 0) + ((c & 4) ? L.sz : 0);
+}
+
+// gather: lane (pt,g) accumulates channels 4g..4g+3 and 16+4g..16+4g+3 of its point
+NSR_DEV Act<2> gather_feat(const GridDev &G, const Lvl &L, int g) {
+    Act<2> c;
+    c.t[0] = f4zero();
+    c.t[1] = f4zero();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float w = corner_w(L, k);
+        const float *src = G.feat + (long long)corner_vox(L, k) * kC + 4 * g;
+        const F4 a = ld4(src), b = ld4(src + 16);
+        c.t[0][0] = fmaf(a.x, w, c.t[0][0]); c.t[0][1] = fmaf(a.y, w, c.t[0][1]);
+        c.t[0][2] = fmaf(a.z, w, c.t[0][2]); c.t[0][3] = fmaf(a.w, w, c.t[0][3]);
+        c.t[1][0] = fmaf(b.x, w, c.t[1][0]); c.t[1][1] = fmaf(b.y, w, c.t[1][1]);
+        c.t[1][2] = fmaf(b.z, w, c.t[1][2]); c.t[1][3] = fmaf(b.w, w, c.t[1][3]);
+    }
+    return c;
+}
+
+// backward of the gather: scatter-add dc into the grid gradient; optionally the coordinate gradient
+// (d value / d u per axis, ATen grid_sampler_3d_backward), returned already reduced over g.
+template <bool COORD>
+NSR_DEV void scatter_feat(const GridDev &G, const Lvl &L, int g, const Act<2> &dc, bool active, bool to_grid,
+                          float &dux, float &duy, float &duz) {
+    float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const long long base = (long long)corner_vox(L, k) * kC + 4 * g;
+        if (to_grid && active) {
+            const float w = corner_w(L, k);
+            float *dst = G.dfeat + base;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                atomic_add_global(dst + r, dc.t[0][r] * w);
+                atomic_add_global(dst + 16 + r, dc.t[1][r] * w);
+            }
+        }
+        if (COORD) {
+            const float *src = G.feat + base;
+            const F4 a = ld4(src), b = ld4(src + 16);
+            float dot = a.x * dc.t[0][0];
+            dot = fmaf(a.y, dc.t[0][1], dot); dot = fmaf(a.z, dc.t[0][2], dot); dot = fmaf(a.w, dc.t[0][3], dot);
+            dot = fmaf(b.x, dc.t[1][0], dot); dot = fmaf(b.y, dc.t[1][1], dot);
+            dot = fmaf(b.z, dc.t[1][2], dot); dot = fmaf(b.w, dc.t[1][3], dot);
+            const float wx = (k & 1) ? L.fx : L.gx, wy = (k & 2) ? L.fy : L.gy, wz = (k & 4) ? L.fz : L.gz;
+            ax = fmaf((k & 1) ? dot : -dot, wy * wz, ax);
+            ay = fmaf((k & 2) ? dot : -dot, wx * wz, ay);
+            az = fmaf((k & 4) ? dot : -dot, wx * wy, az);
+        }
+    }
+    if (COORD) {
+        ax += shfl_xor(ax, 16); ax += shfl_xor(ax, 32);
+        ay += shfl_xor(ay, 16); ay += shfl_xor(ay, 32);
+        az += shfl_xor(az, 16); az += shfl_xor(az, 32);
+        dux = ax * L.mx; duy = ay * L.my; duz = az * L.mz;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MFMA building blocks
+// ------------------------------------------------------------------------------------------------
+// acc[Tp] += W(slice) * x          (A from the packed stream, B = x registers)
+template <int NT>
+NSR_DEV void gemv_fwd(f32x4 (&acc)[2], const Act<NT> &x, const float *pk, int lane) {
+    const Stream st = make_stream(pk);      // scalar descriptor; the lane offset is the only VGPR
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a0 = stream_ld(st, lane, ((T * 4 + r) * 2) * 64);
+            const float a1 = stream_ld(st, lane, ((T * 4 + r) * 2) * 64 + 64);
+            acc[0] = mfma16(a0, x.t[T][r], acc[0]);
+            acc[1] = mfma16(a1, x.t[T][r], acc[1]);
+        }
+    }
+    sched_fence();
+}
+
+// dx[Tk] += W(slice)^T * dy       (A = W row-major from the flat blob, B = dy registers)
+template <int NTK>
+NSR_DEV void gemv_bwd(f32x4 (&dx)[NTK], const Act<2> &dy, const float *flat, const Mat m, int i, int g) {
+    const Stream st = make_stream(flat + m.off + m.kbeg);            // wave-uniform descriptor
+    const int lo = 4 * g * m.stride + i;                             // the only lane-dependent part
+#pragma unroll
+    for (int To = 0; To < 2; ++To) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int Tk = 0; Tk < NTK; ++Tk) {
+                const int k = 16 * Tk + i;
+                const float w = stream_ld(st, lo, (16 * To + r) * m.stride + 16 * Tk);   // always inside the blob
+                const float a = (k < m.kcols) ? w : 0.f;
+                dx[Tk] = mfma16(a, dy.t[To][r], dx[Tk]);
+            }
+        }
+    }
+    sched_fence();
+}
+
+// per-wave transposition buffers: Tx[pt][kTxS]
+NSR_DEV void tx_store(float *Tx, const Act<2> &v, int pt, int g) {
+    st4(Tx + pt * kTxS + 4 * g, to_F4(v.t[0]));
+    st4(Tx + pt * kTxS + 16 + 4 * g, to_F4(v.t[1]));
+}
+// element s = Tx[4s+g][16T + i]: the MFMA operand "lane = channel i of tile T, k = point 4s+g"
+NSR_DEV f32x4 tx_load_cm(const float *Tx, int T, int i, int g) {
+    f32x4 r;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) r[s] = Tx[(4 * s + g) * kTxS + 16 * T + i];
+    return r;
+}
+
+// acc_lds[W slice] += dy^T x for one 16-channel tile of x (xT = CM operand of that tile)
+NSR_DEV void dw_tile(float *acc_lds, const Mat m, int Tk, const f32x4 (&aT)[2], f32x4 xT, int i, int g) {
+    const int k = 16 * Tk + i;
+#pragma unroll
+    for (int To = 0; To < 2; ++To) {
+        f32x4 d = f4zero();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) d = mfma16(aT[To][s], xT[s], d);
+        if (k < m.kcols) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                atomic_add_lds(acc_lds + m.off + (16 * To + 4 * g + r) * m.stride + m.kbeg + k, d[r]);
+        }
+    }
+}
+// same with x supplied as a CL activation of 32 channels staged through TxB
+NSR_DEV void dw_act32(float *acc_lds, const Mat m, int Tk0, const f32x4 (&aT)[2], float *TxB, const Act<2> &x, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    tx_store(TxB, x, i, g);
+    wave_fence();
+#pragma unroll
+    for (int Tk = 0; Tk < 2; ++Tk) dw_tile(acc_lds, m, Tk0 + Tk, aT, tx_load_cm(TxB, Tk, i, g), i, g);
+    wave_fence();
+}
+// bias gradient: acc_lds[off + o] += sum over the tile's points of dy[pt][o]
+NSR_DEV void db_tile(float *acc_lds, int off, const f32x4 (&aT)[2], int i, int g) {
+#pragma unroll
+    for (int To = 0; To < 2; ++To) {
+        float s = (aT[To][0] + aT[To][1]) + (aT[To][2] + aT[To][3]);
+        s += shfl_xor(s, 16);
+        s += shfl_xor(s, 32);
+        if (g == 0) atomic_add_lds(acc_lds + off + 16 * To + i, s);
+    }
+}
+
+NSR_DEV float red_g(float v) { v += shfl_xor(v, 16); v += shfl_xor(v, 32); return v; }
+
+NSR_DEV unsigned relu_mask(f32x4 (&acc)[2]) {
+    unsigned m = 0;
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (acc[T][r] > 0.f) m |= 1u << (T * 4 + r); else acc[T][r] = 0.f;
+        }
+    return m;
+}
+NSR_DEV Act<2> apply_mask(const Act<2> &d, unsigned m) {
+    Act<2> o;
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o.t[T][r] = (m >> (T * 4 + r)) & 1u ? d.t[T][r] : 0.f;
+    return o;
+}
+
+// sin / cos for Fourier arguments |x| up to a few thousand: two-constant Cody-Waite reduction by
+// pi/2 (exact products through fma) + minimax polynomials on [-pi/4, pi/4]; abs error ~1e-7, i.e.
+// the same class as libm sinf, branch-free so it schedules between MFMAs.
+NSR_DEV void sincos_core(float x, float &s, float &c, int &q) {
+    const float k = rintf(x * 0.63661977236758134f);
+    float r = fmaf(k, -1.57079637050628662109375f, x);
+    r = fmaf(k, 4.37113900018624283e-8f, r);
+    q = (int)k;
+    const float r2 = r * r;
+    float ps = fmaf(r2, 2.72436227533035e-06f, -1.984003756660968e-04f);
+    ps = fmaf(ps, r2, 8.333331905305386e-03f);
+    ps = fmaf(ps, r2, -1.666666716337204e-01f);
+    s = fmaf(ps * r2, r, r);
+    float pc = fmaf(r2, 2.4457105610053986e-05f, -1.3887537643313408e-03f);
+    pc = fmaf(pc, r2, 4.166664928197861e-02f);
+    pc = fmaf(pc, r2, -0.5f);
+    c = fmaf(pc, r2, 1.f);
+}
+NSR_DEV float sin_acc(float x) {
+    float s, c; int q;
+    sincos_core(x, s, c, q);
+    const float v = (q & 1) ? c : s;
+    return (q & 2) ? -v : v;
+}
+NSR_DEV float cos_acc(float x) {
+    float s, c; int q;
+    sincos_core(x, s, c, q);
+    const float v = (q & 1) ? s : c;
+    return ((q + 1) & 2) ? -v : v;
+}
+
+NSR_DEV void embed(Act<kET> &e, const float *aux, float px, float py, float pz, int g) {
+#pragma unroll
+    for (int T = 0; T < kET; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const F4 b = ld4(aux + AUX_BM + (16 * T + 4 * g + r) * 4);
+            const float arg = fmaf(pz, b.z, fmaf(py, b.y, px * b.x));     // decoder.py:29
+            e.t[T][r] = sin_acc(arg);                                       // decoder.py:30
+            if (r == 3) sched_fence();      // bound the ILP the scheduler extracts from 24 independent sines
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoder forward for one tile.  KEEP keeps what the backward needs (h_i and relu masks).
+// ------------------------------------------------------------------------------------------------
+template <int KIND>
+struct Kept {
+    Act<2> h[5];
+    unsigned mask[5];
+};
+
+// MLP (decoder.py:177-203): h_i = relu(W_i x_i + b_i) + (U_i c + v_i), x_3 = [e | h_2]
+template <int KIND, bool KEEP>
+NSR_DEV void mlp_xyz_fwd(const float *__restrict__ pk, const float *aux, float px, float py, float pz,
+                         const Act<cdim_of(KIND) / 16> &c, int lane, float (&out)[nout_of(KIND)], Kept<KIND> *kept) {
+    constexpr int CD = cdim_of(KIND), NOUT = nout_of(KIND), NTC = CD / 16;
+    const int g = lane >> 4;
+    Act<kET> e;
+    embed(e, aux, px, py, pz, g);
+    Act<2> h;
+    act_zero(h);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        f32x4 acc[2];
+        acc[0] = to_v(ld4(aux + AUX_B + i * 32 + 4 * g));
+        acc[1] = to_v(ld4(aux + AUX_B + i * 32 + 16 + 4 * g));
+        if (i == 0) {
+            gemv_fwd<kET>(acc, e, pk + xyz_mat(CD, XW0).pk, lane);
+        } else if (i == 3) {
+            gemv_fwd<kET>(acc, e, pk + xyz_mat(CD, XW3E).pk, lane);
+            gemv_fwd<2>(acc, h, pk + xyz_mat(CD, XW3H).pk, lane);
+        } else {
+            gemv_fwd<2>(acc, h, pk + xyz_mat(CD, i == 1 ? XW1 : (i == 2 ? XW2 : XW4)).pk, lane);
+        }
+        const unsigned m = relu_mask(acc);
+        acc[0] += to_v(ld4(aux + AUX_V + i * 32 + 4 * g));
+        acc[1] += to_v(ld4(aux + AUX_V + i * 32 + 16 + 4 * g));
+        gemv_fwd<NTC>(acc, c, pk + xyz_mat(CD, i == 0 ? XU0 : (i == 1 ? XU1 : (i == 2 ? XU2 : (i == 3 ? XU3 : XU4)))).pk, lane);
+        h.t[0] = acc[0];
+        h.t[1] = acc[1];
+        if (KEEP) { kept->h[i] = h; kept->mask[i] = m; }
+    }
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) {
+        const F4 w0 = ld4(aux + AUX_WO + n * 32 + 4 * g), w1 = ld4(aux + AUX_WO + n * 32 + 16 + 4 * g);
+        float s = w0.x * h.t[0][0];
+        s = fmaf(w0.y, h.t[0][1], s); s = fmaf(w0.z, h.t[0][2], s); s = fmaf(w0.w, h.t[0][3], s);
+        s = fmaf(w1.x, h.t[1][0], s); s = fmaf(w1.y, h.t[1][1], s); s = fmaf(w1.z, h.t[1][2], s); s = fmaf(w1.w, h.t[1][3], s);
+        out[n] = red_g(s) + aux[AUX_BO + n];
+    }
+}
+
+// MLP_no_xyz (decoder.py:262-274): h = c; h = relu(W_i h + b_i); after i == 2: h = [c | h]
+template <bool KEEP>
+NSR_DEV void mlp_nox_fwd(const float *__restrict__ pk, const float *aux, const Act<2> &c, int lane, float (&out)[1], Kept<0> *kept) {
+    const int g = lane >> 4;
+    Act<2> h = c;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        f32x4 acc[2];
+        acc[0] = to_v(ld4(aux + AUX_B + i * 32 + 4 * g));
+        acc[1] = to_v(ld4(aux + AUX_B + i * 32 + 16 + 4 * g));
+        if (i == 3) {
+            gemv_fwd<2>(acc, c, pk + nox_mat(NW3C).pk, lane);
+            gemv_fwd<2>(acc, h, pk + nox_mat(NW3H).pk, lane);
+        } else {
+            gemv_fwd<2>(acc, h, pk + nox_mat(i == 0 ? NW0 : (i == 1 ? NW1 : (i == 2 ? NW2 : NW4))).pk, lane);
+        }
+        const unsigned m = relu_mask(acc);
+        h.t[0] = acc[0];
+        h.t[1] = acc[1];
+        if (KEEP) { kept->h[i] = h; kept->mask[i] = m; }
+    }
+    const F4 w0 = ld4(aux + AUX_WO + 4 * g), w1 = ld4(aux + AUX_WO + 16 + 4 * g);
+    float s = w0.x * h.t[0][0];
+    s = fmaf(w0.y, h.t[0][1], s); s = fmaf(w0.z, h.t[0][2], s); s = fmaf(w0.w, h.t[0][3], s);
+    s = fmaf(w1.x, h.t[1][0], s); s = fmaf(w1.y, h.t[1][1], s); s = fmaf(w1.z, h.t[1][2], s); s = fmaf(w1.w, h.t[1][3], s);
+    out[0] = red_g(s) + aux[AUX_BO];
+}
+
+// ------------------------------------------------------------------------------------------------
+// NICE.forward for the point of this lane (decoder.py:312-342) + the out-of-bound override of
+// Renderer.eval_points (Renderer.py:43-46,57).  Returns (r,g,b,occ); every lane of a point gets
+// the same value.
+// ------------------------------------------------------------------------------------------------
+template <int STAGE>
+NSR_DEV F4 decode_point(const RenderParams &P, const float *aux, double px, double py, double pz, int lane) {
+    const int g = lane >> 4;
+    const bool inside = (px > P.blo[0]) && (px < P.bhi[0]) && (py > P.blo[1]) && (py < P.bhi[1]) &&
+                        (pz > P.blo[2]) && (pz < P.bhi[2]);
+    F4 raw = F4{0.f, 0.f, 0.f, 0.f};
+    if (STAGE == NSR_STAGE_COARSE) {
+        const Lvl L = make_level(P.grid[NSR_COARSE], px, py, pz);
+        const Act<2> c = gather_feat(P.grid[NSR_COARSE], L, g);
+        float o[1];
+        mlp_nox_fwd<false>(P.dec[NSR_COARSE].packed, aux, c, lane, o, nullptr);
+        raw.w = o[0];
+    } else {
+        const float fx = (float)px, fy = (float)py, fz = (float)pz;     // decoder.py:189
+        const Lvl Lm = make_level(P.grid[NSR_MIDDLE], px, py, pz);
+        const Act<2> cm = gather_feat(P.grid[NSR_MIDDLE], Lm, g);
+        float om[1];
+        mlp_xyz_fwd<NSR_MIDDLE, false>(P.dec[NSR_MIDDLE].packed, aux, fx, fy, fz, cm, lane, om, nullptr);
+        float occ = om[0];
+        if (STAGE >= NSR_STAGE_FINE) {
+            const Lvl Lf = make_level(P.grid[NSR_FINE], px, py, pz);
+            const Act<2> cf = gather_feat(P.grid[NSR_FINE], Lf, g);
+            Act<4> cc;
+            cc.t[0] = cf.t[0]; cc.t[1] = cf.t[1]; cc.t[2] = cm.t[0]; cc.t[3] = cm.t[1];    // decoder.py:182-187
+            float of[1];
+            mlp_xyz_fwd<NSR_FINE, false>(P.dec[NSR_FINE].packed, aux + AUX_FLOATS, fx, fy, fz, cc, lane, of, nullptr);
+            occ = of[0] + om[0];                                                            // decoder.py:333,341
+        }
+        if (STAGE == NSR_STAGE_COLOR) {
+            const Lvl Lc = make_level(P.grid[NSR_COLOR], px, py, pz);
+            const Act<2> ccol = gather_feat(P.grid[NSR_COLOR], Lc, g);
+            float oc[4];
+            mlp_xyz_fwd<NSR_COLOR, false>(P.dec[NSR_COLOR].packed, aux + 2 * AUX_FLOATS, fx, fy, fz, ccol, lane, oc, nullptr);
+            raw.x = oc[0]; raw.y = oc[1]; raw.z = oc[2];
+        }
+        raw.w = occ;
+    }
+    if (!inside) raw.w = 100.f;
+    return raw;
+}
+
+template <int STAGE>
+NSR_DEV void load_stage_aux(const RenderParams &P, float *aux) {
+    if (STAGE == NSR_STAGE_COARSE) {
+        load_aux<NSR_COARSE>(aux, P.dec[NSR_COARSE].params);
+    } else {
+        load_aux<NSR_MIDDLE>(aux, P.dec[NSR_MIDDLE].params);
+        if (STAGE >= NSR_STAGE_FINE) load_aux<NSR_FINE>(aux + AUX_FLOATS, P.dec[NSR_FINE].params);
+        if (STAGE == NSR_STAGE_COLOR) load_aux<NSR_COLOR>(aux + 2 * AUX_FLOATS, P.dec[NSR_COLOR].params);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// compositor (common.py:231-244, occupancy branch), one wave per ray, lane = sample
+// ------------------------------------------------------------------------------------------------
+struct Comp { float alpha, T, w, t; };
+
+NSR_DEV Comp comp_weights(float occ, bool active, int lane) {
+    Comp c;
+    c.alpha = active ? 1.f / (1.f + expf(-(10.f * occ))) : 0.f;
+    c.t = active ? (1.f - c.alpha) + 1e-10f : 1.f;
+    float v = c.t;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = shfl_up(v, d);
+        if (lane >= d) v *= o;
+    }
+    float T = shfl_up(v, 1);
+    if (lane == 0) T = 1.f;
+    c.T = T;
+    c.w = c.alpha * T;
+    return c;
+}
+NSR_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += shfl_xor(v, d);
+    return v;
+}
+NSR_DEV double wave_sum_d(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += shfl_xor_d(v, d);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward kernel
+// LDS: aux[3*AUX] | ztmp[npts] f64 | zbuf[npts] f64 | rawbuf[npts] F4
+// ------------------------------------------------------------------------------------------------
+NSR_DEV int lds_fwd_floats(int npts) { return 3 * AUX_FLOATS + 4 * npts + 4 * npts; }
+
+template <int STAGE>
+NSR_KERNEL NSR_BOUNDS(768) void render_fwd_kernel(const RenderParams P) {
+    char *lds = lds_base();
+    const int npts = P.rays_per_block * P.S;
+    float *aux = reinterpret_cast<float *>(lds);
+    double *ztmp = reinterpret_cast<double *>(lds + sizeof(float) * (3 * AUX_FLOATS + (3 * AUX_FLOATS & 1)));
+    double *zbuf = ztmp + npts;
+    F4 *rawbuf = reinterpret_cast<F4 *>(zbuf + npts);
+    const int lane = tid() & 63, wave = tid() >> 6, nwaves = nthreads() >> 6;
+    const int S = P.S;
+
+    load_stage_aux<STAGE>(P, aux);
+    for (long long grp = bid_x(); grp < P.n_groups; grp += nblk_x()) {
+        loop_fence();       // weights are loop-invariant: keep LICM from hoisting ~250 operand loads into registers
+        const long long ray0 = grp * P.rays_per_block;
+        compute_z(P, ray0, ztmp, zbuf);            // ends with block_sync (also covers the aux load)
+        {   // decode the tile of this wave
+            const int pidx = wave * kTile + (lane & 15);
+            const int r = pidx / S, k = pidx - r * S;
+            const long long ray = ray0 + r;
+            const bool active = (pidx < npts) && (ray < P.n_rays);
+            const long long rr = active ? ray : 0;
+            const double z = active ? zbuf[pidx] : 0.0;
+            // pts = o + d*z in fp64 (Renderer.py:172-174)
+            const double px = (double)P.rays_o[rr * 3 + 0] + (double)P.rays_d[rr * 3 + 0] * z;
+            const double py = (double)P.rays_o[rr * 3 + 1] + (double)P.rays_d[rr * 3 + 1] * z;
+            const double pz = (double)P.rays_o[rr * 3 + 2] + (double)P.rays_d[rr * 3 + 2] * z;
+            const F4 raw = decode_point<STAGE>(P, aux, px, py, pz, lane);
+            if (active && (lane >> 4) == 0) {
+                rawbuf[pidx] = raw;
+                if (P.raw) st4(P.raw + (ray * S + k) * 4, raw);
+            }
+            (void)k;
+        }
+        block_sync();
+        for (int r = wave; r < P.rays_per_block; r += nwaves) {
+            const long long ray = ray0 + r;
+            if (ray >= P.n_rays) break;
+            const bool act = lane < S;
+            const F4 rw = act ? rawbuf[r * S + lane] : F4{0.f, 0.f, 0.f, 0.f};
+            const double z = act ? zbuf[r * S + lane] : 0.0;
+            const Comp c = comp_weights(rw.w, act, lane);
+            const float cr = wave_sum(c.w * rw.x), cg = wave_sum(c.w * rw.y), cb = wave_sum(c.w * rw.z);
+            const double depth = wave_sum_d((double)c.w * z);
+            const double dz = z - depth;
+            const double var = wave_sum_d(((double)c.w * dz) * dz);
+            if (lane == 0) {
+                P.depth[ray] = depth;
+                P.var[ray] = var;
+                P.rgb[ray * 3 + 0] = cr; P.rgb[ray * 3 + 1] = cg; P.rgb[ray * 3 + 2] = cb;
+            }
+        }
+        block_sync();
+    }
+}
+
+// Renderer.eval_points forward over a flat list of points (Renderer.py:23-61)
+template <int STAGE>
+NSR_KERNEL NSR_BOUNDS(512) void eval_points_kernel(const RenderParams P) {
+    float *aux = reinterpret_cast<float *>(lds_base());
+    const int lane = tid() & 63, wave = tid() >> 6, nwaves = nthreads() >> 6;
+    load_stage_aux<STAGE>(P, aux);
+    block_sync();
+    const long long ntiles = (P.n_points + kTile - 1) / kTile;
+    for (long long tile = (long long)bid_x() * nwaves + wave; tile < ntiles; tile += (long long)nblk_x() * nwaves) {
+        loop_fence();
+        const long long pi = tile * kTile + (lane & 15);
+        const bool active = pi < P.n_points;
+        const long long pp = active ? pi : 0;
+        const F4 raw = decode_point<STAGE>(P, aux, P.points[pp * 3 + 0], P.points[pp * 3 + 1], P.points[pp * 3 + 2], lane);
+        if (active && (lane >> 4) == 0) st4(P.out_points + pi * 4, raw);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of one decoder for one tile
+// ------------------------------------------------------------------------------------------------
+struct BwdFlags { bool grid, params, rays; };
+
+// one layer of the xyz-decoder backward (i = 4..0), instantiated per layer so that every register
+// array index is a compile-time constant
+template <int KIND>
+struct XyzBwd {
+    static constexpr int CD = cdim_of(KIND), NTC = CD / 16;
+    const float *__restrict__ flat;
+    const float *aux;
+    float *acc_lds, *TxA, *TxB;
+    float px, py, pz;
+    const Act<NTC> &c;
+    const Kept<KIND> &K;
+    BwdFlags F;
+    int lane;
+    Act<2> &dc;
+    Act<2> &dh;
+    Act<2> dY3, dY0;
+
+    template <int I>
+    NSR_DEV void layer() {
+        const int i16 = lane & 15, g = lane >> 4;
+        constexpr int uid = I == 0 ? XU0 : (I == 1 ? XU1 : (I == 2 ? XU2 : (I == 3 ? XU3 : XU4)));
+        constexpr int hid = I == 1 ? XW1 : (I == 2 ? XW2 : (I == 3 ? XW3H : XW4));
+        const Mat mu = xyz_mat(CD, uid);
+        // ---- fc_c branch: the gradient of (U_i c + v_i) is dh itself
+        if (F.params) {
+            f32x4 aH[2];
+            tx_store(TxA, dh, i16, g);
+            wave_fence();
+            aH[0] = tx_load_cm(TxA, 0, i16, g);
+            aH[1] = tx_load_cm(TxA, 1, i16, g);
+            db_tile(acc_lds, fcb_off(KIND, I), aH, i16, g);
+#pragma unroll
+            for (int q = 0; q < NTC / 2; ++q) {
+                Act<2> cq;
+                cq.t[0] = c.t[2 * q]; cq.t[1] = c.t[2 * q + 1];
+                dw_act32(acc_lds, mu, 2 * q, aH, TxB, cq, lane);
+            }
+            wave_fence();
+        }
+        if (F.grid || F.rays) gemv_bwd<2>(dc.t, dh, flat, mu, i16, g);     // first 32 feature columns only
+        // ---- main branch
+        const Act<2> dY = apply_mask(dh, K.mask[I]);
+        if (I == 3) dY3 = dY;
+        if (I == 0) dY0 = dY;
+        if (F.params) {
+            f32x4 aY[2];
+            tx_store(TxA, dY, i16, g);
+            wave_fence();
+            aY[0] = tx_load_cm(TxA, 0, i16, g);
+            aY[1] = tx_load_cm(TxA, 1, i16, g);
+            db_tile(acc_lds, bias_off(KIND, I), aY, i16, g);
+            if (I == 0 || I == 3) {
+                // x = embedding, produced directly in "lane = channel" form
+                const Mat me = xyz_mat(CD, I == 0 ? XW0 : XW3E);
+                float qx[4], qy[4], qz[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { qx[s] = shfl(px, 4 * s + g); qy[s] = shfl(py, 4 * s + g); qz[s] = shfl(pz, 4 * s + g); }
+#pragma unroll
+                for (int Tk = 0; Tk < kET; ++Tk) {
+                    const F4 b = ld4(aux + AUX_BM + (16 * Tk + i16) * 4);
+                    f32x4 xT;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) xT[s] = sin_acc(fmaf(qz[s], b.z, fmaf(qy[s], b.y, qx[s] * b.x)));
+                    dw_tile(acc_lds, me, Tk, aY, xT, i16, g);
+                }
+            }
+            if (I > 0) dw_act32(acc_lds, xyz_mat(CD, hid), 0, aY, TxB, K.h[I > 0 ? I - 1 : 0], lane);
+            wave_fence();
+        }
+        if (I > 0) {
+            Act<2> nd;
+            act_zero(nd);
+            gemv_bwd<2>(nd.t, dY, flat, xyz_mat(CD, hid), i16, g);
+            dh = nd;
+        }
+    }
+};
+
+// xyz decoder.  c: features (CL).  d_out: gradient of the decoder outputs of this lane's point.
+// dc: gradient w.r.t. the first 32 feature channels (the decoder's own grid).  dp: gradient w.r.t.
+// the fp32 world position through the embedding (already reduced over g).
+template <int KIND>
+NSR_DEV void mlp_xyz_bwd(const float *__restrict__ flat, const float *__restrict__ pk, const float *aux, float *acc_lds,
+                         float *TxA, float *TxB, float px, float py, float pz, const Act<cdim_of(KIND) / 16> &c,
+                         const float (&d_out)[nout_of(KIND)], BwdFlags F, int lane, Act<2> &dc, float (&dp)[3]) {
+    constexpr int CD = cdim_of(KIND), NOUT = nout_of(KIND), NTC = CD / 16;
+    const int i16 = lane & 15, g = lane >> 4;
+    Kept<KIND> K;
+    float out[NOUT];
+    mlp_xyz_fwd<KIND, true>(pk, aux, px, py, pz, c, lane, out, &K);
+    (void)out;
+
+    // output layer
+    Act<2> dh;
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+        f32x4 v = f4zero();
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) {
+            const F4 w = ld4(aux + AUX_WO + n * 32 + 16 * T + 4 * g);
+            v[0] = fmaf(w.x, d_out[n], v[0]); v[1] = fmaf(w.y, d_out[n], v[1]);
+            v[2] = fmaf(w.z, d_out[n], v[2]); v[3] = fmaf(w.w, d_out[n], v[3]);
+        }
+        dh.t[T] = v;
+    }
+    if (F.params) {
+        tx_store(TxB, K.h[4], i16, g);
+        wave_fence();
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) {
+            float dn[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) dn[s] = shfl(d_out[n], 4 * s + g);
+#pragma unroll
+            for (int Tk = 0; Tk < 2; ++Tk) {
+                const f32x4 xT = tx_load_cm(TxB, Tk, i16, g);
+                float s = dn[0] * xT[0];
+                s = fmaf(dn[1], xT[1], s); s = fmaf(dn[2], xT[2], s); s = fmaf(dn[3], xT[3], s);
+                s = red_g(s);
+                if (g == 0) atomic_add_lds(acc_lds + wo_off(KIND) + n * 32 + 16 * Tk + i16, s);
+            }
+            float b = (g == 0) ? d_out[n] : 0.f;
+            b = wave_sum(b);
+            if (lane == 0) atomic_add_lds(acc_lds + bo_off(KIND) + n, b);
+        }
+        wave_fence();
+    }
+
+    act_zero(dc);
+    XyzBwd<KIND> X{flat, aux, acc_lds, TxA, TxB, px, py, pz, c, K, F, lane, dc, dh};
+    act_zero(X.dY3);
+    act_zero(X.dY0);
+    X.template layer<4>();
+    X.template layer<3>();
+    X.template layer<2>();
+    X.template layer<1>();
+    X.template layer<0>();
+    const Act<2> dY3 = X.dY3, dY0 = X.dY0;
+
+    // ---- embedding: dE = W0^T dY0 + W3e^T dY3 ; d arg = dE * cos(arg)
+    dp[0] = dp[1] = dp[2] = 0.f;
+    const bool need_dB = F.params;
+    if (F.rays || need_dB) {
+        const Mat m0 = xyz_mat(CD, XW0), m3 = xyz_mat(CD, XW3E);
+        const Stream st0 = make_stream(flat + m0.off), st3 = make_stream(flat + m3.off);
+        float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+        for (int Tk = 0; Tk < kET; ++Tk) {
+            f32x4 dE = f4zero();
+            const int k = 16 * Tk + i16;
+#pragma unroll
+            for (int To = 0; To < 2; ++To)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float w0 = stream_ld(st0, 4 * g * m0.stride + i16, (16 * To + r) * m0.stride + 16 * Tk);
+                    const float w3 = stream_ld(st3, 4 * g * m3.stride + i16, (16 * To + r) * m3.stride + 16 * Tk);
+                    const float a0 = (k < kE) ? w0 : 0.f, a3 = (k < kE) ? w3 : 0.f;
+                    dE = mfma16(a0, dY0.t[To][r], dE);
+                    dE = mfma16(a3, dY3.t[To][r], dE);
+                }
+            f32x4 darg;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const F4 b = ld4(aux + AUX_BM + (16 * Tk + 4 * g + r) * 4);
+                const float arg = fmaf(pz, b.z, fmaf(py, b.y, px * b.x));
+                darg[r] = dE[r] * cos_acc(arg);
+                ax = fmaf(darg[r], b.x, ax); ay = fmaf(darg[r], b.y, ay); az = fmaf(darg[r], b.z, az);
+            }
+            if (need_dB) {
+                // dB[d][ch] += sum_pt darg[pt][ch] * p[pt][d]   (decoder.py:29: x @ B)
+                st4(TxA + i16 * kTxS + 4 * g, to_F4(darg));
+                wave_fence();
+                float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float v = TxA[(4 * s + g) * kTxS + i16];
+                    sx = fmaf(v, shfl(px, 4 * s + g), sx);
+                    sy = fmaf(v, shfl(py, 4 * s + g), sy);
+                    sz = fmaf(v, shfl(pz, 4 * s + g), sz);
+                }
+                sx = red_g(sx); sy = red_g(sy); sz = red_g(sz);
+                if (g == 0 && k < kE) {
+                    atomic_add_lds(acc_lds + B_off(KIND) + 0 * kE + k, sx);
+                    atomic_add_lds(acc_lds + B_off(KIND) + 1 * kE + k, sy);
+                    atomic_add_lds(acc_lds + B_off(KIND) + 2 * kE + k, sz);
+                }
+                wave_fence();
+            }
+        }
+        dp[0] = red_g(ax); dp[1] = red_g(ay); dp[2] = red_g(az);
+    }
+}
+
+struct NoxBwd {
+    const float *__restrict__ flat;
+    float *acc_lds, *TxA, *TxB;
+    const Act<2> &c;
+    const Kept<0> &K;
+    BwdFlags F;
+    int lane;
+    Act<2> &dc;
+    Act<2> &dh;
+
+    template <int I>
+    NSR_DEV void layer() {
+        const int i16 = lane & 15, g = lane >> 4;
+        const Act<2> dY = apply_mask(dh, K.mask[I]);
+        const Mat mh = nox_mat(I == 0 ? NW0 : (I == 1 ? NW1 : (I == 2 ? NW2 : (I == 3 ? NW3H : NW4))));
+        if (F.params) {
+            f32x4 aY[2];
+            tx_store(TxA, dY, i16, g);
+            wave_fence();
+            aY[0] = tx_load_cm(TxA, 0, i16, g);
+            aY[1] = tx_load_cm(TxA, 1, i16, g);
+            db_tile(acc_lds, nox_b(I), aY, i16, g);
+            if (I == 3) dw_act32(acc_lds, nox_mat(NW3C), 0, aY, TxB, c, lane);
+            dw_act32(acc_lds, mh, 0, aY, TxB, I == 0 ? c : K.h[I > 0 ? I - 1 : 0], lane);
+            wave_fence();
+        }
+        if (I == 3) gemv_bwd<2>(dc.t, dY, flat, nox_mat(NW3C), i16, g);
+        if (I == 0) {
+            gemv_bwd<2>(dc.t, dY, flat, mh, i16, g);
+        } else {
+            Act<2> nd;
+            act_zero(nd);
+            gemv_bwd<2>(nd.t, dY, flat, mh, i16, g);
+            dh = nd;
+        }
+    }
+};
+
+// coarse decoder backward (MLP_no_xyz)
+NSR_DEV void mlp_nox_bwd(const float *__restrict__ flat, const float *__restrict__ pk, const float *aux, float *acc_lds,
+                         float *TxA, float *TxB, const Act<2> &c, float d_out, BwdFlags F, int lane, Act<2> &dc) {
+    const int i16 = lane & 15, g = lane >> 4;
+    Kept<0> K;
+    float out[1];
+    mlp_nox_fwd<true>(pk, aux, c, lane, out, &K);
+    (void)out;
+    Act<2> dh;
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+        const F4 w = ld4(aux + AUX_WO + 16 * T + 4 * g);
+        f32x4 v = {w.x * d_out, w.y * d_out, w.z * d_out, w.w * d_out};
+        dh.t[T] = v;
+    }
+    if (F.params) {
+        tx_store(TxB, K.h[4], i16, g);
+        wave_fence();
+        float dn[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dn[s] = shfl(d_out, 4 * s + g);
+#pragma unroll
+        for (int Tk = 0; Tk < 2; ++Tk) {
+            const f32x4 xT = tx_load_cm(TxB, Tk, i16, g);
+            float s = dn[0] * xT[0];
+            s = fmaf(dn[1], xT[1], s); s = fmaf(dn[2], xT[2], s); s = fmaf(dn[3], xT[3], s);
+            s = red_g(s);
+            if (g == 0) atomic_add_lds(acc_lds + nox_wo() + 16 * Tk + i16, s);
+        }
+        float b = (g == 0) ? d_out : 0.f;
+        b = wave_sum(b);
+        if (lane == 0) atomic_add_lds(acc_lds + nox_bo(), b);
+        wave_fence();
+    }
+    act_zero(dc);
+    NoxBwd X{flat, acc_lds, TxA, TxB, c, K, F, lane, dc, dh};
+    X.layer<4>();
+    X.layer<3>();
+    X.layer<2>();
+    X.layer<1>();
+    X.layer<0>();
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward kernel.  grid = (blocks, passes); pass p handles one decoder:
+//   coarse stage: p0 = coarse.   otherwise: p0 = middle, p1 = fine, p2 = color.
+// LDS: aux[AUX] | acc[param_total] | ztmp f64[npts] | zbuf f64[npts] | draw F4[npts] | dpb f64[npts*3]
+//      | per-wave TxA, TxB
+// ------------------------------------------------------------------------------------------------
+template <int KIND>
+NSR_DEV void bwd_pass(const RenderParams &P) {
+    constexpr int NPAR = param_total(KIND);
+    char *lds = lds_base();
+    const int npts = P.rays_per_block * P.S, S = P.S;
+    const int lane = tid() & 63, wave = tid() >> 6, nwaves = nthreads() >> 6;
+    float *aux = reinterpret_cast<float *>(lds);
+    float *acc = aux + AUX_FLOATS;
+    constexpr int head = (AUX_FLOATS + NPAR + 3) & ~3;
+    double *ztmp = reinterpret_cast<double *>(aux + head);
+    double *zbuf = ztmp + npts;
+    F4 *draw = reinterpret_cast<F4 *>(zbuf + npts);
+    double *dpb = reinterpret_cast<double *>(draw + npts);
+    const int tx_off = (head * 4 + npts * (8 + 8 + 16 + 24) + 15) & ~15;
+    float *TxA = reinterpret_cast<float *>(lds + tx_off) + wave * (2 * kTile * kTxS);
+    float *TxB = TxA + kTile * kTxS;
+
+    const GridDev &G = P.grid[KIND];
+    const DecDev &D = P.dec[KIND];
+    BwdFlags F;
+    F.grid = G.dfeat != nullptr;
+    F.params = D.dparams != nullptr;
+    F.rays = P.d_rays_o != nullptr;
+    if (!F.grid && !F.params && !F.rays) return;
+
+    load_aux<KIND>(aux, D.params);
+    if (F.params) for (int t = tid(); t < NPAR; t += nthreads()) acc[t] = 0.f;
+
+    for (long long grp = bid_x(); grp < P.n_groups; grp += nblk_x()) {
+        loop_fence();       // weights are loop-invariant: keep LICM from hoisting ~250 operand loads into registers
+        const long long ray0 = grp * P.rays_per_block;
+        compute_z(P, ray0, ztmp, zbuf);
+        // ---- compositor backward: d raw per sample (common.py:231-244 differentiated)
+        for (int r = wave; r < P.rays_per_block; r += nwaves) {
+            const long long ray = ray0 + r;
+            if (ray >= P.n_rays) break;
+            const bool act = lane < S;
+            const F4 rw = act ? ld4(P.raw + (ray * S + lane) * 4) : F4{0.f, 0.f, 0.f, 0.f};
+            const double z = act ? zbuf[r * S + lane] : 0.0;
+            const Comp c = comp_weights(rw.w, act, lane);
+            const double gD = P.d_depth ? P.d_depth[ray] : 0.0;
+            const double gV = P.d_var ? P.d_var[ray] : 0.0;
+            float gr = 0.f, gg = 0.f, gb = 0.f;
+            if (P.d_rgb) { gr = P.d_rgb[ray * 3 + 0]; gg = P.d_rgb[ray * 3 + 1]; gb = P.d_rgb[ray * 3 + 2]; }
+            const double dz = z - P.g_depth[ray];
+            const double s1 = wave_sum_d((double)c.w * dz);
+            const float Gz = (float)(gD * z + gV * (dz * dz - 2.0 * s1 * z));
+            const float Gw = Gz + fmaf(gb, rw.z, fmaf(gg, rw.y, gr * rw.x));
+            float v = act ? Gw * c.w : 0.f;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const float o = shfl_down(v, d);
+                if (lane + d < 64) v += o;
+            }
+            float suffix = shfl_down(v, 1);
+            if (lane == 63) suffix = 0.f;
+            const float dalpha = Gw * c.T - suffix / c.t;
+            const float docc = 10.f * (dalpha * ((1.f - c.alpha) * c.alpha));
+            if (act) draw[r * S + lane] = F4{c.w * gr, c.w * gg, c.w * gb, docc};
+        }
+        block_sync();
+        {   // ---- decoder backward for the tile of this wave
+            const int pidx = wave * kTile + (lane & 15);
+            const int g = lane >> 4;
+            const int r = pidx / S;
+            const long long ray = ray0 + r;
+            const bool active = (pidx < npts) && (ray < P.n_rays);
+            const long long rr = active ? ray : 0;
+            const double z = active ? zbuf[pidx] : 0.0;
+            const double px = (double)P.rays_o[rr * 3 + 0] + (double)P.rays_d[rr * 3 + 0] * z;
+            const double py = (double)P.rays_o[rr * 3 + 1] + (double)P.rays_d[rr * 3 + 1] * z;
+            const double pz = (double)P.rays_o[rr * 3 + 2] + (double)P.rays_d[rr * 3 + 2] * z;
+            const bool inside = (px > P.blo[0]) && (px < P.bhi[0]) && (py > P.blo[1]) && (py < P.bhi[1]) &&
+                                (pz > P.blo[2]) && (pz < P.bhi[2]);
+            F4 dr = active ? draw[pidx] : F4{0.f, 0.f, 0.f, 0.f};
+            if (!inside) dr.w = 0.f;                               // Renderer.py:57 cuts the occupancy gradient
+            const Lvl L = make_level(G, px, py, pz);
+            const Act<2> c = gather_feat(G, L, g);
+            Act<2> dc;
+            float dpe[3] = {0.f, 0.f, 0.f};
+            if (KIND == NSR_COARSE) {
+                mlp_nox_bwd(D.params, D.packed, aux, acc, TxA, TxB, c, dr.w, F, lane, dc);
+            } else if (KIND == NSR_MIDDLE) {
+                float d_out[1] = {dr.w};
+                mlp_xyz_bwd<NSR_MIDDLE>(D.params, D.packed, aux, acc, TxA, TxB, (float)px, (float)py, (float)pz, c, d_out, F, lane, dc, dpe);
+            } else if (KIND == NSR_FINE) {
+                const Lvl Lm = make_level(P.grid[NSR_MIDDLE], px, py, pz);
+                const Act<2> cm = gather_feat(P.grid[NSR_MIDDLE], Lm, g);
+                Act<4> cc;
+                cc.t[0] = c.t[0]; cc.t[1] = c.t[1]; cc.t[2] = cm.t[0]; cc.t[3] = cm.t[1];
+                float d_out[1] = {dr.w};
+                mlp_xyz_bwd<NSR_FINE>(D.params, D.packed, aux, acc, TxA, TxB, (float)px, (float)py, (float)pz, cc, d_out, F, lane, dc, dpe);
+            } else {
+                float d_out[4] = {dr.x, dr.y, dr.z, 0.f};          // decoder.py:341 overwrites the 4th colour output
+                mlp_xyz_bwd<NSR_COLOR>(D.params, D.packed, aux, acc, TxA, TxB, (float)px, (float)py, (float)pz, c, d_out, F, lane, dc, dpe);
+            }
+            float dux = 0.f, duy = 0.f, duz = 0.f;
+            if (F.rays) scatter_feat<true>(G, L, g, dc, active, F.grid, dux, duy, duz);
+            else if (F.grid) scatter_feat<false>(G, L, g, dc, active, true, dux, duy, duz);
+            if (F.rays && active && g == 0) {
+                // d p = d u * (n-1)/2 * 2/(hi-lo)  (+ embedding part), fp64 like autograd through Renderer.py:172
+                dpb[pidx * 3 + 0] = (double)dux * (2.0 * G.inv[0]) + (double)dpe[0];
+                dpb[pidx * 3 + 1] = (double)duy * (2.0 * G.inv[1]) + (double)dpe[1];
+                dpb[pidx * 3 + 2] = (double)duz * (2.0 * G.inv[2]) + (double)dpe[2];
+            }
+        }
+        block_sync();
+        if (F.rays) {
+            for (int t = tid(); t < P.rays_per_block * 6; t += nthreads()) {
+                const int r = t / 6, q = t - r * 6, a = q % 3;
+                const long long ray = ray0 + r;
+                if (ray >= P.n_rays) continue;
+                double s = 0.0;
+                for (int k = 0; k < S; ++k) {
+                    const double d = dpb[(r * S + k) * 3 + a];
+                    s += (q < 3) ? d : d * zbuf[r * S + k];
+                }
+                atomic_add_global((q < 3 ? P.d_rays_o : P.d_rays_d) + ray * 3 + a, (float)s);
+            }
+        }
+        block_sync();
+    }
+    if (F.params) {
+        block_sync();
+        const int pass = bid_y();
+        float *dst = P.partials + ((long long)pass * nblk_x() + bid_x()) * P.partial_stride;
+        for (int t = tid(); t < NPAR; t += nthreads()) dst[t] = acc[t];
+    }
+}
+
+template <int STAGE>
+NSR_KERNEL NSR_BOUNDS(768) void render_bwd_kernel(const RenderParams P) {
+    if (STAGE == NSR_STAGE_COARSE) {
+        bwd_pass<NSR_COARSE>(P);
+    } else {
+        const int pass = bid_y();
+        if (pass == 0) bwd_pass<NSR_MIDDLE>(P);
+        else if (pass == 1) { if (STAGE >= NSR_STAGE_FINE) bwd_pass<NSR_FINE>(P); }
+        else { if (STAGE == NSR_STAGE_COLOR) bwd_pass<NSR_COLOR>(P); }
+    }
+}
+
+// sum the per-block partial parameter gradients:  dparams[t] += sum_b partials[b][t]
+NSR_KERNEL void reduce_partials_kernel(const float *__restrict__ partials, int nblocks, int stride, int n, float *__restrict__ dparams) {
+    const int t = bid_x() * nthreads() + tid();
+    if (t >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partials[(long long)b * stride + t];
+    dparams[t] += s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// get_samples after the index draw (common.py:74-134)
+// ------------------------------------------------------------------------------------------------
+struct SampleParams {
+    const long long *indices;
+    long long n;
+    int H0, W0, crop_w, W_full;
+    float fx, fy, cx, cy;
+    const float *c2w;
+    int c2w_stride;
+    const float *depth, *color;
+    float *rays_o, *rays_d, *out_depth, *out_color;
+};
+
+NSR_KERNEL void get_samples_kernel(const SampleParams P) {
+    const long long t = (long long)bid_x() * nthreads() + tid();
+    if (t >= P.n) return;
+    const long long idx = P.indices[t];
+    const int row = (int)(idx / P.crop_w) + P.H0, col = (int)(idx % P.crop_w) + P.W0;
+    const long long pix = (long long)row * P.W_full + col;
+    P.out_depth[t] = P.depth[pix];
+    P.out_color[t * 3 + 0] = P.color[pix * 3 + 0];
+    P.out_color[t * 3 + 1] = P.color[pix * 3 + 1];
+    P.out_color[t * 3 + 2] = P.color[pix * 3 + 2];
+    const float dx = ((float)col - P.cx) / P.fx, dy = -(((float)row - P.cy) / P.fy), dzv = -1.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float *R = P.c2w + a * P.c2w_stride;
+        // torch.sum(dirs * c2w[:3,:3], -1): products, then left-to-right sum (common.py:87)
+        P.rays_d[t * 3 + a] = (dx * R[0] + dy * R[1]) + dzv * R[2];
+        P.rays_o[t * 3 + a] = R[3];
+    }
+}
+
+}  // namespace nsr
