@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- rendered rays/s (forward + backward) of the NICE-SLAM mapping render hot path on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 launched under
+torch.distributed.run, one rank per GPU.  One STEP = one mapping iteration's pass of the hot path over one
+ray batch of BASELINE configs[1] (Replica room0 full config): get_samples for the 5-keyframe window ->
+render_batch_ray -> mapping loss -> backward (grid, decoder and nothing else; no optimiser: Adam and the
+masked write-back belong to the unchanged caller).  The stage of step i follows the reference
+schedule of a 60-iteration frame batch (25 middle / 12 fine / 23 color, src/Mapper.py:403-410), so the
+default K=60 reproduces the Replica mapping mix exactly.  Prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+RAYS_PER_GPU = 1000            # mapping.pixels (configs/Replica/replica.yaml)
+WINDOW = 5                     # mapping_window_size -> 5 x 200 pixels
+FP32_PEAK = 157.3e12           # MI355X dense fp32 MFMA peak (MI355X_MICROARCH.md)
+# necessary backward FLOP per ray of the dominant kernel (color-stage backward): SURVEY §8(d)
+#   (106 140 - 51 653) MAC/pt * 2 FLOP * 48 pts  (dX chain + stepped dW + d-embedding; the forward is a separate launch)
+BWD_COLOR_FLOP_PER_RAY = (106140 - 51653) * 2 * 48
+FWD_FLOP_PER_RAY = {"middle": 15479 * 2 * 48, "fine": 36078 * 2 * 48, "color": 51653 * 2 * 48}
+
+
+def stage_of(it, n=60):
+    it = it % n
+    return "middle" if it <= int(n * 0.4) else ("fine" if it <= int(n * 0.6) else "color")
+
+
+class HipEvents:
+    """Raw hipEvent pairs (the kernels run on torch's current stream, recorded inside nsr_render_bwd)."""
+
+    def __init__(self):
+        self.hip = ctypes.CDLL("libamdhip64.so.7")      # already mapped by torch: same runtime instance
+        self.pairs = {}
+
+    def new(self):
+        e = ctypes.c_void_p()
+        assert self.hip.hipEventCreate(ctypes.byref(e)) == 0
+        return e
+
+    def pair_for(self, stage):
+        p = (self.new(), self.new())
+        self.pairs.setdefault(stage, []).append(p)
+        return p[0], p[1]
+
+    def summary(self):
+        out = {}
+        for stage, pairs in self.pairs.items():
+            ms = []
+            for a, b in pairs:
+                t = ctypes.c_float()
+                if self.hip.hipEventElapsedTime(ctypes.byref(t), a, b) == 0:
+                    ms.append(t.value)
+            if ms:
+                out[stage] = (sum(ms) / len(ms), len(ms))
+        return out
+
+
+def cpu_baseline(sc, reps=1):
+    """The CPU oracle (a torch restatement of the reference path, kind='port') on this box's host cores,
+    one forward+backward per stage on the same 1000-ray workload, stage-weighted like the GPU run."""
+    from scene_util import oracle_render
+    t = {}
+    for stage in ("middle", "fine", "color"):
+        oracle_render(sc, stage, backward=True, rays=slice(0, 64))       # warm-up
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            oracle_render(sc, stage, backward=True)
+        t[stage] = (time.perf_counter() - t0) / reps
+    n = sc["rays_o"].shape[0]
+    mix = (25 * t["middle"] + 12 * t["fine"] + 23 * t["color"]) / 60.0
+    return {"value": n / mix, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle fwd+bwd, {n} rays, 1 iter per stage (middle {t['middle']*1e3:.0f} ms, fine {t['fine']*1e3:.0f} ms, "
+                      f"color {t['color']*1e3:.0f} ms), weighted 25/12/23"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage", default=None, help="pin every step to one stage (profiling)")
+    ap.add_argument("--rays", type=int, default=RAYS_PER_GPU)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from scene_util import make_scene, build_product
+    import nice_slam_amd as nsa
+    from nice_slam_amd.parallel import ShardedRenderer
+
+    n_total = args.rays * world                                   # weak scaling: fixed rays per GPU
+    sc = make_scene(seed=0, n_rays=args.rays, scene="replica_room0", fine_scale=1.0, zero_frac=0.01, depth_range=(1.0, 4.0))
+    renderer, dec, grids = build_product(sc, dev)
+    grids = {k: v.requires_grad_(True) for k, v in grids.items()}
+    for n_, p in dec.named_parameters():                          # reference: every decoder parameter has requires_grad=True
+        p.requires_grad_(True)
+    H, W, fx, fy, cx, cy = sc["intr"]
+    depth_img, color_img, c2w = sc["depth_img"].to(dev), sc["color_img"].to(dev), sc["c2w"].to(dev)
+    ev = HipEvents()
+    renderer.profile_events = ev.pair_for
+    rend = ShardedRenderer(renderer) if world > 1 else renderer
+    torch.manual_seed(1234)                                       # identical index draws on every rank
+    per_frame = n_total // WINDOW
+
+    def step(it, timed):
+        stage = args.stage or stage_of(it)
+        ro, rd, gd, gc = [], [], [], []
+        for _ in range(WINDOW):
+            o, d, dep, col = nsa.get_samples(0, H, 0, W, per_frame, H, W, fx, fy, cx, cy, c2w, depth_img, color_img, dev)
+            ro.append(o); rd.append(d); gd.append(dep); gc.append(col)
+        rays_o, rays_d, gt_depth, gt_color = torch.cat(ro), torch.cat(rd), torch.cat(gd), torch.cat(gc)
+        for g in grids.values():
+            g.grad = None
+        for p in dec.parameters():
+            p.grad = None
+        if not timed:
+            renderer.profile_events = None
+        depth, unc, color = rend.render_batch_ray(grids, dec, rays_d, rays_o, dev, stage, gt_depth=gt_depth)
+        mask = gt_depth > 0
+        loss = torch.abs(gt_depth - depth)[mask].sum()            # src/Mapper.py:487-489
+        if stage == "color":
+            loss = loss + 0.2 * torch.abs(gt_color - color).sum()  # :490-493
+        loss.backward()
+        renderer.profile_events = ev.pair_for
+        return stage
+
+    for i in range(args.warmup):
+        step(i, False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stages = [step(i, True) for i in range(args.steps)]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        ksum = ev.summary()
+        res = {
+            "metric": "rendered rays/sec (fwd+bwd) per mapping iter", "value": n_total * args.steps / dt, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f64 sample placement / depth)",
+            "data": "synthetic",
+            "config": {"workload": "Replica room0 full config (BASELINE configs[1]): grids 21x28x37 / 43x56x74 x2, 32 ch fp32, "
+                                   "random-init decoders, 680x1200 synthetic RGB-D, 5x200 pixels/iter, S=32+16",
+                       "rays_per_gpu": args.rays, "stage_mix": {s: stages.count(s) for s in sorted(set(stages))},
+                       "timed_region": "get_samples + render_batch_ray + mapping loss + backward (all decoder/grid grads), no optimiser",
+                       "parallelism": f"ray-sharded x{world}, dense RCCL all-reduce of grid grads" if world > 1 else "single GPU"},
+        }
+        if "color" in ksum:
+            ms, cnt = ksum["color"]
+            rays_launch = args.rays
+            ach = rays_launch * BWD_COLOR_FLOP_PER_RAY / (ms * 1e-3)
+            res["roofline"] = {"bound": "mfma", "kernel": "render_bwd_kernel<color>", "achieved": ach / 1e12, "peak": FP32_PEAK / 1e12,
+                               "unit": "TFLOP/s", "frac": ach / FP32_PEAK, "traffic": None,
+                               "avg_kernel_ms": ms, "launches": cnt,
+                               "algorithmic_flop_per_launch": rays_launch * BWD_COLOR_FLOP_PER_RAY}
+        res["kernel_ms"] = {f"render_bwd<{s}>": round(v[0], 4) for s, v in ksum.items()}
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(sc)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

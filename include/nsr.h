@@ -93,6 +93,8 @@ typedef struct nsr_bwd_args {
     int64_t workspace_floats;
     int32_t max_blocks;       /* persistent-grid cap used to size the workspace (0 = library default) */
     int32_t pad_;
+    void *ev_start;           /* optional hipEvent_t pair recorded on `stream` right before / after the main   */
+    void *ev_stop;            /* backward kernel (excludes the small partial-sum kernels); NULL = no timing      */
 } nsr_bwd_args;
 
 int nsr_version(void);

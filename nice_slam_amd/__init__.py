@@ -1,0 +1,13 @@
+"""nice_slam_amd -- MI355X-native (gfx950, HIP) implementation of the NICE-SLAM volume-rendering hot
+path, drop-in behind the reference's Renderer / decoder / get_samples call surface.
+
+    from nice_slam_amd import Renderer, NICE, get_samples, grid_init, load_bound
+
+No CPU / PyTorch fallback exists: every arithmetic entry point goes through libnsr.so.
+"""
+from .common import get_samples, get_rays, grid_init, load_bound, to_channels_last  # noqa: F401
+from .decoders import NICE, MLP, MLP_no_xyz  # noqa: F401
+from .renderer import Renderer  # noqa: F401
+
+__all__ = ["Renderer", "NICE", "MLP", "MLP_no_xyz", "get_samples", "get_rays", "grid_init", "load_bound",
+           "to_channels_last"]

@@ -9,6 +9,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- must be loaded first: libnsr.so binds to the HIP runtime (libamdhip64.so.7) torch already mapped
+
 MAX_SAMPLES = 64
 STAGE_ID = {"coarse": 0, "middle": 1, "fine": 2, "color": 3}
 SLOT_NAMES = ("coarse", "middle", "fine", "color")
@@ -41,7 +43,8 @@ class NsrBwdArgs(C.Structure):
     _fields_ = [("d_depth", C.c_void_p), ("d_var", C.c_void_p), ("d_rgb", C.c_void_p), ("depth", C.c_void_p),
                 ("d_rays_o", C.c_void_p), ("d_rays_d", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
-                ("max_blocks", C.c_int32), ("pad_", C.c_int32)]
+                ("max_blocks", C.c_int32), ("pad_", C.c_int32),
+                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
 
 
 # every symbol include/nsr.h declares: (name, restype, argtypes)

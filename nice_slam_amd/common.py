@@ -1,0 +1,146 @@
+"""Host-side mirror of the reference's ray helpers and scene-geometry setup.
+
+get_samples / get_rays : src/common.py:74-134, 248-266
+load_bound / grid_init : src/NICE_SLAM.py:137-157, 192-250  (grids are allocated channels-last)
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _capi
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise _capi.NsrError(f"{what} must live on an AMD GPU (got {t.device}); nice_slam_amd has no CPU path")
+
+
+# --------------------------------------------------------------------------------------------------
+# scene geometry
+# --------------------------------------------------------------------------------------------------
+def load_bound(cfg: dict, scale: Optional[float] = None) -> torch.Tensor:
+    """src/NICE_SLAM.py:137-150: scene bound (3,2) fp64, upper corner enlarged to a multiple of
+    ``grid_len.bound_divisible``."""
+    scale = cfg["scale"] if scale is None else scale
+    bound = torch.from_numpy(np.array(cfg["mapping"]["bound"], dtype=np.float64) * scale)
+    div = cfg["grid_len"]["bound_divisible"]
+    bound[:, 1] = (((bound[:, 1] - bound[:, 0]) / div).int() + 1) * div + bound[:, 0]
+    return bound
+
+
+def set_decoder_bounds(decoders, bound: torch.Tensor, coarse_bound_enlarge: float = 2.0):
+    """src/NICE_SLAM.py:151-157."""
+    decoders.bound = bound
+    decoders.middle_decoder.bound = bound
+    decoders.fine_decoder.bound = bound
+    decoders.color_decoder.bound = bound
+    if hasattr(decoders, "coarse_decoder"):
+        decoders.coarse_decoder.bound = bound * coarse_bound_enlarge
+
+
+def grid_shapes(cfg: dict, bound: torch.Tensor) -> Dict[str, Tuple[int, int, int]]:
+    """Cells per axis, (Z,Y,X) order (src/NICE_SLAM.py:211-246)."""
+    xyz_len = bound[:, 1] - bound[:, 0]
+    out = {}
+    names = (("coarse",) if cfg.get("coarse", True) else ()) + ("middle", "fine", "color")
+    for name in names:
+        ext = xyz_len * cfg["model"]["coarse_bound_enlarge"] if name == "coarse" else xyz_len
+        nx, ny, nz = (int(v) for v in (ext / cfg["grid_len"][name]).tolist())
+        out["grid_" + name] = (nz, ny, nx)
+    return out
+
+
+def to_channels_last(grid: torch.Tensor) -> torch.Tensor:
+    """Logical [1,C,Z,Y,X] tensor whose memory is [Z][Y][X][C] (what the kernels read).  No-op if it already is."""
+    return grid.contiguous(memory_format=torch.channels_last_3d)
+
+
+def grid_init(cfg: dict, bound: torch.Tensor, device="cpu") -> Dict[str, torch.Tensor]:
+    """src/NICE_SLAM.py:192-250 with the same init statistics (normal std 0.01, fine 1e-4), allocated in
+    torch.channels_last_3d so that a voxel's 32 channels are one 128-byte line."""
+    c_dim = cfg["model"]["c_dim"]
+    out = {}
+    for key, zyx in grid_shapes(cfg, bound).items():
+        std = 1e-4 if key == "grid_fine" else 1e-2
+        val = torch.zeros((1, c_dim) + tuple(zyx)).normal_(mean=0, std=std)
+        out[key] = to_channels_last(val.to(device))
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# rays
+# --------------------------------------------------------------------------------------------------
+class _GetSamplesFn(torch.autograd.Function):
+    """indices -> (rays_o, rays_d, depth, color); differentiable w.r.t. c2w (tracking / BA)."""
+
+    @staticmethod
+    def forward(ctx, c2w, indices, depth, color, H0, H1, W0, W1, fx, fy, cx, cy):
+        lib = _capi.get_lib()
+        n = indices.shape[0]
+        dev = depth.device
+        rays_o = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        rays_d = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        s_depth = torch.empty((n,), dtype=torch.float32, device=dev)
+        s_color = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        c2w_c = c2w.detach().to(device=dev, dtype=torch.float32).contiguous()
+        lib.check(lib.nsr_get_samples(indices.data_ptr(), n, H0, H1, W0, W1, depth.shape[1], fx, fy, cx, cy,
+                                      c2w_c.data_ptr(), c2w_c.stride(0), depth.data_ptr(), color.data_ptr(),
+                                      rays_o.data_ptr(), rays_d.data_ptr(), s_depth.data_ptr(), s_color.data_ptr(),
+                                      _stream(dev)), "nsr_get_samples")
+        ctx.geom = (H0, W0, W1 - W0, fx, fy, cx, cy, tuple(c2w.shape), c2w.dtype, c2w.device)
+        ctx.save_for_backward(indices)
+        ctx.mark_non_differentiable(s_depth, s_color)
+        return rays_o, rays_d, s_depth, s_color
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_o, g_d, _gd, _gc):
+        (indices,) = ctx.saved_tensors
+        H0, W0, w, fx, fy, cx, cy, shape, dtype, dev = ctx.geom
+        col = (indices % w + W0).to(torch.float32)
+        row = (torch.div(indices, w, rounding_mode="floor") + H0).to(torch.float32)
+        dirs = torch.stack([(col - cx) / fx, -(row - cy) / fy, -torch.ones_like(col)], -1)
+        g = torch.zeros(shape, dtype=torch.float32, device=g_d.device)
+        g[:3, :3] = g_d.t() @ dirs                       # rays_d[n,a] = sum_k dirs[n,k] * c2w[a,k]
+        g[:3, 3] = g_o.sum(0)                            # rays_o[n,a] = c2w[a,3]
+        return (g.to(device=dev, dtype=dtype),) + (None,) * 11
+
+
+def get_samples(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, c2w, depth, color, device):
+    """Drop-in for src/common.py:125-134.  The index draw is the reference's own call
+    (``torch.randint(h*w, (n,), device=device)``, common.py:99) so the RNG stream is consumed identically;
+    everything after the draw is one fused kernel."""
+    if isinstance(c2w, np.ndarray):
+        c2w = torch.from_numpy(c2w).to(device)
+    depth = depth.to(device=device)
+    color = color.to(device=device)
+    _require_cuda(depth, "get_samples: depth image")
+    indices = torch.randint((H1 - H0) * (W1 - W0), (n,), device=device)
+    return samples_from_indices(indices, H0, H1, W0, W1, fx, fy, cx, cy, c2w, depth, color)
+
+
+def samples_from_indices(indices, H0, H1, W0, W1, fx, fy, cx, cy, c2w, depth, color):
+    depth = depth.to(torch.float32).contiguous()
+    color = color.to(torch.float32).contiguous()
+    return _GetSamplesFn.apply(c2w, indices.contiguous(), depth, color, int(H0), int(H1), int(W0), int(W1),
+                               float(fx), float(fy), float(cx), float(cy))
+
+
+def get_rays(H, W, fx, fy, cx, cy, c2w, device):
+    """src/common.py:248-266: rays for a whole image (used by render_img, forward only)."""
+    if isinstance(c2w, np.ndarray):
+        c2w = torch.from_numpy(c2w)
+    c2w = c2w.to(device)
+    i, j = torch.meshgrid(torch.linspace(0, W - 1, W, device=device), torch.linspace(0, H - 1, H, device=device), indexing="ij")
+    i, j = i.t(), j.t()
+    dirs = torch.stack([(i - cx) / fx, -(j - cy) / fy, -torch.ones_like(i)], -1).reshape(H, W, 1, 3)
+    rays_d = torch.sum(dirs * c2w[:3, :3], -1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d

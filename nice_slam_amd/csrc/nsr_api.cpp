@@ -186,8 +186,10 @@ int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream
         if (int rc = launch_cfg(nsr::render_bwd_kernel<ST>, lds, "nsr_render_bwd")) return rc;    \
         NSR_LAUNCH(nsr::render_bwd_kernel<ST>, grid, block, lds, stream, P);                      \
         break;
+    if (b->ev_start) nsr::rt_record(b->ev_start, stream);
     switch (P.stage) { NSR_BWD(0) NSR_BWD(1) NSR_BWD(2) NSR_BWD(3) }
 #undef NSR_BWD
+    if (b->ev_stop) nsr::rt_record(b->ev_stop, stream);
     if (int rc = finish("nsr_render_bwd")) return rc;
     if (any_params) {
         const int first = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE;

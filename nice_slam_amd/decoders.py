@@ -1,0 +1,207 @@
+"""Decoder modules with the reference's attribute / state_dict surface, stored as ONE flat fp32 blob
+per decoder so the kernels can read them without any per-call gathering.
+
+Reference: src/conv_onet/models/decoder.py (MLP :91-203, MLP_no_xyz :206-274, NICE :277-342).
+The arithmetic lives in libnsr.so; these classes only own parameters.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _capi
+from .layout import param_spec, stage_slots
+
+
+class _Holder(nn.Module):
+    """A leaf module that only carries Parameters (stands in for nn.Linear / DenseLayer / the embedder)."""
+
+    def forward(self, *a, **k):
+        raise RuntimeError("nice_slam_amd decoders are evaluated by the fused HIP kernels; sub-layers are not callable")
+
+
+class _FlatDecoder(nn.Module):
+    """Common machinery: every Parameter is a view into ``self._flat`` (reference named_parameters() order)."""
+
+    slot = ""
+
+    def __init__(self, name: str):
+        super().__init__()
+        self.name = name
+        self.bound: Optional[torch.Tensor] = None          # set by the system, src/NICE_SLAM.py:152-157
+        self._spec = param_spec(self.slot)
+        self._flat = torch.zeros(sum(math.prod(s) for _, s in self._spec), dtype=torch.float32)
+        self._grad_flat: Optional[torch.Tensor] = None
+        self._packed = None                                 # (key, tensor) cache of the MFMA operand stream
+        self._build_modules()
+        self.reset_parameters()
+
+    # -- structure ---------------------------------------------------------------------------------
+    def _build_modules(self):
+        names = [n for n, _ in self._spec]
+        # attribute order == reference registration order, so named_parameters() matches decoder.py
+        if any(n.startswith("fc_c.") for n in names):
+            self.fc_c = nn.ModuleList([_Holder() for _ in range(5)])
+        if "embedder._B" in names:
+            self.embedder = _Holder()
+        self.pts_linears = nn.ModuleList([_Holder() for _ in range(5)])
+        self.output_linear = _Holder()
+        off = 0
+        self._views: List[nn.Parameter] = []
+        self._offsets: List[int] = []
+        for pname, shape in self._spec:
+            n = math.prod(shape)
+            p = nn.Parameter(self._flat[off:off + n].view(shape))
+            mod = self
+            parts = pname.split(".")
+            for part in parts[:-1]:
+                mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
+            mod.register_parameter(parts[-1], p)
+            self._views.append(p)
+            self._offsets.append(off)
+            off += n
+
+    def reset_parameters(self):
+        """Same init statistics as the reference (DenseLayer xavier/zero bias decoder.py:75-79, default
+        nn.Linear init for fc_c, randn*25 for the Fourier matrix :21-22)."""
+        with torch.no_grad():
+            for (pname, shape), p in zip(self._spec, self._views):
+                if pname.startswith("fc_c"):
+                    fan_in = self._spec_shape(pname.rsplit(".", 1)[0] + ".weight")[1]
+                    bound = 1.0 / math.sqrt(fan_in)
+                    if pname.endswith("weight"):
+                        nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+                    else:
+                        nn.init.uniform_(p, -bound, bound)
+                elif pname == "embedder._B":
+                    p.copy_(torch.randn(shape) * 25.0)
+                elif pname.endswith("weight"):
+                    gain = 1.0 if pname.startswith("output_linear") else nn.init.calculate_gain("relu")
+                    nn.init.xavier_uniform_(p, gain=gain)
+                else:
+                    p.zero_()
+
+    def _spec_shape(self, pname):
+        return dict(self._spec)[pname]
+
+    # -- flat storage ------------------------------------------------------------------------------
+    def flat_params(self) -> torch.Tensor:
+        """The flat blob; re-establishes the view relationship if something (``.to()``, deepcopy,
+        ``share_memory``) replaced the Parameters' storage since the last call."""
+        f = self._flat
+        p0, pl = self._views[0], self._views[-1]
+        ok = (p0.device == f.device and p0.data_ptr() == f.data_ptr()
+              and pl.data_ptr() == f.data_ptr() + 4 * self._offsets[-1])
+        if not ok:
+            dev = p0.device
+            with torch.no_grad():
+                f = torch.cat([p.detach().reshape(-1).to(device=dev, dtype=torch.float32) for p in self._views])
+            for p, off in zip(self._views, self._offsets):
+                p.data = f[off:off + p.numel()].view(p.shape)
+            self._flat = f
+            self._grad_flat = None
+            self._packed = None
+        return self._flat
+
+    def packed_params(self, lib, stream) -> torch.Tensor:
+        f = self.flat_params()
+        key = (f.data_ptr(), f._version, f.device)
+        if self._packed is None or self._packed[0] != key:
+            slot = _capi.SLOT_NAMES.index(self.slot)
+            pk = torch.empty(lib.nsr_packed_count(slot), dtype=torch.float32, device=f.device)
+            lib.check(lib.nsr_pack_params(slot, f.data_ptr(), pk.data_ptr(), stream), "nsr_pack_params")
+            self._packed = (key, pk)
+        return self._packed[1]
+
+    def wants_grad(self) -> bool:
+        return any(p.requires_grad for p in self._views)
+
+    def publish_grads(self, gflat: torch.Tensor):
+        """Expose a freshly computed flat gradient as the ``.grad`` of every Parameter (views, no copies)."""
+        for p, off in zip(self._views, self._offsets):
+            if not p.requires_grad:
+                continue
+            g = gflat[off:off + p.numel()].view(p.shape)
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad = p.grad + g
+
+    def __deepcopy__(self, memo):
+        # Tracker.update_para_from_mapping deep-copies the decoders (src/Tracker.py:138)
+        new = self.__class__.__new__(self.__class__)
+        nn.Module.__init__(new)
+        new.name, new.bound = self.name, (None if self.bound is None else self.bound.clone())
+        new._spec = self._spec
+        new._flat = self.flat_params().detach().clone()
+        new._grad_flat, new._packed = None, None
+        new._build_modules()
+        for a, b in zip(new._views, self._views):
+            a.requires_grad_(b.requires_grad)
+        for k, v in self.__dict__.items():
+            if k not in new.__dict__ and not k.startswith("_"):
+                new.__dict__[k] = v
+        return new
+
+    def forward(self, p, c_grid=None, **kwargs):
+        raise RuntimeError("call NICE.forward / Renderer.eval_points: single decoders are evaluated inside the fused kernels")
+
+
+class MLP(_FlatDecoder):
+    """decoder.py:91-203 (c_dim 32 or 64, 93-wide Gaussian Fourier embedding, 5 blocks, skip at 2)."""
+
+    def __init__(self, name="", dim=3, c_dim=32, hidden_size=32, n_blocks=5, leaky=False, sample_mode="bilinear",
+                 color=False, skips=(2,), grid_len=0.16, pos_embedding_method="fourier", concat_feature=False):
+        if (dim, hidden_size, n_blocks, tuple(skips), pos_embedding_method, sample_mode, leaky) != \
+                (3, 32, 5, (2,), "fourier", "bilinear", False):
+            raise NotImplementedError("only the NICE-SLAM decoder configuration is implemented (SURVEY §2: iMAP* out of scope)")
+        self.slot = "color" if color else ("fine" if concat_feature else "middle")
+        if c_dim != (64 if concat_feature else 32):
+            raise NotImplementedError("c_dim must be 32 (64 for the concat-feature fine decoder)")
+        self.color, self.c_dim, self.grid_len, self.concat_feature = color, c_dim, grid_len, concat_feature
+        self.n_blocks, self.skips, self.no_grad_feature, self.sample_mode = n_blocks, list(skips), False, sample_mode
+        super().__init__(name)
+
+
+class MLP_no_xyz(_FlatDecoder):
+    """decoder.py:206-274 (the coarse decoder)."""
+    slot = "coarse"
+
+    def __init__(self, name="", dim=3, c_dim=32, hidden_size=32, n_blocks=5, leaky=False, sample_mode="bilinear",
+                 color=False, skips=(2,), grid_len=0.16):
+        if (dim, c_dim, hidden_size, n_blocks, tuple(skips), color, leaky) != (3, 32, 32, 5, (2,), False, False):
+            raise NotImplementedError("only the NICE-SLAM coarse decoder configuration is implemented")
+        self.color, self.c_dim, self.grid_len = color, c_dim, grid_len
+        self.n_blocks, self.skips, self.no_grad_feature, self.sample_mode = n_blocks, list(skips), False, sample_mode
+        super().__init__(name)
+
+
+class NICE(nn.Module):
+    """decoder.py:277-342.  ``forward(p, c_grid, stage)`` is the point query used by the reference's
+    Renderer.eval_points / Mesher.eval_points: (1,M,3) or (M,3) points -> (M,4) [rgb, occupancy]."""
+
+    def __init__(self, dim=3, c_dim=32, coarse_grid_len=2.0, middle_grid_len=0.16, fine_grid_len=0.16,
+                 color_grid_len=0.16, hidden_size=32, coarse=False, pos_embedding_method="fourier"):
+        super().__init__()
+        self.bound: Optional[torch.Tensor] = None
+        if coarse:
+            self.coarse_decoder = MLP_no_xyz(name="coarse", dim=dim, c_dim=c_dim, color=False,
+                                             hidden_size=hidden_size, grid_len=coarse_grid_len)
+        self.middle_decoder = MLP(name="middle", dim=dim, c_dim=c_dim, color=False, hidden_size=hidden_size,
+                                  grid_len=middle_grid_len, pos_embedding_method=pos_embedding_method)
+        self.fine_decoder = MLP(name="fine", dim=dim, c_dim=c_dim * 2, color=False, hidden_size=hidden_size,
+                                grid_len=fine_grid_len, concat_feature=True, pos_embedding_method=pos_embedding_method)
+        self.color_decoder = MLP(name="color", dim=dim, c_dim=c_dim, color=True, hidden_size=hidden_size,
+                                 grid_len=color_grid_len, pos_embedding_method=pos_embedding_method)
+
+    def sub(self, slot: str) -> _FlatDecoder:
+        return getattr(self, slot + "_decoder")
+
+    def forward(self, p, c_grid, stage="middle", **kwargs):
+        from .renderer import eval_points_raw          # local import: renderer imports this module
+        if torch.is_grad_enabled() and (p.requires_grad or any(v.requires_grad for v in c_grid.values())):
+            raise RuntimeError("NICE.forward is forward-only; differentiate through Renderer.render_batch_ray")
+        return eval_points_raw(p.reshape(-1, 3), self, c_grid, stage, None)

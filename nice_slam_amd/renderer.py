@@ -1,0 +1,293 @@
+"""Drop-in ``Renderer`` (reference: src/utils/Renderer.py) on top of the fused HIP kernels.
+
+Same constructor, same method names, same argument meaning.  ``render_batch_ray`` is one forward
+kernel (+ one backward kernel under autograd) instead of the ~250 ATen launches of the reference
+(SURVEY §2.1).  The decoders object must be a ``nice_slam_amd.NICE``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _capi
+from .common import _require_cuda, _stream, get_rays, to_channels_last
+from .layout import param_count, stage_slots
+
+_SLOT_IDX = {s: i for i, s in enumerate(_capi.SLOT_NAMES)}
+
+
+_BOUND_CACHE: Dict[tuple, tuple] = {}
+
+
+def _bound6(t: Optional[torch.Tensor]) -> tuple:
+    """(lo_x, lo_y, lo_z, hi_x, hi_y, hi_z) as python floats; cached so CUDA-resident bounds cost one sync ever."""
+    if t is None:
+        return (float("-inf"),) * 3 + (float("inf"),) * 3
+    key = (id(t), t.data_ptr(), t._version)
+    v = _BOUND_CACHE.get(key)
+    if v is None:
+        b = t.detach().cpu().to(torch.float64)
+        v = tuple(float(b[i, 0]) for i in range(3)) + tuple(float(b[i, 1]) for i in range(3))
+        if len(_BOUND_CACHE) > 256:
+            _BOUND_CACHE.clear()
+        _BOUND_CACHE[key] = v
+    return v
+
+
+def _fill_common(a: _capi.NsrRenderArgs, stage: str, bound: Optional[torch.Tensor], decoders, grids: Dict[str, torch.Tensor],
+                 packed: Dict[str, torch.Tensor], flats: Dict[str, torch.Tensor]):
+    a.stage = _capi.STAGE_ID[stage]
+    b6 = _bound6(bound)
+    for i in range(3):
+        a.bound_lo[i], a.bound_hi[i] = b6[i], b6[3 + i]
+    for s in stage_slots(stage):
+        i = _SLOT_IDX[s]
+        g = grids[s]
+        a.grid[i].feat = g.data_ptr()
+        a.grid[i].Z, a.grid[i].Y, a.grid[i].X = g.shape[2], g.shape[3], g.shape[4]
+        db = decoders.sub(s).bound
+        if db is None:
+            raise _capi.NsrError(f"{s}_decoder.bound is not set (reference: NICE_SLAM.load_bound)")
+        d6 = _bound6(db)
+        for d in range(3):
+            a.grid[i].lo[d], a.grid[i].hi[d] = d6[d], d6[3 + d]
+        a.dec[i].params = flats[s].data_ptr()
+        a.dec[i].packed = packed[s].data_ptr()
+
+
+def _prep_grids(c: Dict[str, torch.Tensor], stage: str, device) -> Dict[str, torch.Tensor]:
+    out = {}
+    for s in stage_slots(stage):
+        g = c["grid_" + s]
+        if g.device != device:
+            g = g.to(device)
+        if g.dtype != torch.float32 or g.dim() != 5 or g.shape[0] != 1 or g.shape[1] != 32:
+            raise _capi.NsrError(f"grid_{s}: expected fp32 [1,32,Z,Y,X], got {g.dtype} {tuple(g.shape)}")
+        out[s] = to_channels_last(g)           # differentiable; no copy when the grid already is channels-last
+    return out
+
+
+def eval_points_raw(p: torch.Tensor, decoders, c: Dict[str, torch.Tensor], stage: str, bound: Optional[torch.Tensor]):
+    """Forward-only point query: (M,3) world points -> (M,4) fp32 [r,g,b,occ]; occ := 100 outside the open
+    ``bound`` box when ``bound`` is given (src/utils/Renderer.py:43-46,57)."""
+    lib = _capi.get_lib()
+    _require_cuda(p, "eval_points: points")
+    dev = p.device
+    with torch.no_grad():
+        pts = p.detach().to(torch.float64).contiguous()
+        grids = _prep_grids({k: v.detach() for k, v in c.items()}, stage, dev)
+        stream = _stream(dev)
+        flats = {s: decoders.sub(s).flat_params() for s in stage_slots(stage)}
+        packed = {s: decoders.sub(s).packed_params(lib, stream) for s in stage_slots(stage)}
+        a = _capi.NsrRenderArgs()
+        a.n_samples, a.n_surface, a.n_rays = 1, 0, 0
+        _fill_common(a, stage, bound, decoders, grids, packed, flats)
+        out = torch.empty((pts.shape[0], 4), dtype=torch.float32, device=dev)
+        lib.check(lib.nsr_eval_points_fwd(C.byref(a), pts.data_ptr(), pts.shape[0], out.data_ptr(), stream), "nsr_eval_points_fwd")
+    return out
+
+
+class _RenderFn(torch.autograd.Function):
+    """inputs: rays_o, rays_d, then one grid per decoder of the stage, then one 0-dim 'gate' tensor per
+    decoder (requires_grad iff that decoder's parameters do).  Parameter gradients are published straight
+    into ``Parameter.grad`` as views of one flat buffer (no per-tensor kernels)."""
+
+    @staticmethod
+    def forward(ctx, meta, rays_o, rays_d, *tensors):
+        renderer, decoders, stage, gt_depth, reduce_hook = meta
+        lib = _capi.get_lib()
+        slots = stage_slots(stage)
+        grids = dict(zip(slots, tensors[:len(slots)]))
+        dev = rays_o.device
+        stream = _stream(dev)
+        n = rays_o.shape[0]
+        guided = gt_depth is not None and stage != "coarse"
+        S = renderer.N_samples + (renderer.N_surface if guided else 0)
+        flats = {s: decoders.sub(s).flat_params() for s in slots}
+        packed = {s: decoders.sub(s).packed_params(lib, stream) for s in slots}
+        a = _capi.NsrRenderArgs.from_buffer_copy(renderer._arg_template)     # sample fractions pre-filled
+        a.n_samples, a.n_surface, a.n_rays = renderer.N_samples, renderer.N_surface, n
+        a.rays_o, a.rays_d = rays_o.data_ptr(), rays_d.data_ptr()
+        keep = []
+        if guided:
+            gmax = renderer._gt_max if renderer._gt_max is not None else torch.max(gt_depth).reshape(1)
+            keep.append(gmax)
+            a.gt_depth, a.gt_max = gt_depth.data_ptr(), gmax.data_ptr()
+        _fill_common(a, stage, renderer.bound, decoders, grids, packed, flats)
+        depth = torch.empty((n,), dtype=torch.float64, device=dev)
+        var = torch.empty((n,), dtype=torch.float64, device=dev)
+        rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        need_bwd = any(ctx.needs_input_grad)
+        raw = torch.empty((n, S, 4), dtype=torch.float32, device=dev) if need_bwd else None
+        a.depth, a.var, a.rgb = depth.data_ptr(), var.data_ptr(), rgb.data_ptr()
+        a.raw = raw.data_ptr() if raw is not None else None
+        lib.check(lib.nsr_render_fwd(C.byref(a), stream), "nsr_render_fwd")
+        if need_bwd:
+            ctx.args, ctx.keep = a, (keep, rays_o, rays_d, gt_depth, grids, flats, packed, raw, depth)
+            ctx.meta = (renderer, decoders, stage, S, reduce_hook)
+        return depth, var, rgb
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_depth, g_var, g_rgb):
+        lib = _capi.get_lib()
+        renderer, decoders, stage, S, reduce_hook = ctx.meta
+        keep, rays_o, rays_d, gt_depth, grids, flats, packed, raw, depth = ctx.keep
+        a = ctx.args
+        slots = stage_slots(stage)
+        dev = rays_o.device
+        stream = _stream(dev)
+        n = rays_o.shape[0]
+        need_o, need_d = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        need_grid = ctx.needs_input_grad[3:3 + len(slots)]
+        need_par = ctx.needs_input_grad[3 + len(slots):3 + 2 * len(slots)]
+        b = _capi.NsrBwdArgs()
+        g_depth = g_depth.to(torch.float64).contiguous()
+        g_var = g_var.to(torch.float64).contiguous()
+        g_rgb = g_rgb.to(torch.float32).contiguous()
+        b.d_depth, b.d_var, b.d_rgb, b.depth = g_depth.data_ptr(), g_var.data_ptr(), g_rgb.data_ptr(), depth.data_ptr()
+        d_o = d_d = None
+        if need_o or need_d:
+            d_od = torch.zeros((2, n, 3), dtype=torch.float32, device=dev)
+            d_o, d_d = d_od[0], d_od[1]
+            b.d_rays_o, b.d_rays_d = d_o.data_ptr(), d_d.data_ptr()
+        d_grids = []
+        for s, need in zip(slots, need_grid):
+            i = _SLOT_IDX[s]
+            if need:
+                dg = torch.zeros_like(grids[s], memory_format=torch.preserve_format)
+                a.grid[i].dfeat = dg.data_ptr()
+                d_grids.append(dg)
+            else:
+                a.grid[i].dfeat = None
+                d_grids.append(None)
+        gflat = None
+        offs = {}
+        if any(need_par):
+            total = sum(param_count(s) for s, need in zip(slots, need_par) if need)
+            gflat = torch.zeros((total,), dtype=torch.float32, device=dev)
+            off = 0
+            for s, need in zip(slots, need_par):
+                i = _SLOT_IDX[s]
+                if need:
+                    offs[s] = off
+                    a.dec[i].dparams = gflat.data_ptr() + 4 * off
+                    off += param_count(s)
+                else:
+                    a.dec[i].dparams = None
+            nws = lib.nsr_bwd_workspace_floats(_capi.STAGE_ID[stage], n, S, renderer.bwd_max_blocks)
+            ws = renderer._workspace(nws, dev)
+            b.workspace, b.workspace_floats = ws.data_ptr(), nws
+        else:
+            for s in slots:
+                a.dec[_SLOT_IDX[s]].dparams = None
+        b.max_blocks = renderer.bwd_max_blocks
+        if renderer.profile_events is not None:           # bench.py: hipEvent pair around the main backward kernel
+            b.ev_start, b.ev_stop = renderer.profile_events(stage)
+        lib.check(lib.nsr_render_bwd(C.byref(a), C.byref(b), stream), "nsr_render_bwd")
+        if reduce_hook is not None:                       # multi-GPU: sum shard gradients (parallel.py)
+            reduce_hook([g for g in d_grids if g is not None], gflat)
+        for s, need in zip(slots, need_par):
+            if need:
+                decoders.sub(s).publish_grads(gflat[offs[s]:offs[s] + param_count(s)])
+        ctx.keep = ctx.args = None
+        return (None, d_o if need_o else None, d_d if need_d else None, *d_grids, *([None] * len(slots)))
+
+
+class Renderer(object):
+    """src/utils/Renderer.py:5-21.  ``slam`` only needs ``nice, bound, H, W, fx, fy, cx, cy``."""
+
+    def __init__(self, cfg, args, slam, points_batch_size=500000, ray_batch_size=100000):
+        self.ray_batch_size = ray_batch_size
+        self.points_batch_size = points_batch_size       # kept for API parity; the fused kernel needs no chunking
+        self.lindisp = cfg["rendering"]["lindisp"]
+        self.perturb = cfg["rendering"]["perturb"]
+        self.N_samples = cfg["rendering"]["N_samples"]
+        self.N_surface = cfg["rendering"]["N_surface"]
+        self.N_importance = cfg["rendering"]["N_importance"]
+        self.scale = cfg["scale"]
+        self.occupancy = cfg["occupancy"]
+        self.nice = slam.nice
+        self.bound = slam.bound
+        self.H, self.W, self.fx, self.fy, self.cx, self.cy = slam.H, slam.W, slam.fx, slam.fy, slam.cx, slam.cy
+        if self.lindisp or self.perturb > 0 or self.N_importance > 0 or not self.occupancy or not self.nice:
+            raise NotImplementedError("nice_slam_amd implements the NICE-SLAM configuration of the render path "
+                                      "(occupancy, perturb=0, N_importance=0, lindisp=False); iMAP* is out of scope")
+        if self.N_samples + self.N_surface > _capi.MAX_SAMPLES:
+            raise NotImplementedError("N_samples + N_surface must not exceed 64")
+        # sample fractions exactly as torch produces them (Renderer.py:132,152)
+        self._t_uniform = torch.linspace(0.0, 1.0, steps=self.N_samples).tolist()
+        self._t_surface = torch.linspace(0.0, 1.0, steps=max(self.N_surface, 1)).double().tolist()[:self.N_surface]
+        tmpl = _capi.NsrRenderArgs()
+        for i, v in enumerate(self._t_uniform):
+            tmpl.t_uniform[i] = v
+        for i, v in enumerate(self._t_surface):
+            tmpl.t_surface[i] = v
+        self._arg_template = bytes(tmpl)
+        self.bwd_max_blocks = 0                 # 0 = library default persistent-grid cap
+        self.profile_events = None              # optional callable(stage) -> (hipEvent_t start, hipEvent_t stop)
+        self._gt_max = None                     # set by the multi-GPU wrapper: batch-global max(gt_depth)
+        self._reduce_hook = None
+        self._ws = {}                           # per-device backward workspace (not pickled)
+
+    def __getstate__(self):                      # Renderer objects are pickled into spawned processes
+        d = dict(self.__dict__)
+        d["_ws"] = {}
+        d["_reduce_hook"] = None
+        d["profile_events"] = None
+        return d
+
+    def _workspace(self, nfloats: int, dev) -> torch.Tensor:
+        ws = self._ws.get(dev)
+        if ws is None or ws.numel() < nfloats:
+            ws = torch.empty((max(nfloats, 1),), dtype=torch.float32, device=dev)
+            self._ws[dev] = ws
+        return ws
+
+    # ---------------------------------------------------------------------------------------------
+    def eval_points(self, p, decoders, c=None, stage="color", device="cuda:0"):
+        """Renderer.py:23-61 (forward only)."""
+        return eval_points_raw(p, decoders, c, stage, self.bound)
+
+    def render_batch_ray(self, c, decoders, rays_d, rays_o, device, stage, gt_depth=None):
+        """Renderer.py:63-198: returns (depth fp64 (N,), uncertainty fp64 (N,), color fp32 (N,3))."""
+        _require_cuda(rays_o, "render_batch_ray: rays")
+        dev = rays_o.device
+        if stage == "coarse":
+            gt_depth = None
+        slots = stage_slots(stage)
+        rays_o = rays_o.to(torch.float32).contiguous()
+        rays_d = rays_d.to(torch.float32).contiguous()
+        if gt_depth is not None:
+            gt_depth = gt_depth.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        grids = _prep_grids(c, stage, dev)
+        gates = []
+        for s in slots:
+            want = torch.is_grad_enabled() and decoders.sub(s).wants_grad()
+            gates.append(torch.zeros((), device=dev, requires_grad=True) if want else torch.zeros((), device=dev))
+        meta = (self, decoders, stage, gt_depth, self._reduce_hook)
+        return _RenderFn.apply(meta, rays_o, rays_d, *[grids[s] for s in slots], *gates)
+
+    def render_img(self, c, decoders, c2w, device, stage, gt_depth=None):
+        """Renderer.py:200-255 (the reference requires gt_depth here; we also accept None)."""
+        with torch.no_grad():
+            H, W = self.H, self.W
+            rays_o, rays_d = get_rays(H, W, self.fx, self.fy, self.cx, self.cy, c2w, device)
+            rays_o = rays_o.reshape(-1, 3).contiguous()
+            rays_d = rays_d.reshape(-1, 3).contiguous()
+            gd = None if gt_depth is None else gt_depth.reshape(-1)
+            depth_l, unc_l, col_l = [], [], []
+            for i in range(0, rays_d.shape[0], self.ray_batch_size):
+                sl = slice(i, i + self.ray_batch_size)
+                d, u, col = self.render_batch_ray(c, decoders, rays_d[sl], rays_o[sl], device, stage,
+                                                  gt_depth=None if gd is None else gd[sl])
+                depth_l.append(d.double()); unc_l.append(u.double()); col_l.append(col)
+            depth = torch.cat(depth_l).reshape(H, W)
+            unc = torch.cat(unc_l).reshape(H, W)
+            color = torch.cat(col_l).reshape(H, W, 3)
+            return depth, unc, color
+
+    def regulation(self, c, decoders, rays_d, rays_o, gt_depth, device, stage="color"):
+        raise NotImplementedError("Renderer.regulation is only used by iMAP* (src/Mapper.py:496-501), out of scope")

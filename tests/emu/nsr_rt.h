@@ -2,6 +2,7 @@
 #pragma once
 namespace nsr {
 inline const char *rt_check_last() { return nullptr; }
+inline void rt_record(void *, void *) {}
 template <typename K>
 inline const char *rt_allow_lds(K, int) { return nullptr; }
 }  // namespace nsr

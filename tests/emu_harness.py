@@ -130,6 +130,8 @@ class HostScene:
         res = {}
         for s in stage_slots(stage):
             i = _capi.SLOT_NAMES.index(s)
+            a.grid[i].dfeat = None
+            a.dec[i].dparams = None
             if want_grid:
                 res["d_grid_" + s] = np.zeros_like(self.grids[s])
                 a.grid[i].dfeat = ptr(res["d_grid_" + s])

@@ -1,0 +1,78 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/nsr.h declares.
+No compute call is made (there is no GPU here)."""
+import os
+import re
+import shutil
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "nsr.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(nsr_[a-z_]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    from nice_slam_amd import build, _capi
+    build.build_lib()
+    return _capi.Lib(_capi.LIB_PATH)
+
+
+def test_header_symbols_are_bound_and_exported(lib):
+    from nice_slam_amd import _capi
+    declared = _declared_symbols()
+    assert len(declared) >= 10
+    assert sorted(n for n, _, _ in _capi.SYMBOLS) == declared      # the ctypes table covers the whole header
+    for name in declared:
+        assert hasattr(lib.cdll, name), name
+
+
+def test_sizes_and_error_reporting(lib):
+    from nice_slam_amd.layout import param_count
+    assert lib.nsr_version() == 1
+    assert [lib.nsr_param_count(i) for i in range(4)] == [param_count(s) for s in ("coarse", "middle", "fine", "color")] \
+        == [6337, 15800, 20920, 15899]
+    assert [lib.nsr_packed_count(i) for i in range(4)] == [6144, 15360, 20480, 15360]
+    assert lib.nsr_param_count(7) == -1
+    assert lib.nsr_bwd_workspace_floats(3, 1000, 48, 0) == 3 * 250 * 20920
+    # argument validation happens before any device work
+    assert lib.nsr_pack_params(9, None, None, None) != 0
+    assert b"slot" in lib.nsr_last_error()
+    assert lib.nsr_render_fwd(None, None) != 0 and b"null" in lib.nsr_last_error()
+
+
+def test_ctypes_struct_layout_matches_header():
+    """sizeof of the mirrored structs, computed independently from the header with the C compiler."""
+    import ctypes
+    import subprocess
+    import tempfile
+    from nice_slam_amd import _capi
+    src = '#include <stdio.h>\n#include "nsr.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(nsr_grid), sizeof(nsr_decoder), ' \
+          'sizeof(nsr_render_args), sizeof(nsr_bwd_args));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")], check=True)
+        out = subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()
+    assert [int(v) for v in out] == [ctypes.sizeof(_capi.NsrGrid), ctypes.sizeof(_capi.NsrDecoder),
+                                     ctypes.sizeof(_capi.NsrRenderArgs), ctypes.sizeof(_capi.NsrBwdArgs)]
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import nice_slam_amd as nsa
+    from nice_slam_amd._capi import NsrError
+    from scene_util import make_scene, build_product
+    sc = make_scene(seed=1, n_rays=4, small=True)
+    renderer, dec, grids = build_product(sc, "cpu")
+    with pytest.raises(NsrError):
+        renderer.render_batch_ray(grids, dec, sc["rays_d"], sc["rays_o"], "cpu", "middle", gt_depth=sc["gt_depth"])
+    with pytest.raises(NsrError):
+        nsa.get_samples(0, 8, 0, 8, 4, 48, 64, 60., 60., 31.5, 23.5, sc["c2w"], sc["depth_img"], sc["color_img"], "cpu")

@@ -1,0 +1,123 @@
+"""CPU: the kernel SOURCES (nice_slam_amd/csrc, compiled for the host against the fiber shim in tests/emu)
+against the reference goldens and the oracle.  This exercises every index, layout and reduction of the HIP
+kernels without a GPU; the GPU run (test_hip_parity.py) then only has to confirm the hardware primitives."""
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_scene, rel_err
+from scene_util import make_scene, oracle_render
+
+STAGES = ("coarse", "middle", "fine", "color")
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import os
+    if not (os.path.exists("/opt/rocm/lib/llvm/bin/clang++") or shutil.which("clang++")):
+        pytest.skip("no host clang++ for the emulator build")
+    from emu_harness import emu_lib
+    return emu_lib()
+
+
+def _host_scene(emu, grids, params, bound, enl=2.0):
+    from emu_harness import HostScene
+    return HostScene(emu, grids, params, np.asarray(bound), enl)
+
+
+@pytest.mark.parametrize("stage", STAGES)
+def test_golden_forward_backward(emu, golden, stage):
+    grids, params, bound = golden_scene(golden)
+    sc = _host_scene(emu, grids, params, bound.numpy(), float(golden["coarse_bound_enlarge"]))
+    fwd = sc.forward(stage, golden["rays_o"], golden["rays_d"], golden["gt_depth"])
+    pre = f"out/{stage}/"
+    for k in ("depth", "var", "rgb"):
+        assert rel_err(fwd[k], golden[pre + k]) < TOL, (stage, k)
+    res = sc.backward(stage, fwd, golden["w_depth"], golden["w_var"], golden["w_rgb"])
+    checked = 0
+    for k, v in res.items():
+        gk = pre + k
+        if gk in golden:
+            assert rel_err(v, golden[gk]) < TOL, (stage, k)
+            checked += 1
+        else:
+            assert float(np.abs(v).max()) == 0.0, (stage, k)
+    assert checked >= 8
+
+
+def test_golden_forward_without_depth(emu, golden):
+    grids, params, bound = golden_scene(golden)
+    sc = _host_scene(emu, grids, params, bound.numpy(), float(golden["coarse_bound_enlarge"]))
+    fwd = sc.forward("middle", golden["rays_o"], golden["rays_d"], None)
+    assert fwd["raw"].shape[1] == 32
+    assert rel_err(fwd["depth"], golden["out/middle_nodepth/depth"]) < TOL
+    assert rel_err(fwd["var"], golden["out/middle_nodepth/var"]) < TOL
+
+
+@pytest.mark.parametrize("stage,n", [("color", 37), ("fine", 5), ("coarse", 13), ("middle", 1)])
+def test_random_scene_against_oracle(emu, stage, n):
+    """ragged ray counts (not a multiple of rays-per-block), persistent loop with a tiny grid cap"""
+    s = make_scene(seed=100 + n, n_rays=n, small=True)
+    s["gt_depth"][0] = 0.0
+    sc = _host_scene(emu, s["grids"], s["params"], s["bound"].numpy())
+    fwd = sc.forward(stage, s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy())
+    ref = oracle_render(s, stage, backward=True)
+    for k in ("depth", "var", "rgb"):
+        assert rel_err(fwd[k], ref[k]) < TOL, (stage, k)
+    res = sc.backward(stage, fwd, s["w"]["depth"].numpy(), s["w"]["var"].numpy(), s["w"]["rgb"].numpy(), max_blocks=2)
+    for k, v in ref.items():
+        if k in ("depth", "var", "rgb"):
+            continue
+        assert rel_err(res[k], v) < TOL, (stage, k)
+
+
+def test_backward_flag_subsets(emu):
+    """tracking (ray grads only) and grid-only requests give the same numbers as the full backward"""
+    s = make_scene(seed=7, n_rays=9, small=True)
+    sc = _host_scene(emu, s["grids"], s["params"], s["bound"].numpy())
+    w = s["w"]
+    fwd = sc.forward("color", s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy())
+    full = sc.backward("color", fwd, w["depth"].numpy(), w["var"].numpy(), w["rgb"].numpy())
+    rays = sc.backward("color", fwd, w["depth"].numpy(), w["var"].numpy(), w["rgb"].numpy(), want_grid=False, want_params=False)
+    grid = sc.backward("color", fwd, w["depth"].numpy(), w["var"].numpy(), w["rgb"].numpy(), want_params=False, want_rays=False)
+    assert set(rays) == {"d_rays_o", "d_rays_d"}
+    for k in rays:
+        assert rel_err(rays[k], full[k]) < 1e-6
+    for k in grid:
+        assert rel_err(grid[k], full[k]) < 1e-6
+    # depth-only upstream gradient (d_var = d_rgb = NULL)
+    dd = sc.backward("fine", sc.forward("fine", s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy()),
+                     w["depth"].numpy(), None, None)
+    assert np.isfinite(dd["d_grid_fine"]).all()
+
+
+def test_eval_points_and_get_samples(emu, golden):
+    import ctypes as C
+    from emu_harness import ptr
+    from nice_slam_amd import _capi
+    from oracle import nice_oracle as orc
+    grids, params, bound = golden_scene(golden)
+    sc = _host_scene(emu, grids, params, bound.numpy(), float(golden["coarse_bound_enlarge"]))
+    g = torch.Generator().manual_seed(3)
+    pts = (torch.rand((50, 3), generator=g, dtype=torch.float64) * 1.3 - 0.15) * (bound[:, 1] - bound[:, 0]) + bound[:, 0]
+    for stage in STAGES:
+        a = sc._args(stage, np.zeros((1, 3), np.float32), np.zeros((1, 3), np.float32), None, [])
+        out = np.full((50, 4), np.nan, dtype=np.float32)
+        p = np.ascontiguousarray(pts.numpy())
+        emu.check(emu.nsr_eval_points_fwd(C.byref(a), ptr(p), 50, ptr(out), None))
+        ref = orc.eval_points(pts, grids, params, orc.decoder_bounds(bound, float(golden["coarse_bound_enlarge"])), bound, stage)
+        assert rel_err(out, ref) < TOL, stage
+    H, W, fx, fy, cx, cy = golden["intr"]
+    H0, H1, W0, W1 = (int(v) for v in golden["gs/crop"])
+    n = golden["gs/idx"].shape[0]
+    o, d = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32)
+    sd, scol = np.empty(n, np.float32), np.empty((n, 3), np.float32)
+    idx = np.ascontiguousarray(golden["gs/idx"].astype(np.int64))
+    c2w = np.ascontiguousarray(golden["c2w"])
+    emu.check(emu.nsr_get_samples(ptr(idx), n, H0, H1, W0, W1, int(W), fx, fy, cx, cy, ptr(c2w), 4,
+                                  ptr(golden["depth_img"]), ptr(golden["color_img"]), ptr(o), ptr(d), ptr(sd), ptr(scol), None))
+    assert np.array_equal(o, golden["gs/rays_o"]) and np.array_equal(d, golden["gs/rays_d"])      # bit-exact
+    assert np.array_equal(sd, golden["gs/depth"]) and np.array_equal(scol, golden["gs/color"])
