@@ -262,6 +262,10 @@ class Renderer(object):
         rays_d = rays_d.to(torch.float32).contiguous()
         if gt_depth is not None:
             gt_depth = gt_depth.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        if rays_o.shape[0] == 0:                 # empty batch (e.g. every ray removed by the caller's AABB pre-filter)
+            z = (rays_o.sum() + rays_d.sum()) * 0.0  # keeps the graph connected
+            return (torch.zeros((0,), dtype=torch.float64, device=dev) + z, torch.zeros((0,), dtype=torch.float64, device=dev) + z,
+                    torch.zeros((0, 3), dtype=torch.float32, device=dev) + z)
         grids = _prep_grids(c, stage, dev)
         gates = []
         for s in slots:
