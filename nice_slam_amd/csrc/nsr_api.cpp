@@ -197,8 +197,8 @@ int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream
         for (int s = first; s <= last; ++s) {
             if (!P.dec[s].dparams) continue;
             const int pass = P.stage == NSR_STAGE_COARSE ? 0 : s - NSR_MIDDLE;
-            const int n = nsr::param_total(s), tb = 256;
-            NSR_LAUNCH(nsr::reduce_partials_kernel, dim3((n + tb - 1) / tb), dim3(tb), 0, stream,
+            const int n = nsr::param_total(s), tb = 1024;        // 64 parameters x 16 slices of the partial list
+            NSR_LAUNCH(nsr::reduce_partials_kernel, dim3((n + 63) / 64), dim3(tb), tb * 4, stream,
                        (const float *)(P.partials + (long long)pass * nblk * P.partial_stride), nblk, P.partial_stride, n,
                        P.dec[s].dparams);
         }

@@ -262,43 +262,82 @@ NSR_DEV Act<2> gather_feat(const GridDev &G, const Lvl &L, int g) {
     return c;
 }
 
-// backward of the gather: scatter-add dc into the grid gradient; optionally the coordinate gradient
-// (d value / d u per axis, ATen grid_sampler_3d_backward), returned already reduced over g.
-template <bool COORD>
-NSR_DEV void scatter_feat(const GridDev &G, const Lvl &L, int g, const Act<2> &dc, bool active, bool to_grid,
-                          float &dux, float &duy, float &duz) {
+// per-wave transposition buffers: Tx[pt][kTxS]
+NSR_DEV void tx_store(float *Tx, const Act<2> &v, int pt, int g) {
+    st4(Tx + pt * kTxS + 4 * g, to_F4(v.t[0]));
+    st4(Tx + pt * kTxS + 16 + 4 * g, to_F4(v.t[1]));
+}
+// element s = Tx[4s+g][16T + i]: the MFMA operand "lane = channel i of tile T, k = point 4s+g"
+NSR_DEV f32x4 tx_load_cm(const float *Tx, int T, int i, int g) {
+    f32x4 r;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) r[s] = Tx[(4 * s + g) * kTxS + 16 * T + i];
+    return r;
+}
+
+// backward of the gather, part 1: coordinate gradient (d value / d u per axis, ATen
+// grid_sampler_3d_backward), returned already reduced over g.
+NSR_DEV void coord_grad(const GridDev &G, const Lvl &L, int g, const Act<2> &dc, float &dux, float &duy, float &duz) {
     float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const long long base = (long long)corner_vox(L, k) * kC + 4 * g;
-        if (to_grid && active) {
-            const float w = corner_w(L, k);
-            float *dst = G.dfeat + base;
+        const float *src = G.feat + (long long)corner_vox(L, k) * kC + 4 * g;
+        const F4 a = ld4(src), b = ld4(src + 16);
+        float dot = a.x * dc.t[0][0];
+        dot = fmaf(a.y, dc.t[0][1], dot); dot = fmaf(a.z, dc.t[0][2], dot); dot = fmaf(a.w, dc.t[0][3], dot);
+        dot = fmaf(b.x, dc.t[1][0], dot); dot = fmaf(b.y, dc.t[1][1], dot);
+        dot = fmaf(b.z, dc.t[1][2], dot); dot = fmaf(b.w, dc.t[1][3], dot);
+        const float wx = (k & 1) ? L.fx : L.gx, wy = (k & 2) ? L.fy : L.gy, wz = (k & 4) ? L.fz : L.gz;
+        ax = fmaf((k & 1) ? dot : -dot, wy * wz, ax);
+        ay = fmaf((k & 2) ? dot : -dot, wx * wz, ay);
+        az = fmaf((k & 4) ? dot : -dot, wx * wy, az);
+    }
+    ax += shfl_xor(ax, 16); ax += shfl_xor(ax, 32);
+    ay += shfl_xor(ay, 16); ay += shfl_xor(ay, 32);
+    az += shfl_xor(az, 16); az += shfl_xor(az, 32);
+    dux = ax * L.mx; duy = ay * L.my; duz = az * L.mz;
+}
+
+// backward of the gather, part 2: scatter-add dc into the grid gradient.
+// Measured on MI355X (tools/atomic_probe.hip): a global f32 atomic costs one request per touched 64-byte
+// line (~21 G lines/s chip-wide) no matter how many of its 16 dwords an instruction updates, and lanes of
+// one instruction that hit the SAME dword serialise.  So the tile is re-laid out through LDS to
+// "lane = channel": each half-wave owns one corner index k and walks the tile's 16 points (consecutive
+// samples of a ray, i.e. spatially sorted), summing weighted dc while the corner voxel stays the same and
+// issuing ONE 32-lane atomic (two full 64-byte lines) per run of equal voxels.
+//   Tx  : [16][kTxS] floats  dc of the tile, point-major
+//   tab : [16][8] ints (corner voxel or -1) followed by [16][8] floats (corner weight)
+NSR_DEV void scatter_merged(const GridDev &G, const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab) {
+    const int pt = lane & 15, g = lane >> 4;
+    int *vt = reinterpret_cast<int *>(tab);
+    float *wt = tab + 128;
+    tx_store(Tx, dc, pt, g);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                atomic_add_global(dst + r, dc.t[0][r] * w);
-                atomic_add_global(dst + 16 + r, dc.t[1][r] * w);
+    for (int c = 0; c < 2; ++c) {
+        const int k = 2 * g + c;
+        vt[pt * 8 + k] = active ? corner_vox(L, k) : -1;
+        wt[pt * 8 + k] = corner_w(L, k);
+    }
+    wave_fence();
+    const int h = lane >> 5, ch = lane & 31;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        const int k = 2 * q + h;
+        float acc = 0.f;
+        int cur = -1;
+#pragma unroll 4
+        for (int p = 0; p < 16; ++p) {
+            const int v = vt[p * 8 + k];
+            if (v != cur) {
+                if (cur >= 0) atomic_add_global(G.dfeat + (long long)cur * kC + ch, acc);
+                acc = 0.f;
+                cur = v;
             }
+            acc = fmaf(Tx[p * kTxS + ch], wt[p * 8 + k], acc);
         }
-        if (COORD) {
-            const float *src = G.feat + base;
-            const F4 a = ld4(src), b = ld4(src + 16);
-            float dot = a.x * dc.t[0][0];
-            dot = fmaf(a.y, dc.t[0][1], dot); dot = fmaf(a.z, dc.t[0][2], dot); dot = fmaf(a.w, dc.t[0][3], dot);
-            dot = fmaf(b.x, dc.t[1][0], dot); dot = fmaf(b.y, dc.t[1][1], dot);
-            dot = fmaf(b.z, dc.t[1][2], dot); dot = fmaf(b.w, dc.t[1][3], dot);
-            const float wx = (k & 1) ? L.fx : L.gx, wy = (k & 2) ? L.fy : L.gy, wz = (k & 4) ? L.fz : L.gz;
-            ax = fmaf((k & 1) ? dot : -dot, wy * wz, ax);
-            ay = fmaf((k & 2) ? dot : -dot, wx * wz, ay);
-            az = fmaf((k & 4) ? dot : -dot, wx * wy, az);
-        }
+        if (cur >= 0) atomic_add_global(G.dfeat + (long long)cur * kC + ch, acc);
     }
-    if (COORD) {
-        ax += shfl_xor(ax, 16); ax += shfl_xor(ax, 32);
-        ay += shfl_xor(ay, 16); ay += shfl_xor(ay, 32);
-        az += shfl_xor(az, 16); az += shfl_xor(az, 32);
-        dux = ax * L.mx; duy = ay * L.my; duz = az * L.mz;
-    }
+    wave_fence();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -340,19 +379,6 @@ NSR_DEV void gemv_bwd(f32x4 (&dx)[NTK], const Act<2> &dy, const float *flat, con
         }
     }
     sched_fence();
-}
-
-// per-wave transposition buffers: Tx[pt][kTxS]
-NSR_DEV void tx_store(float *Tx, const Act<2> &v, int pt, int g) {
-    st4(Tx + pt * kTxS + 4 * g, to_F4(v.t[0]));
-    st4(Tx + pt * kTxS + 16 + 4 * g, to_F4(v.t[1]));
-}
-// element s = Tx[4s+g][16T + i]: the MFMA operand "lane = channel i of tile T, k = point 4s+g"
-NSR_DEV f32x4 tx_load_cm(const float *Tx, int T, int i, int g) {
-    f32x4 r;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) r[s] = Tx[(4 * s + g) * kTxS + 16 * T + i];
-    return r;
 }
 
 // acc_lds[W slice] += dy^T x for one 16-channel tile of x (xT = CM operand of that tile)
@@ -1083,8 +1109,8 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
                 mlp_xyz_bwd<NSR_COLOR>(D.params, D.packed, aux, acc, TxA, TxB, (float)px, (float)py, (float)pz, c, d_out, F, lane, dc, dpe);
             }
             float dux = 0.f, duy = 0.f, duz = 0.f;
-            if (F.rays) scatter_feat<true>(G, L, g, dc, active, F.grid, dux, duy, duz);
-            else if (F.grid) scatter_feat<false>(G, L, g, dc, active, true, dux, duy, duz);
+            if (F.rays) coord_grad(G, L, g, dc, dux, duy, duz);
+            if (F.grid) scatter_merged(G, L, lane, dc, active, TxA, TxB);
             if (F.rays && active && g == 0) {
                 // d p = d u * (n-1)/2 * 2/(hi-lo)  (+ embedding part), fp64 like autograd through Renderer.py:172
                 dpb[pidx * 3 + 0] = (double)dux * (2.0 * G.inv[0]) + (double)dpe[0];
@@ -1129,12 +1155,20 @@ NSR_KERNEL NSR_BOUNDS(768) void render_bwd_kernel(const RenderParams P) {
 }
 
 // sum the per-block partial parameter gradients:  dparams[t] += sum_b partials[b][t]
+// block = 64 parameters x (blockDim/64) slices of the partial list (coalesced 256-byte rows, split serial sum)
 NSR_KERNEL void reduce_partials_kernel(const float *__restrict__ partials, int nblocks, int stride, int n, float *__restrict__ dparams) {
-    const int t = bid_x() * nthreads() + tid();
-    if (t >= n) return;
+    float *red = reinterpret_cast<float *>(lds_base());
+    const int lane = tid() & 63, slice = tid() >> 6, nslice = nthreads() >> 6;
+    const int t = bid_x() * 64 + lane;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partials[(long long)b * stride + t];
-    dparams[t] += s;
+    if (t < n)
+        for (int b = slice; b < nblocks; b += nslice) s += partials[(long long)b * stride + t];
+    red[tid()] = s;
+    block_sync();
+    if (slice == 0 && t < n) {
+        for (int k = 1; k < nslice; ++k) s += red[k * 64 + lane];
+        dparams[t] += s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

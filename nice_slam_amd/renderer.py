@@ -18,21 +18,21 @@ from .layout import param_count, stage_slots
 _SLOT_IDX = {s: i for i, s in enumerate(_capi.SLOT_NAMES)}
 
 
-_BOUND_CACHE: Dict[tuple, tuple] = {}
-
-
 def _bound6(t: Optional[torch.Tensor]) -> tuple:
-    """(lo_x, lo_y, lo_z, hi_x, hi_y, hi_z) as python floats; cached so CUDA-resident bounds cost one sync ever."""
+    """(lo_x, lo_y, lo_z, hi_x, hi_y, hi_z) as python floats.  The conversion is cached ON the tensor object
+    (keyed by its version counter), so a CUDA-resident bound costs one host sync ever and a recycled id() /
+    data_ptr() can never alias another tensor's values."""
     if t is None:
         return (float("-inf"),) * 3 + (float("inf"),) * 3
-    key = (id(t), t.data_ptr(), t._version)
-    v = _BOUND_CACHE.get(key)
-    if v is None:
-        b = t.detach().cpu().to(torch.float64)
-        v = tuple(float(b[i, 0]) for i in range(3)) + tuple(float(b[i, 1]) for i in range(3))
-        if len(_BOUND_CACHE) > 256:
-            _BOUND_CACHE.clear()
-        _BOUND_CACHE[key] = v
+    cached = getattr(t, "_nsr_bound6", None)
+    if cached is not None and cached[0] == t._version:
+        return cached[1]
+    b = t.detach().cpu().to(torch.float64)
+    v = tuple(float(b[i, 0]) for i in range(3)) + tuple(float(b[i, 1]) for i in range(3))
+    try:
+        t._nsr_bound6 = (t._version, v)
+    except Exception:
+        pass
     return v
 
 
