@@ -16,7 +16,7 @@ STAGE_ID = {"coarse": 0, "middle": 1, "fine": 2, "color": 3}
 SLOT_NAMES = ("coarse", "middle", "fine", "color")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnsr.so")
+LIB_PATH = os.environ.get("NSR_LIB_PATH", os.path.join(_HERE, "libnsr.so"))   # override: A/B builds of the same HIP library
 
 
 class NsrGrid(C.Structure):

@@ -21,10 +21,15 @@ constexpr int kLdsLimit = 160 * 1024;
 
 inline int round16(int bytes) { return (bytes + 15) & ~15; }
 
-int rays_per_block(int S) {
-    int rb = (kMaxTiles * nsr::kTile) / S;
+// forward: up to 12 tiles (768 threads, 3 waves/SIMD, <=168 VGPRs).  backward: up to kBwdTiles tiles so that the
+// register-hungry backward gets 2 waves/SIMD with the full 256-VGPR budget instead of spilling.
+constexpr int kBwdTiles = NSR_BWD_TILES;
+int rays_per_block_t(int S, int max_tiles) {
+    int rb = (max_tiles * nsr::kTile) / S;
     return rb < 1 ? 1 : rb;
 }
+int rays_per_block(int S) { return rays_per_block_t(S, kMaxTiles); }
+int rays_per_block_bwd(int S) { return rays_per_block_t(S, kBwdTiles); }
 
 int stage_passes(int stage) { return stage == NSR_STAGE_COARSE ? 1 : 3; }
 
@@ -38,7 +43,7 @@ int bwd_blocks(long long n_groups, int max_blocks) {
 }
 
 // validate + translate the public argument block
-int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays) {
+int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays, bool bwd = false) {
     if (!a) return fail("nsr: null argument block");
     if (a->stage < 0 || a->stage > 3) return fail("nsr: stage out of range");
     std::memset(&P, 0, sizeof(P));
@@ -55,7 +60,7 @@ int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays)
         if (a->n_rays < 0) return fail("nsr: negative ray count");
         if (a->n_rays > 0 && (!a->rays_o || !a->rays_d)) return fail("nsr: null ray pointers");
     }
-    P.rays_per_block = rays_per_block(P.S);
+    P.rays_per_block = bwd ? rays_per_block_bwd(P.S) : rays_per_block(P.S);
     P.tiles_per_block = (P.rays_per_block * P.S + nsr::kTile - 1) / nsr::kTile;
     P.n_groups = (P.n_rays + P.rays_per_block - 1) / P.rays_per_block;
     P.rays_o = a->rays_o;
@@ -120,7 +125,7 @@ int64_t nsr_packed_count(int slot) { return (slot < 0 || slot > 3) ? -1 : nsr::p
 
 int64_t nsr_bwd_workspace_floats(int stage, int64_t n_rays, int n_samples_total, int max_blocks) {
     if (stage < 0 || stage > 3 || n_samples_total < 1 || n_samples_total > NSR_MAX_SAMPLES) return -1;
-    const int rb = rays_per_block(n_samples_total);
+    const int rb = rays_per_block_bwd(n_samples_total);
     const long long groups = (n_rays + rb - 1) / rb;
     const long long blocks = bwd_blocks(groups, max_blocks);
     return (int64_t)stage_passes(stage) * (blocks > 0 ? blocks : 1) * max_param_count(stage);
@@ -159,7 +164,7 @@ int nsr_render_fwd(const nsr_render_args *a, void *stream) {
 
 int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream) {
     nsr::RenderParams P;
-    if (int rc = build_params(a, P, true)) return rc;
+    if (int rc = build_params(a, P, true, true)) return rc;
     if (!b) return fail("nsr_render_bwd: null backward block");
     if (!a->raw) return fail("nsr_render_bwd: the forward pass must have saved `raw`");
     if (!b->d_depth && !b->d_var && !b->d_rgb) return fail("nsr_render_bwd: no output gradient given");

@@ -19,6 +19,10 @@
 #include "nsr_layout.h"
 #include "../../include/nsr.h"
 
+#ifndef NSR_BWD_TILES
+#define NSR_BWD_TILES 8     // waves per backward block (see nsr_api.cpp)
+#endif
+
 namespace nsr {
 
 template <int NT>
@@ -1143,7 +1147,7 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
 }
 
 template <int STAGE>
-NSR_KERNEL NSR_BOUNDS(768) void render_bwd_kernel(const RenderParams P) {
+NSR_KERNEL NSR_BOUNDS(64 * NSR_BWD_TILES) void render_bwd_kernel(const RenderParams P) {
     if (STAGE == NSR_STAGE_COARSE) {
         bwd_pass<NSR_COARSE>(P);
     } else {

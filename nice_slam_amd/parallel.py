@@ -67,9 +67,16 @@ class _SumGrad(torch.autograd.Function):
 
 
 def _all_gather_rows(x: torch.Tensor, sizes: List[int], group) -> torch.Tensor:
-    outs = [torch.empty((s,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device) for s in sizes]
-    dist.all_gather(outs, x, group=group)
-    return torch.cat(outs, 0)
+    """all-gather of row blocks whose sizes differ by at most one: pad to the largest block, gather into one
+    buffer (a single collective), drop the padding."""
+    m = max(sizes)
+    if x.shape[0] < m:
+        x = torch.cat([x, x.new_zeros((m - x.shape[0],) + tuple(x.shape[1:]))], 0)
+    buf = torch.empty((len(sizes) * m,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(buf, x.contiguous(), group=group)
+    if all(s == m for s in sizes):
+        return buf
+    return torch.cat([buf[r * m:r * m + s] for r, s in enumerate(sizes)], 0)
 
 
 class ShardedRenderer:

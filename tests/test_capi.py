@@ -40,7 +40,9 @@ def test_sizes_and_error_reporting(lib):
         == [6337, 15800, 20920, 15899]
     assert [lib.nsr_packed_count(i) for i in range(4)] == [6144, 15360, 20480, 15360]
     assert lib.nsr_param_count(7) == -1
-    assert lib.nsr_bwd_workspace_floats(3, 1000, 48, 0) == 3 * 250 * 20920
+    # color stage, 1000 rays, S=48: 3 passes x min(groups, cap) blocks x the largest decoder blob
+    assert lib.nsr_bwd_workspace_floats(3, 1000, 48, 7) == 3 * 7 * 20920
+    assert lib.nsr_bwd_workspace_floats(0, 1000, 32, 5) == 1 * 5 * 6337
     # argument validation happens before any device work
     assert lib.nsr_pack_params(9, None, None, None) != 0
     assert b"slot" in lib.nsr_last_error()

@@ -1,0 +1,103 @@
+"""CPU, world_size 2, gloo: the ray-sharding logic of nice_slam_amd.parallel.
+
+The inner renderer is an oracle-backed stand-in with the same ``render_batch_ray`` / ``_gt_max`` protocol
+(the HIP renderer needs a GPU); what is under test is the distributed plumbing: contiguous sharding, the
+batch-global max(gt_depth) taken before slicing, all-gather of outputs, all-gather of ray gradients and the
+SUM all-reduce of the replicated feature-grid gradients.  Result must equal the single-process result."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class OracleRenderer:
+    """Renderer-protocol stand-in built on the CPU oracle."""
+
+    def __init__(self, sc):
+        self.sc, self._gt_max, self._reduce_hook = sc, None, None
+
+    def render_batch_ray(self, c, decoders, rays_d, rays_o, device, stage, gt_depth=None):
+        from oracle import nice_oracle as orc
+        if gt_depth is not None and self._gt_max is not None and gt_depth.numel() > 0:
+            # emulate the kernel's `gt_max` argument: plant the batch-global maximum as an extra ray, drop it after
+            extra_o, extra_d = rays_o[:1].detach(), rays_d[:1].detach()
+            ro, rd = torch.cat([rays_o, extra_o]), torch.cat([rays_d, extra_d])
+            gd = torch.cat([gt_depth, self._gt_max.reshape(1)])
+            d, v, col = orc.render_batch_ray(c, decoders, rd, ro, stage, gd, self.sc["bound"])
+            return d[:-1], v[:-1], col[:-1]
+        return orc.render_batch_ray(c, decoders, rays_d, rays_o, stage, gt_depth, self.sc["bound"])
+
+
+def _worker(rank, world, port, stage, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from scene_util import make_scene
+    from nice_slam_amd.parallel import ShardedRenderer, shard_range
+    sc = make_scene(seed=5, n_rays=23, small=True)           # 23 rays: uneven shards (12 + 11)
+    grids = {k: v.clone().requires_grad_(True) for k, v in sc["grids"].items()}
+    params = {k: v.clone().requires_grad_(True) for k, v in sc["params"].items()}
+    o = sc["rays_o"].clone().requires_grad_(True)
+    d = sc["rays_d"].clone().requires_grad_(True)
+    rend = ShardedRenderer(OracleRenderer(sc))
+    depth, var, rgb = rend.render_batch_ray(grids, params, d, o, "cpu", stage, gt_depth=sc["gt_depth"])
+    w = sc["w"]
+    ((depth * w["depth"]).sum() + (var * w["var"]).sum() + (rgb * w["rgb"]).sum()).backward()
+    # decoder parameters are plain autograd leaves here (the HIP path reduces its flat blob in _reduce_flat)
+    for p in params.values():
+        if p.grad is not None:
+            dist.all_reduce(p.grad)
+    out = {"depth": depth.detach(), "var": var.detach(), "rgb": rgb.detach(), "d_rays_o": o.grad, "d_rays_d": d.grad}
+    out.update({"d_" + k: v.grad for k, v in grids.items() if v.grad is not None})
+    out.update({"dparam/" + k: v.grad for k, v in params.items() if v.grad is not None})
+    out["shard"] = torch.tensor(shard_range(23, world, rank))
+    q.put((rank, {k: v.detach().numpy().copy() for k, v in out.items()}))   # by value: the worker may exit first
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("stage", ["color", "coarse"])
+def test_two_rank_sharding_matches_single_process(stage):
+    from scene_util import make_scene, oracle_render, rel_err
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, stage, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = oracle_render(make_scene(seed=5, n_rays=23, small=True), stage, backward=True)
+    assert res[0]["shard"].tolist() == [0, 12] and res[1]["shard"].tolist() == [12, 23]
+    for rank in (0, 1):
+        for k, v in ref.items():
+            assert rel_err(res[rank][k], v) < 2e-5, (rank, k)
+
+
+def test_shard_range_partition():
+    from nice_slam_amd.parallel import shard_range
+    for n in (0, 1, 7, 8, 1000, 100003):
+        for w in (1, 2, 3, 8):
+            rs = [shard_range(n, w, r) for r in range(w)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+            sizes = [b - a for a, b in rs]
+            assert max(sizes) - min(sizes) <= 1
