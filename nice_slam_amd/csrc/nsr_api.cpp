@@ -110,7 +110,8 @@ int fwd_lds_bytes(int npts) { return round16(3 * nsr::AUX_FLOATS * 4) + npts * (
 int bwd_lds_bytes(int stage, int npts, int tiles) {
     const int npar = max_param_count(stage);
     const int head = (nsr::AUX_FLOATS + npar + 3) & ~3;
-    return round16(head * 4 + npts * (8 + 8 + 16 + 24)) + tiles * (2 * nsr::kTile * nsr::kTxS * 4);
+    const int stg = stage == NSR_STAGE_COARSE ? nsr::stg_floats(0) : nsr::stg_floats(2);     // largest staging region of the stage
+    return round16(head * 4 + npts * (8 + 8 + 16 + 24)) + tiles * stg * 4;
 }
 
 }  // namespace

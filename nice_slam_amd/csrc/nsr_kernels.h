@@ -20,7 +20,7 @@
 #include "../../include/nsr.h"
 
 #ifndef NSR_BWD_TILES
-#define NSR_BWD_TILES 8     // waves per backward block (see nsr_api.cpp)
+#define NSR_BWD_TILES 6     // waves per backward block (see nsr_api.cpp)
 #endif
 
 namespace nsr {
@@ -385,42 +385,143 @@ NSR_DEV void gemv_bwd(f32x4 (&dx)[NTK], const Act<2> &dy, const float *flat, con
     sched_fence();
 }
 
-// acc_lds[W slice] += dy^T x for one 16-channel tile of x (xT = CM operand of that tile)
-NSR_DEV void dw_tile(float *acc_lds, const Mat m, int Tk, const f32x4 (&aT)[2], f32x4 xT, int i, int g) {
+NSR_DEV float red_g(float v) { v += shfl_xor(v, 16); v += shfl_xor(v, 32); return v; }
+NSR_DEV float sin_acc(float x);
+
+// ------------------------------------------------------------------------------------------------
+// Parameter gradients, owner-computes.
+// Measured (tools/lds_atomic_probe.hip): ds_add_f32 costs ~195 cycles per wave instruction per CU, so the
+// per-tile dW blocks are NOT summed with LDS atomics.  Instead every layer is a lock-step phase of the block:
+//   1. each wave stages the operands of its tile (dH, dY, layer input, features, point positions) in LDS,
+//   2. block barrier,
+//   3. each 16x16 block pair of the layer's dW has ONE owner wave, which contracts over the 16 points of
+//      EVERY tile of the block in one MFMA chain (K = 16 x tiles) and adds the result into the block's LDS
+//      image of the flat gradient blob with a plain read-modify-write (exclusive owner => no atomics),
+//   4. block barrier.
+// Per-wave staging region (floats): P[16][4] | DO[16][4] | A0 | A1 | X0 | C[cdim/32]; a tile is 16 rows x 32
+// channels with the column XOR-swizzled by (row&1)<<4 so the transposed reads are bank-conflict free.
+// ------------------------------------------------------------------------------------------------
+constexpr int kStP = 0, kStDO = 64, kStA0 = 128, kStA1 = 128 + 512, kStX0 = 128 + 1024, kStC = 128 + 1536;
+constexpr int stg_floats(int kind) { return 128 + 512 * (3 + cdim_of(kind) / 32); }
+
+NSR_DEV void st_store(float *T, const Act<2> &v, int pt, int g) {
+    const int sw = (pt & 1) << 4;
+    st4(T + pt * 32 + ((4 * g) ^ sw), to_F4(v.t[0]));
+    st4(T + pt * 32 + ((16 + 4 * g) ^ sw), to_F4(v.t[1]));
+}
+// element s = T[4s+g][16*Tt + i]: MFMA operand "lane = channel i of k-tile Tt, k = point 4s+g"
+NSR_DEV f32x4 st_load_cm(const float *T, int Tt, int i, int g) {
+    f32x4 r;
+    const int sw = (g & 1) << 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) r[s] = T[(4 * s + g) * 32 + ((16 * Tt + i) ^ sw)];
+    return r;
+}
+NSR_DEV float st_at(const float *T, int p, int ch) { return T[p * 32 + (ch ^ ((p & 1) << 4))]; }
+
+struct Own {
+    float *img;          // LDS image of the flat parameter-gradient blob (block-wide)
+    const float *stg;    // staging regions of all waves
+    int stride, nw, wave, lane;
+};
+
+// img[W slice, k-tile Tk] += sum over the block's tiles of A^T X.   XSRC 0/1: X staged at x_off (sub-tile x_sub);
+// XSRC 2: X = Fourier embedding recomputed from the staged positions (decoder.py:26-30)
+template <int XSRC>
+NSR_DEV void own_pair(const Own &O, const Mat m, int Tk, int a_off, int x_off, int x_sub, const float *aux) {
+    const int i = O.lane & 15, g = O.lane >> 4;
+    f32x4 d0 = f4zero(), d1 = f4zero();
+    F4 b = F4{0.f, 0.f, 0.f, 0.f};
+    if (XSRC == 2) b = ld4(aux + AUX_BM + (16 * Tk + i) * 4);
+#pragma unroll 2
+    for (int t = 0; t < O.nw; ++t) {
+        const float *S = O.stg + t * O.stride;
+        const f32x4 a0 = st_load_cm(S + a_off, 0, i, g), a1 = st_load_cm(S + a_off, 1, i, g);
+        f32x4 x;
+        if (XSRC == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const F4 pp = ld4(S + kStP + (4 * q + g) * 4);
+                x[q] = sin_acc(fmaf(pp.z, b.z, fmaf(pp.y, b.y, pp.x * b.x)));
+            }
+        } else {
+            x = st_load_cm(S + x_off, x_sub, i, g);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            d0 = mfma16(a0[q], x[q], d0);
+            d1 = mfma16(a1[q], x[q], d1);
+        }
+    }
     const int k = 16 * Tk + i;
+    if (k < m.kcols) {
+        float *w = O.img + m.off + m.kbeg + k;
 #pragma unroll
-    for (int To = 0; To < 2; ++To) {
-        f32x4 d = f4zero();
-#pragma unroll
-        for (int s = 0; s < 4; ++s) d = mfma16(aT[To][s], xT[s], d);
-        if (k < m.kcols) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                atomic_add_lds(acc_lds + m.off + (16 * To + 4 * g + r) * m.stride + m.kbeg + k, d[r]);
+        for (int r = 0; r < 4; ++r) {
+            w[(4 * g + r) * m.stride] += d0[r];
+            w[(16 + 4 * g + r) * m.stride] += d1[r];
         }
     }
 }
-// same with x supplied as a CL activation of 32 channels staged through TxB
-NSR_DEV void dw_act32(float *acc_lds, const Mat m, int Tk0, const f32x4 (&aT)[2], float *TxB, const Act<2> &x, int lane) {
-    const int i = lane & 15, g = lane >> 4;
-    tx_store(TxB, x, i, g);
-    wave_fence();
+// img[off + ch] += sum over tiles and points of A[p][ch]    (bias gradients)
+NSR_DEV void own_colsum(const Own &O, int off, int a_off) {
+    const int ch = O.lane & 31, half = O.lane >> 5;
+    float s = 0.f;
+    for (int t = 0; t < O.nw; ++t) {
+        const float *T = O.stg + t * O.stride + a_off;
 #pragma unroll
-    for (int Tk = 0; Tk < 2; ++Tk) dw_tile(acc_lds, m, Tk0 + Tk, aT, tx_load_cm(TxB, Tk, i, g), i, g);
-    wave_fence();
+        for (int q = 0; q < 8; ++q) s += st_at(T, half * 8 + q, ch);
+    }
+    s += shfl_xor(s, 32);
+    if (half == 0) O.img[off + ch] += s;
 }
-// bias gradient: acc_lds[off + o] += sum over the tile's points of dy[pt][o]
-NSR_DEV void db_tile(float *acc_lds, int off, const f32x4 (&aT)[2], int i, int g) {
+// output layer: img[wo + n*32 + ch] += sum d_out[p][n] * h4[p][ch];  img[bo + n] += sum d_out[p][n]
+template <int NOUT>
+NSR_DEV void own_out(const Own &O, int wo, int bo) {
+    const int ch = O.lane & 31, half = O.lane >> 5;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < O.nw; ++t) {
+        const float *S = O.stg + t * O.stride;
 #pragma unroll
-    for (int To = 0; To < 2; ++To) {
-        float s = (aT[To][0] + aT[To][1]) + (aT[To][2] + aT[To][3]);
-        s += shfl_xor(s, 16);
-        s += shfl_xor(s, 32);
-        if (g == 0) atomic_add_lds(acc_lds + off + 16 * To + i, s);
+        for (int q = 0; q < 8; ++q) {
+            const int p = half * 8 + q;
+            const F4 d = ld4(S + kStDO + p * 4);
+            const float h = st_at(S + kStX0, p, ch);
+            s[0] = fmaf(d.x, h, s[0]); sb[0] += d.x;
+            if (NOUT > 1) { s[1] = fmaf(d.y, h, s[1]); s[2] = fmaf(d.z, h, s[2]); s[3] = fmaf(d.w, h, s[3]); sb[1] += d.y; sb[2] += d.z; sb[3] += d.w; }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) {
+        const float v = s[n] + shfl_xor(s[n], 32);
+        const float bsum = sb[n] + shfl_xor(sb[n], 32);
+        if (half == 0) O.img[wo + n * 32 + ch] += v;
+        if (O.lane == 0) O.img[bo + n] += bsum;
+    }
+}
+// Fourier matrix: img[B + d*93 + ch] += sum darg[p][ch] * p[p][d]  for the 16 channels of k-tile Tk
+// (darg of the whole tile staged as [16][96] starting at kStA0)
+NSR_DEV void own_dB(const Own &O, int Tk, int boff) {
+    const int j = O.lane & 15, pg = O.lane >> 4, ch = 16 * Tk + j;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int t = 0; t < O.nw; ++t) {
+        const float *S = O.stg + t * O.stride;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = 4 * pg + q;
+            const float v = S[kStA0 + p * 96 + ch];
+            const F4 pp = ld4(S + kStP + p * 4);
+            sx = fmaf(v, pp.x, sx); sy = fmaf(v, pp.y, sy); sz = fmaf(v, pp.z, sz);
+        }
+    }
+    sx = red_g(sx); sy = red_g(sy); sz = red_g(sz);
+    if (pg == 0 && ch < kE) {
+        O.img[boff + ch] += sx;
+        O.img[boff + kE + ch] += sy;
+        O.img[boff + 2 * kE + ch] += sz;
     }
 }
 
-NSR_DEV float red_g(float v) { v += shfl_xor(v, 16); v += shfl_xor(v, 32); return v; }
 
 NSR_DEV unsigned relu_mask(f32x4 (&acc)[2]) {
     unsigned m = 0;
@@ -736,16 +837,23 @@ NSR_KERNEL NSR_BOUNDS(512) void eval_points_kernel(const RenderParams P) {
 // ------------------------------------------------------------------------------------------------
 struct BwdFlags { bool grid, params, rays; };
 
+// running index of the first (matrix, k-tile) pair of layer I in the owner round-robin (layers are visited 4..0)
+constexpr int xyz_pairs(int cd, int I) { return cd / 16 + (I > 0 ? 2 : 0) + ((I == 0 || I == 3) ? kET : 0); }
+constexpr int xyz_pair_base(int cd, int I) {
+    int n = 0;
+    for (int j = 4; j > I; --j) n += xyz_pairs(cd, j);
+    return n;
+}
+
 // one layer of the xyz-decoder backward (i = 4..0), instantiated per layer so that every register
 // array index is a compile-time constant
 template <int KIND>
 struct XyzBwd {
     static constexpr int CD = cdim_of(KIND), NTC = CD / 16;
-    const float *__restrict__ flat;
+    const float *flat;
     const float *aux;
-    float *acc_lds, *TxA, *TxB;
-    float px, py, pz;
-    const Act<NTC> &c;
+    Own O;
+    float *S;            // this wave's staging region
     const Kept<KIND> &K;
     BwdFlags F;
     int lane;
@@ -759,51 +867,32 @@ struct XyzBwd {
         constexpr int uid = I == 0 ? XU0 : (I == 1 ? XU1 : (I == 2 ? XU2 : (I == 3 ? XU3 : XU4)));
         constexpr int hid = I == 1 ? XW1 : (I == 2 ? XW2 : (I == 3 ? XW3H : XW4));
         const Mat mu = xyz_mat(CD, uid);
-        // ---- fc_c branch: the gradient of (U_i c + v_i) is dh itself
-        if (F.params) {
-            f32x4 aH[2];
-            tx_store(TxA, dh, i16, g);
-            wave_fence();
-            aH[0] = tx_load_cm(TxA, 0, i16, g);
-            aH[1] = tx_load_cm(TxA, 1, i16, g);
-            db_tile(acc_lds, fcb_off(KIND, I), aH, i16, g);
-#pragma unroll
-            for (int q = 0; q < NTC / 2; ++q) {
-                Act<2> cq;
-                cq.t[0] = c.t[2 * q]; cq.t[1] = c.t[2 * q + 1];
-                dw_act32(acc_lds, mu, 2 * q, aH, TxB, cq, lane);
-            }
-            wave_fence();
-        }
-        if (F.grid || F.rays) gemv_bwd<2>(dc.t, dh, flat, mu, i16, g);     // first 32 feature columns only
-        // ---- main branch
+        if (F.params) st_store(S + kStA0, dh, i16, g);                      // dH_i: gradient of (U_i c + v_i) is dh itself
+        if (F.grid || F.rays) gemv_bwd<2>(dc.t, dh, flat, mu, i16, g);      // first 32 feature columns only
         const Act<2> dY = apply_mask(dh, K.mask[I]);
         if (I == 3) dY3 = dY;
         if (I == 0) dY0 = dY;
         if (F.params) {
-            f32x4 aY[2];
-            tx_store(TxA, dY, i16, g);
-            wave_fence();
-            aY[0] = tx_load_cm(TxA, 0, i16, g);
-            aY[1] = tx_load_cm(TxA, 1, i16, g);
-            db_tile(acc_lds, bias_off(KIND, I), aY, i16, g);
-            if (I == 0 || I == 3) {
-                // x = embedding, produced directly in "lane = channel" form
-                const Mat me = xyz_mat(CD, I == 0 ? XW0 : XW3E);
-                float qx[4], qy[4], qz[4];
+            st_store(S + kStA1, dY, i16, g);
+            if (I > 0) st_store(S + kStX0, K.h[I > 0 ? I - 1 : 0], i16, g);
+            block_sync();
+            int P = xyz_pair_base(CD, I);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) { qx[s] = shfl(px, 4 * s + g); qy[s] = shfl(py, 4 * s + g); qz[s] = shfl(pz, 4 * s + g); }
+            for (int Tk = 0; Tk < NTC; ++Tk, ++P)
+                if (P % O.nw == O.wave) own_pair<1>(O, mu, Tk, kStA0, kStC + (Tk >> 1) * 512, Tk & 1, aux);
+            if (I > 0) {
 #pragma unroll
-                for (int Tk = 0; Tk < kET; ++Tk) {
-                    const F4 b = ld4(aux + AUX_BM + (16 * Tk + i16) * 4);
-                    f32x4 xT;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) xT[s] = sin_acc(fmaf(qz[s], b.z, fmaf(qy[s], b.y, qx[s] * b.x)));
-                    dw_tile(acc_lds, me, Tk, aY, xT, i16, g);
-                }
+                for (int Tk = 0; Tk < 2; ++Tk, ++P)
+                    if (P % O.nw == O.wave) own_pair<0>(O, xyz_mat(CD, hid), Tk, kStA1, kStX0, Tk, aux);
             }
-            if (I > 0) dw_act32(acc_lds, xyz_mat(CD, hid), 0, aY, TxB, K.h[I > 0 ? I - 1 : 0], lane);
-            wave_fence();
+            if (I == 0 || I == 3) {
+#pragma unroll
+                for (int Tk = 0; Tk < kET; ++Tk, ++P)
+                    if (P % O.nw == O.wave) own_pair<2>(O, xyz_mat(CD, I == 0 ? XW0 : XW3E), Tk, kStA1, 0, 0, aux);
+            }
+            if ((2 * (4 - I)) % O.nw == O.wave) own_colsum(O, fcb_off(KIND, I), kStA0);
+            if ((2 * (4 - I) + 1) % O.nw == O.wave) own_colsum(O, bias_off(KIND, I), kStA1);
+            block_sync();
         }
         if (I > 0) {
             Act<2> nd;
@@ -817,9 +906,10 @@ struct XyzBwd {
 // xyz decoder.  c: features (CL).  d_out: gradient of the decoder outputs of this lane's point.
 // dc: gradient w.r.t. the first 32 feature channels (the decoder's own grid).  dp: gradient w.r.t.
 // the fp32 world position through the embedding (already reduced over g).
+// With F.params every wave of the block must call this function (it contains block barriers).
 template <int KIND>
-NSR_DEV void mlp_xyz_bwd(const float *__restrict__ flat, const float *__restrict__ pk, const float *aux, float *acc_lds,
-                         float *TxA, float *TxB, float px, float py, float pz, const Act<cdim_of(KIND) / 16> &c,
+NSR_DEV void mlp_xyz_bwd(const float *flat, const float *pk, const float *aux, const Own &O, float *S,
+                         float px, float py, float pz, const Act<cdim_of(KIND) / 16> &c,
                          const float (&d_out)[nout_of(KIND)], BwdFlags F, int lane, Act<2> &dc, float (&dp)[3]) {
     constexpr int CD = cdim_of(KIND), NOUT = nout_of(KIND), NTC = CD / 16;
     const int i16 = lane & 15, g = lane >> 4;
@@ -842,30 +932,25 @@ NSR_DEV void mlp_xyz_bwd(const float *__restrict__ flat, const float *__restrict
         dh.t[T] = v;
     }
     if (F.params) {
-        tx_store(TxB, K.h[4], i16, g);
-        wave_fence();
-#pragma unroll
-        for (int n = 0; n < NOUT; ++n) {
-            float dn[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) dn[s] = shfl(d_out[n], 4 * s + g);
-#pragma unroll
-            for (int Tk = 0; Tk < 2; ++Tk) {
-                const f32x4 xT = tx_load_cm(TxB, Tk, i16, g);
-                float s = dn[0] * xT[0];
-                s = fmaf(dn[1], xT[1], s); s = fmaf(dn[2], xT[2], s); s = fmaf(dn[3], xT[3], s);
-                s = red_g(s);
-                if (g == 0) atomic_add_lds(acc_lds + wo_off(KIND) + n * 32 + 16 * Tk + i16, s);
-            }
-            float b = (g == 0) ? d_out[n] : 0.f;
-            b = wave_sum(b);
-            if (lane == 0) atomic_add_lds(acc_lds + bo_off(KIND) + n, b);
+        if (g == 0) {
+            st4(S + kStP + i16 * 4, F4{px, py, pz, 0.f});
+            st4(S + kStDO + i16 * 4, F4{d_out[0], NOUT > 1 ? d_out[NOUT > 1 ? 1 : 0] : 0.f, NOUT > 2 ? d_out[NOUT > 2 ? 2 : 0] : 0.f,
+                                        NOUT > 3 ? d_out[NOUT > 3 ? 3 : 0] : 0.f});
         }
-        wave_fence();
+#pragma unroll
+        for (int q = 0; q < NTC / 2; ++q) {
+            Act<2> cq;
+            cq.t[0] = c.t[2 * q]; cq.t[1] = c.t[2 * q + 1];
+            st_store(S + kStC + q * 512, cq, i16, g);
+        }
+        st_store(S + kStX0, K.h[4], i16, g);
+        block_sync();
+        if (O.wave == O.nw - 1) own_out<NOUT>(O, wo_off(KIND), bo_off(KIND));
+        block_sync();
     }
 
     act_zero(dc);
-    XyzBwd<KIND> X{flat, aux, acc_lds, TxA, TxB, px, py, pz, c, K, F, lane, dc, dh};
+    XyzBwd<KIND> X{flat, aux, O, S, K, F, lane, dc, dh};
     act_zero(X.dY3);
     act_zero(X.dY0);
     X.template layer<4>();
@@ -884,7 +969,7 @@ NSR_DEV void mlp_xyz_bwd(const float *__restrict__ flat, const float *__restrict
         float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
         for (int Tk = 0; Tk < kET; ++Tk) {
-            f32x4 dE = f4zero();
+            f32x4 dE = f4zero(), dE2 = f4zero();
             const int k = 16 * Tk + i16;
 #pragma unroll
             for (int To = 0; To < 2; ++To)
@@ -894,8 +979,10 @@ NSR_DEV void mlp_xyz_bwd(const float *__restrict__ flat, const float *__restrict
                     const float w3 = stream_ld(st3, 4 * g * m3.stride + i16, (16 * To + r) * m3.stride + 16 * Tk);
                     const float a0 = (k < kE) ? w0 : 0.f, a3 = (k < kE) ? w3 : 0.f;
                     dE = mfma16(a0, dY0.t[To][r], dE);
-                    dE = mfma16(a3, dY3.t[To][r], dE);
+                    dE2 = mfma16(a3, dY3.t[To][r], dE2);
                 }
+            sched_fence();
+            dE += dE2;
             f32x4 darg;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -904,34 +991,23 @@ NSR_DEV void mlp_xyz_bwd(const float *__restrict__ flat, const float *__restrict
                 darg[r] = dE[r] * cos_acc(arg);
                 ax = fmaf(darg[r], b.x, ax); ay = fmaf(darg[r], b.y, ay); az = fmaf(darg[r], b.z, az);
             }
-            if (need_dB) {
-                // dB[d][ch] += sum_pt darg[pt][ch] * p[pt][d]   (decoder.py:29: x @ B)
-                st4(TxA + i16 * kTxS + 4 * g, to_F4(darg));
-                wave_fence();
-                float sx = 0.f, sy = 0.f, sz = 0.f;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float v = TxA[(4 * s + g) * kTxS + i16];
-                    sx = fmaf(v, shfl(px, 4 * s + g), sx);
-                    sy = fmaf(v, shfl(py, 4 * s + g), sy);
-                    sz = fmaf(v, shfl(pz, 4 * s + g), sz);
-                }
-                sx = red_g(sx); sy = red_g(sy); sz = red_g(sz);
-                if (g == 0 && k < kE) {
-                    atomic_add_lds(acc_lds + B_off(KIND) + 0 * kE + k, sx);
-                    atomic_add_lds(acc_lds + B_off(KIND) + 1 * kE + k, sy);
-                    atomic_add_lds(acc_lds + B_off(KIND) + 2 * kE + k, sz);
-                }
-                wave_fence();
-            }
+            if (need_dB) st4(S + kStA0 + i16 * 96 + 16 * Tk + 4 * g, to_F4(darg));     // [16][96] over A0|A1|X0
         }
         dp[0] = red_g(ax); dp[1] = red_g(ay); dp[2] = red_g(az);
+    }
+    if (need_dB) {
+        block_sync();
+#pragma unroll
+        for (int Tk = 0; Tk < kET; ++Tk)
+            if (Tk % O.nw == O.wave) own_dB(O, Tk, B_off(KIND));
+        block_sync();
     }
 }
 
 struct NoxBwd {
-    const float *__restrict__ flat;
-    float *acc_lds, *TxA, *TxB;
+    const float *flat;
+    Own O;
+    float *S;
     const Act<2> &c;
     const Kept<0> &K;
     BwdFlags F;
@@ -945,15 +1021,21 @@ struct NoxBwd {
         const Act<2> dY = apply_mask(dh, K.mask[I]);
         const Mat mh = nox_mat(I == 0 ? NW0 : (I == 1 ? NW1 : (I == 2 ? NW2 : (I == 3 ? NW3H : NW4))));
         if (F.params) {
-            f32x4 aY[2];
-            tx_store(TxA, dY, i16, g);
-            wave_fence();
-            aY[0] = tx_load_cm(TxA, 0, i16, g);
-            aY[1] = tx_load_cm(TxA, 1, i16, g);
-            db_tile(acc_lds, nox_b(I), aY, i16, g);
-            if (I == 3) dw_act32(acc_lds, nox_mat(NW3C), 0, aY, TxB, c, lane);
-            dw_act32(acc_lds, mh, 0, aY, TxB, I == 0 ? c : K.h[I > 0 ? I - 1 : 0], lane);
-            wave_fence();
+            st_store(S + kStA1, dY, i16, g);
+            st_store(S + kStX0, I == 0 ? c : K.h[I > 0 ? I - 1 : 0], i16, g);
+            block_sync();
+            // pairs visited 4..0: L4 {0,1}  L3 {2,3 (c part), 4,5 (h part)}  L2 {6,7}  L1 {8,9}  L0 {10,11}
+            int P = I == 4 ? 0 : (I == 3 ? 2 : (I == 2 ? 6 : (I == 1 ? 8 : 10)));
+            if (I == 3) {
+#pragma unroll
+                for (int Tk = 0; Tk < 2; ++Tk, ++P)
+                    if (P % O.nw == O.wave) own_pair<1>(O, nox_mat(NW3C), Tk, kStA1, kStC, Tk, nullptr);
+            }
+#pragma unroll
+            for (int Tk = 0; Tk < 2; ++Tk, ++P)
+                if (P % O.nw == O.wave) own_pair<0>(O, mh, Tk, kStA1, kStX0, Tk, nullptr);
+            if ((4 - I + 3) % O.nw == O.wave) own_colsum(O, nox_b(I), kStA1);
+            block_sync();
         }
         if (I == 3) gemv_bwd<2>(dc.t, dY, flat, nox_mat(NW3C), i16, g);
         if (I == 0) {
@@ -968,8 +1050,8 @@ struct NoxBwd {
 };
 
 // coarse decoder backward (MLP_no_xyz)
-NSR_DEV void mlp_nox_bwd(const float *__restrict__ flat, const float *__restrict__ pk, const float *aux, float *acc_lds,
-                         float *TxA, float *TxB, const Act<2> &c, float d_out, BwdFlags F, int lane, Act<2> &dc) {
+NSR_DEV void mlp_nox_bwd(const float *flat, const float *pk, const float *aux, const Own &O, float *S,
+                         const Act<2> &c, float d_out, BwdFlags F, int lane, Act<2> &dc) {
     const int i16 = lane & 15, g = lane >> 4;
     Kept<0> K;
     float out[1];
@@ -983,26 +1065,15 @@ NSR_DEV void mlp_nox_bwd(const float *__restrict__ flat, const float *__restrict
         dh.t[T] = v;
     }
     if (F.params) {
-        tx_store(TxB, K.h[4], i16, g);
-        wave_fence();
-        float dn[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) dn[s] = shfl(d_out, 4 * s + g);
-#pragma unroll
-        for (int Tk = 0; Tk < 2; ++Tk) {
-            const f32x4 xT = tx_load_cm(TxB, Tk, i16, g);
-            float s = dn[0] * xT[0];
-            s = fmaf(dn[1], xT[1], s); s = fmaf(dn[2], xT[2], s); s = fmaf(dn[3], xT[3], s);
-            s = red_g(s);
-            if (g == 0) atomic_add_lds(acc_lds + nox_wo() + 16 * Tk + i16, s);
-        }
-        float b = (g == 0) ? d_out : 0.f;
-        b = wave_sum(b);
-        if (lane == 0) atomic_add_lds(acc_lds + nox_bo(), b);
-        wave_fence();
+        if (g == 0) st4(S + kStDO + i16 * 4, F4{d_out, 0.f, 0.f, 0.f});
+        st_store(S + kStC, c, i16, g);
+        st_store(S + kStX0, K.h[4], i16, g);
+        block_sync();
+        if (O.wave == O.nw - 1) own_out<1>(O, nox_wo(), nox_bo());
+        block_sync();
     }
     act_zero(dc);
-    NoxBwd X{flat, acc_lds, TxA, TxB, c, K, F, lane, dc, dh};
+    NoxBwd X{flat, O, S, c, K, F, lane, dc, dh};
     X.layer<4>();
     X.layer<3>();
     X.layer<2>();
@@ -1014,7 +1085,7 @@ NSR_DEV void mlp_nox_bwd(const float *__restrict__ flat, const float *__restrict
 // backward kernel.  grid = (blocks, passes); pass p handles one decoder:
 //   coarse stage: p0 = coarse.   otherwise: p0 = middle, p1 = fine, p2 = color.
 // LDS: aux[AUX] | acc[param_total] | ztmp f64[npts] | zbuf f64[npts] | draw F4[npts] | dpb f64[npts*3]
-//      | per-wave TxA, TxB
+//      | per-wave staging regions (stg_floats(KIND) each)
 // ------------------------------------------------------------------------------------------------
 template <int KIND>
 NSR_DEV void bwd_pass(const RenderParams &P) {
@@ -1029,9 +1100,9 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
     double *zbuf = ztmp + npts;
     F4 *draw = reinterpret_cast<F4 *>(zbuf + npts);
     double *dpb = reinterpret_cast<double *>(draw + npts);
-    const int tx_off = (head * 4 + npts * (8 + 8 + 16 + 24) + 15) & ~15;
-    float *TxA = reinterpret_cast<float *>(lds + tx_off) + wave * (2 * kTile * kTxS);
-    float *TxB = TxA + kTile * kTxS;
+    const int stg_off = (head * 4 + npts * (8 + 8 + 16 + 24) + 15) & ~15;
+    float *stg = reinterpret_cast<float *>(lds + stg_off);
+    float *Sw = stg + wave * stg_floats(KIND);             // this wave's staging region (also Tx / tab of the scatter)
 
     const GridDev &G = P.grid[KIND];
     const DecDev &D = P.dec[KIND];
@@ -1043,6 +1114,7 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
 
     load_aux<KIND>(aux, D.params);
     if (F.params) for (int t = tid(); t < NPAR; t += nthreads()) acc[t] = 0.f;
+    const Own O{acc, stg, stg_floats(KIND), nwaves, wave, lane};
 
     for (long long grp = bid_x(); grp < P.n_groups; grp += nblk_x()) {
         loop_fence();       // weights are loop-invariant: keep LICM from hoisting ~250 operand loads into registers
@@ -1097,24 +1169,24 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
             Act<2> dc;
             float dpe[3] = {0.f, 0.f, 0.f};
             if (KIND == NSR_COARSE) {
-                mlp_nox_bwd(D.params, D.packed, aux, acc, TxA, TxB, c, dr.w, F, lane, dc);
+                mlp_nox_bwd(D.params, D.packed, aux, O, Sw, c, dr.w, F, lane, dc);
             } else if (KIND == NSR_MIDDLE) {
                 float d_out[1] = {dr.w};
-                mlp_xyz_bwd<NSR_MIDDLE>(D.params, D.packed, aux, acc, TxA, TxB, (float)px, (float)py, (float)pz, c, d_out, F, lane, dc, dpe);
+                mlp_xyz_bwd<NSR_MIDDLE>(D.params, D.packed, aux, O, Sw, (float)px, (float)py, (float)pz, c, d_out, F, lane, dc, dpe);
             } else if (KIND == NSR_FINE) {
                 const Lvl Lm = make_level(P.grid[NSR_MIDDLE], px, py, pz);
                 const Act<2> cm = gather_feat(P.grid[NSR_MIDDLE], Lm, g);
                 Act<4> cc;
                 cc.t[0] = c.t[0]; cc.t[1] = c.t[1]; cc.t[2] = cm.t[0]; cc.t[3] = cm.t[1];
                 float d_out[1] = {dr.w};
-                mlp_xyz_bwd<NSR_FINE>(D.params, D.packed, aux, acc, TxA, TxB, (float)px, (float)py, (float)pz, cc, d_out, F, lane, dc, dpe);
+                mlp_xyz_bwd<NSR_FINE>(D.params, D.packed, aux, O, Sw, (float)px, (float)py, (float)pz, cc, d_out, F, lane, dc, dpe);
             } else {
                 float d_out[4] = {dr.x, dr.y, dr.z, 0.f};          // decoder.py:341 overwrites the 4th colour output
-                mlp_xyz_bwd<NSR_COLOR>(D.params, D.packed, aux, acc, TxA, TxB, (float)px, (float)py, (float)pz, c, d_out, F, lane, dc, dpe);
+                mlp_xyz_bwd<NSR_COLOR>(D.params, D.packed, aux, O, Sw, (float)px, (float)py, (float)pz, c, d_out, F, lane, dc, dpe);
             }
             float dux = 0.f, duy = 0.f, duz = 0.f;
             if (F.rays) coord_grad(G, L, g, dc, dux, duy, duz);
-            if (F.grid) scatter_merged(G, L, lane, dc, active, TxA, TxB);
+            if (F.grid) scatter_merged(G, L, lane, dc, active, Sw + kStA0, Sw + kStA0 + kTile * kTxS);
             if (F.rays && active && g == 0) {
                 // d p = d u * (n-1)/2 * 2/(hi-lo)  (+ embedding part), fp64 like autograd through Renderer.py:172
                 dpb[pidx * 3 + 0] = (double)dux * (2.0 * G.inv[0]) + (double)dpe[0];
