@@ -97,19 +97,27 @@ int finish(const char *what) {
     return 0;
 }
 
+// raise the dynamic-LDS limit of a kernel once per process and size (not a stream operation, but kept out of the
+// steady state so that a captured hipGraph contains kernel launches only)
 template <typename K>
 int launch_cfg(K kernel, int lds_bytes, const char *what) {
     if (lds_bytes > kLdsLimit) return fail(std::string(what) + ": LDS budget exceeded");
-    if (lds_bytes > 48 * 1024)
+    static thread_local int granted = 0;         // one instance per kernel type K
+    if (lds_bytes > 48 * 1024 && lds_bytes > granted) {
         if (const char *e = nsr::rt_allow_lds(kernel, lds_bytes)) return fail(std::string(what) + ": " + e);
+        granted = lds_bytes;
+    }
     return 0;
 }
 
-int fwd_lds_bytes(int npts) { return round16(3 * nsr::AUX_FLOATS * 4) + npts * (8 + 8 + 16); }
+int fwd_lds_bytes(int stage, int npts) {
+    const int wl = stage == NSR_STAGE_COARSE ? nsr::packed_total(0) : (stage == NSR_STAGE_MIDDLE ? nsr::packed_total(1) : nsr::packed_total(2));
+    return round16(3 * nsr::AUX_FLOATS * 4) + npts * (8 + 8 + 16) + wl * 4;
+}
 
 int bwd_lds_bytes(int stage, int npts, int tiles) {
-    const int npar = max_param_count(stage);
-    const int head = (nsr::AUX_FLOATS + npar + 3) & ~3;
+    const int npk = stage == NSR_STAGE_COARSE ? nsr::packed_total(0) : nsr::packed_total(2);   // largest packed stream of the stage
+    const int head = (nsr::AUX_FLOATS + npk + 3) & ~3;
     const int stg = stage == NSR_STAGE_COARSE ? nsr::stg_floats(0) : nsr::stg_floats(2);     // largest staging region of the stage
     return round16(head * 4 + npts * (8 + 8 + 16 + 24)) + tiles * stg * 4;
 }
@@ -151,7 +159,7 @@ int nsr_render_fwd(const nsr_render_args *a, void *stream) {
     if (!a->depth || !a->var || !a->rgb) return fail("nsr_render_fwd: null output pointer");
     if (P.n_rays == 0) return 0;
     const int npts = P.rays_per_block * P.S;
-    const int lds = fwd_lds_bytes(npts);
+    const int lds = fwd_lds_bytes(P.stage, npts);
     const dim3 grid((unsigned)(P.n_groups < (1 << 20) ? P.n_groups : (1 << 20))), block(64 * P.tiles_per_block);
 #define NSR_FWD(ST)                                                                              \
     case ST:                                                                                     \

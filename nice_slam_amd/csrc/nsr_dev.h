@@ -68,6 +68,10 @@ NSR_DEV float stream_ld(const Stream &s, int lane_off, int const_off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, lane_off * 4, const_off * 4, 0));
 }
 
+NSR_DEV void stream_st(const Stream &s, int lane_off, int const_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), s.rsrc, lane_off * 4, const_off * 4, 0);
+}
+
 NSR_DEV F4 ld4(const float *p) { float4 v = *reinterpret_cast<const float4 *>(p); return F4{v.x, v.y, v.z, v.w}; }
 NSR_DEV void st4(float *p, F4 v) { *reinterpret_cast<float4 *>(p) = make_float4(v.x, v.y, v.z, v.w); }
 

@@ -348,8 +348,27 @@ NSR_DEV void scatter_merged(const GridDev &G, const Lvl &L, int lane, const Act<
 // MFMA building blocks
 // ------------------------------------------------------------------------------------------------
 // acc[Tp] += W(slice) * x          (A from the packed stream, B = x registers)
-template <int NT>
+// LDSW: `pk` points at the decoder's packed stream staged in LDS (row r, lane l at pk[r*64 + l], conflict-free);
+// otherwise it is the global packed stream, read with buffer loads.
+template <int NT, bool LDSW>
 NSR_DEV void gemv_fwd(f32x4 (&acc)[2], const Act<NT> &x, const float *pk, int lane) {
+    if (LDSW) {
+        // explicit operand ring, depth kD steps (2 LDS reads each): bounds the reads in flight to 2*kD registers
+        // (the scheduler would otherwise hoist all 2*4*NT reads of the slice and spill) while covering the
+        // ~100-cycle LDS latency behind kD MFMA pairs.
+        constexpr int kD = 4, NS = NT * 4;
+        float ra[kD], rb[kD];
+#pragma unroll
+        for (int q = 0; q < kD; ++q) { ra[q] = pk[(q * 2) * 64 + lane]; rb[q] = pk[(q * 2) * 64 + 64 + lane]; }
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            acc[0] = mfma16(ra[q % kD], x.t[q >> 2][q & 3], acc[0]);
+            acc[1] = mfma16(rb[q % kD], x.t[q >> 2][q & 3], acc[1]);
+            if (q + kD < NS) { ra[q % kD] = pk[((q + kD) * 2) * 64 + lane]; rb[q % kD] = pk[((q + kD) * 2) * 64 + 64 + lane]; }
+        }
+        sched_fence();
+        return;
+    }
     const Stream st = make_stream(pk);      // scalar descriptor; the lane offset is the only VGPR
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
@@ -364,11 +383,35 @@ NSR_DEV void gemv_fwd(f32x4 (&acc)[2], const Act<NT> &x, const float *pk, int la
     sched_fence();
 }
 
-// dx[Tk] += W(slice)^T * dy       (A = W row-major from the flat blob, B = dy registers)
-template <int NTK>
-NSR_DEV void gemv_bwd(f32x4 (&dx)[NTK], const Act<2> &dy, const float *flat, const Mat m, int i, int g) {
-    const Stream st = make_stream(flat + m.off + m.kbeg);            // wave-uniform descriptor
-    const int lo = 4 * g * m.stride + i;                             // the only lane-dependent part
+// dx[Tk] += W(slice)^T * dy       (B = dy registers; A = W[16To+4g+r][16Tk+i])
+// LDSW: read from the packed stream in LDS (`w` = LDS base of the slice): element W[o][k] of a slice sits at
+//   Tk*512 + (k&3)*128 + (o>>4)*64 + (o&15) + 16*((k>>2)&3)    -- 8-way bank conflict, ~16 cycles per read, fine
+// next to a 64-cycle MFMA pair; columns beyond kcols are zero in the packed stream.
+// otherwise: W row-major from the flat parameter blob (64-byte runs) with buffer loads.
+template <int NTK, bool LDSW>
+NSR_DEV void gemv_bwd(f32x4 (&dx)[NTK], const Act<2> &dy, const float *w, const Mat m, int i, int g) {
+    if (LDSW) {
+        const int lo = (i & 3) * 128 + 16 * (i >> 2) + 4 * g;
+        constexpr int kD = 4, NS = 8;                     // step q = (To, r); NTK reads + NTK MFMAs per step
+        float ra[kD][NTK];
+#pragma unroll
+        for (int q = 0; q < kD; ++q)
+#pragma unroll
+            for (int Tk = 0; Tk < NTK; ++Tk) ra[q][Tk] = w[Tk * 512 + (q >> 2) * 64 + (q & 3) + lo];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+#pragma unroll
+            for (int Tk = 0; Tk < NTK; ++Tk) dx[Tk] = mfma16(ra[q % kD][Tk], dy.t[q >> 2][q & 3], dx[Tk]);
+            if (q + kD < NS) {
+#pragma unroll
+                for (int Tk = 0; Tk < NTK; ++Tk) ra[q % kD][Tk] = w[Tk * 512 + ((q + kD) >> 2) * 64 + ((q + kD) & 3) + lo];
+            }
+        }
+        sched_fence();
+        return;
+    }
+    const Stream st = make_stream(w + m.off + m.kbeg);
+    const int lo = 4 * g * m.stride + i;
 #pragma unroll
     for (int To = 0; To < 2; ++To) {
 #pragma unroll
@@ -376,13 +419,18 @@ NSR_DEV void gemv_bwd(f32x4 (&dx)[NTK], const Act<2> &dy, const float *flat, con
 #pragma unroll
             for (int Tk = 0; Tk < NTK; ++Tk) {
                 const int k = 16 * Tk + i;
-                const float w = stream_ld(st, lo, (16 * To + r) * m.stride + 16 * Tk);   // always inside the blob
-                const float a = (k < m.kcols) ? w : 0.f;
-                dx[Tk] = mfma16(a, dy.t[To][r], dx[Tk]);
+                const float v = stream_ld(st, lo, (16 * To + r) * m.stride + 16 * Tk);   // always inside the blob
+                dx[Tk] = mfma16((k < m.kcols) ? v : 0.f, dy.t[To][r], dx[Tk]);
             }
         }
     }
     sched_fence();
+}
+
+// cooperative copy of a decoder's packed operand stream into LDS (caller provides the barriers)
+template <int KIND>
+NSR_DEV void load_packed(float *wl, const float *__restrict__ packed) {
+    for (int t = tid(); t < packed_total(KIND) / 4; t += nthreads()) st4(wl + 4 * t, ld4(packed + 4 * t));
 }
 
 NSR_DEV float red_g(float v) { v += shfl_xor(v, 16); v += shfl_xor(v, 32); return v; }
@@ -420,10 +468,16 @@ NSR_DEV f32x4 st_load_cm(const float *T, int Tt, int i, int g) {
 NSR_DEV float st_at(const float *T, int p, int ch) { return T[p * 32 + (ch ^ ((p & 1) << 4))]; }
 
 struct Own {
-    float *img;          // LDS image of the flat parameter-gradient blob (block-wide)
+    Stream img;          // this block's image of the flat parameter-gradient blob (global partial buffer, L2 resident);
+                         // addressed through a buffer descriptor: 32-bit offsets, no 64-bit address registers
     const float *stg;    // staging regions of all waves
     int stride, nw, wave, lane;
+    bool first;          // first ray group of this block: store instead of accumulate (no zero-fill needed)
 };
+NSR_DEV void img_add(const Own &O, int lane_off, int const_off, float v) {
+    if (!O.first) v += stream_ld(O.img, lane_off, const_off);
+    stream_st(O.img, lane_off, const_off, v);
+}
 
 // img[W slice, k-tile Tk] += sum over the block's tiles of A^T X.   XSRC 0/1: X staged at x_off (sub-tile x_sub);
 // XSRC 2: X = Fourier embedding recomputed from the staged positions (decoder.py:26-30)
@@ -455,11 +509,11 @@ NSR_DEV void own_pair(const Own &O, const Mat m, int Tk, int a_off, int x_off, i
     }
     const int k = 16 * Tk + i;
     if (k < m.kcols) {
-        float *w = O.img + m.off + m.kbeg + k;
+        const int lo = 4 * g * m.stride + i;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            w[(4 * g + r) * m.stride] += d0[r];
-            w[(16 + 4 * g + r) * m.stride] += d1[r];
+            img_add(O, lo, m.off + m.kbeg + 16 * Tk + r * m.stride, d0[r]);
+            img_add(O, lo, m.off + m.kbeg + 16 * Tk + (16 + r) * m.stride, d1[r]);
         }
     }
 }
@@ -473,7 +527,7 @@ NSR_DEV void own_colsum(const Own &O, int off, int a_off) {
         for (int q = 0; q < 8; ++q) s += st_at(T, half * 8 + q, ch);
     }
     s += shfl_xor(s, 32);
-    if (half == 0) O.img[off + ch] += s;
+    if (half == 0) img_add(O, ch, off, s);
 }
 // output layer: img[wo + n*32 + ch] += sum d_out[p][n] * h4[p][ch];  img[bo + n] += sum d_out[p][n]
 template <int NOUT>
@@ -495,8 +549,8 @@ NSR_DEV void own_out(const Own &O, int wo, int bo) {
     for (int n = 0; n < NOUT; ++n) {
         const float v = s[n] + shfl_xor(s[n], 32);
         const float bsum = sb[n] + shfl_xor(sb[n], 32);
-        if (half == 0) O.img[wo + n * 32 + ch] += v;
-        if (O.lane == 0) O.img[bo + n] += bsum;
+        if (half == 0) img_add(O, ch, wo + n * 32, v);
+        if (O.lane == 0) img_add(O, 0, bo + n, bsum);
     }
 }
 // Fourier matrix: img[B + d*93 + ch] += sum darg[p][ch] * p[p][d]  for the 16 channels of k-tile Tk
@@ -516,9 +570,9 @@ NSR_DEV void own_dB(const Own &O, int Tk, int boff) {
     }
     sx = red_g(sx); sy = red_g(sy); sz = red_g(sz);
     if (pg == 0 && ch < kE) {
-        O.img[boff + ch] += sx;
-        O.img[boff + kE + ch] += sy;
-        O.img[boff + 2 * kE + ch] += sz;
+        img_add(O, j, boff + 16 * Tk, sx);
+        img_add(O, j, boff + kE + 16 * Tk, sy);
+        img_add(O, j, boff + 2 * kE + 16 * Tk, sz);
     }
 }
 
@@ -595,8 +649,8 @@ struct Kept {
 };
 
 // MLP (decoder.py:177-203): h_i = relu(W_i x_i + b_i) + (U_i c + v_i), x_3 = [e | h_2]
-template <int KIND, bool KEEP>
-NSR_DEV void mlp_xyz_fwd(const float *__restrict__ pk, const float *aux, float px, float py, float pz,
+template <int KIND, bool KEEP, bool LDSW>
+NSR_DEV void mlp_xyz_fwd(const float *pk, const float *aux, float px, float py, float pz,
                          const Act<cdim_of(KIND) / 16> &c, int lane, float (&out)[nout_of(KIND)], Kept<KIND> *kept) {
     constexpr int CD = cdim_of(KIND), NOUT = nout_of(KIND), NTC = CD / 16;
     const int g = lane >> 4;
@@ -610,17 +664,17 @@ NSR_DEV void mlp_xyz_fwd(const float *__restrict__ pk, const float *aux, float p
         acc[0] = to_v(ld4(aux + AUX_B + i * 32 + 4 * g));
         acc[1] = to_v(ld4(aux + AUX_B + i * 32 + 16 + 4 * g));
         if (i == 0) {
-            gemv_fwd<kET>(acc, e, pk + xyz_mat(CD, XW0).pk, lane);
+            gemv_fwd<kET, LDSW>(acc, e, pk + xyz_mat(CD, XW0).pk, lane);
         } else if (i == 3) {
-            gemv_fwd<kET>(acc, e, pk + xyz_mat(CD, XW3E).pk, lane);
-            gemv_fwd<2>(acc, h, pk + xyz_mat(CD, XW3H).pk, lane);
+            gemv_fwd<kET, LDSW>(acc, e, pk + xyz_mat(CD, XW3E).pk, lane);
+            gemv_fwd<2, LDSW>(acc, h, pk + xyz_mat(CD, XW3H).pk, lane);
         } else {
-            gemv_fwd<2>(acc, h, pk + xyz_mat(CD, i == 1 ? XW1 : (i == 2 ? XW2 : XW4)).pk, lane);
+            gemv_fwd<2, LDSW>(acc, h, pk + xyz_mat(CD, i == 1 ? XW1 : (i == 2 ? XW2 : XW4)).pk, lane);
         }
         const unsigned m = relu_mask(acc);
         acc[0] += to_v(ld4(aux + AUX_V + i * 32 + 4 * g));
         acc[1] += to_v(ld4(aux + AUX_V + i * 32 + 16 + 4 * g));
-        gemv_fwd<NTC>(acc, c, pk + xyz_mat(CD, i == 0 ? XU0 : (i == 1 ? XU1 : (i == 2 ? XU2 : (i == 3 ? XU3 : XU4)))).pk, lane);
+        gemv_fwd<NTC, LDSW>(acc, c, pk + xyz_mat(CD, i == 0 ? XU0 : (i == 1 ? XU1 : (i == 2 ? XU2 : (i == 3 ? XU3 : XU4)))).pk, lane);
         h.t[0] = acc[0];
         h.t[1] = acc[1];
         if (KEEP) { kept->h[i] = h; kept->mask[i] = m; }
@@ -636,8 +690,8 @@ NSR_DEV void mlp_xyz_fwd(const float *__restrict__ pk, const float *aux, float p
 }
 
 // MLP_no_xyz (decoder.py:262-274): h = c; h = relu(W_i h + b_i); after i == 2: h = [c | h]
-template <bool KEEP>
-NSR_DEV void mlp_nox_fwd(const float *__restrict__ pk, const float *aux, const Act<2> &c, int lane, float (&out)[1], Kept<0> *kept) {
+template <bool KEEP, bool LDSW>
+NSR_DEV void mlp_nox_fwd(const float *pk, const float *aux, const Act<2> &c, int lane, float (&out)[1], Kept<0> *kept) {
     const int g = lane >> 4;
     Act<2> h = c;
 #pragma unroll
@@ -646,10 +700,10 @@ NSR_DEV void mlp_nox_fwd(const float *__restrict__ pk, const float *aux, const A
         acc[0] = to_v(ld4(aux + AUX_B + i * 32 + 4 * g));
         acc[1] = to_v(ld4(aux + AUX_B + i * 32 + 16 + 4 * g));
         if (i == 3) {
-            gemv_fwd<2>(acc, c, pk + nox_mat(NW3C).pk, lane);
-            gemv_fwd<2>(acc, h, pk + nox_mat(NW3H).pk, lane);
+            gemv_fwd<2, LDSW>(acc, c, pk + nox_mat(NW3C).pk, lane);
+            gemv_fwd<2, LDSW>(acc, h, pk + nox_mat(NW3H).pk, lane);
         } else {
-            gemv_fwd<2>(acc, h, pk + nox_mat(i == 0 ? NW0 : (i == 1 ? NW1 : (i == 2 ? NW2 : NW4))).pk, lane);
+            gemv_fwd<2, LDSW>(acc, h, pk + nox_mat(i == 0 ? NW0 : (i == 1 ? NW1 : (i == 2 ? NW2 : NW4))).pk, lane);
         }
         const unsigned m = relu_mask(acc);
         h.t[0] = acc[0];
@@ -678,14 +732,14 @@ NSR_DEV F4 decode_point(const RenderParams &P, const float *aux, double px, doub
         const Lvl L = make_level(P.grid[NSR_COARSE], px, py, pz);
         const Act<2> c = gather_feat(P.grid[NSR_COARSE], L, g);
         float o[1];
-        mlp_nox_fwd<false>(P.dec[NSR_COARSE].packed, aux, c, lane, o, nullptr);
+        mlp_nox_fwd<false, false>(P.dec[NSR_COARSE].packed, aux, c, lane, o, nullptr);
         raw.w = o[0];
     } else {
         const float fx = (float)px, fy = (float)py, fz = (float)pz;     // decoder.py:189
         const Lvl Lm = make_level(P.grid[NSR_MIDDLE], px, py, pz);
         const Act<2> cm = gather_feat(P.grid[NSR_MIDDLE], Lm, g);
         float om[1];
-        mlp_xyz_fwd<NSR_MIDDLE, false>(P.dec[NSR_MIDDLE].packed, aux, fx, fy, fz, cm, lane, om, nullptr);
+        mlp_xyz_fwd<NSR_MIDDLE, false, false>(P.dec[NSR_MIDDLE].packed, aux, fx, fy, fz, cm, lane, om, nullptr);
         float occ = om[0];
         if (STAGE >= NSR_STAGE_FINE) {
             const Lvl Lf = make_level(P.grid[NSR_FINE], px, py, pz);
@@ -693,14 +747,14 @@ NSR_DEV F4 decode_point(const RenderParams &P, const float *aux, double px, doub
             Act<4> cc;
             cc.t[0] = cf.t[0]; cc.t[1] = cf.t[1]; cc.t[2] = cm.t[0]; cc.t[3] = cm.t[1];    // decoder.py:182-187
             float of[1];
-            mlp_xyz_fwd<NSR_FINE, false>(P.dec[NSR_FINE].packed, aux + AUX_FLOATS, fx, fy, fz, cc, lane, of, nullptr);
+            mlp_xyz_fwd<NSR_FINE, false, false>(P.dec[NSR_FINE].packed, aux + AUX_FLOATS, fx, fy, fz, cc, lane, of, nullptr);
             occ = of[0] + om[0];                                                            // decoder.py:333,341
         }
         if (STAGE == NSR_STAGE_COLOR) {
             const Lvl Lc = make_level(P.grid[NSR_COLOR], px, py, pz);
             const Act<2> ccol = gather_feat(P.grid[NSR_COLOR], Lc, g);
             float oc[4];
-            mlp_xyz_fwd<NSR_COLOR, false>(P.dec[NSR_COLOR].packed, aux + 2 * AUX_FLOATS, fx, fy, fz, ccol, lane, oc, nullptr);
+            mlp_xyz_fwd<NSR_COLOR, false, false>(P.dec[NSR_COLOR].packed, aux + 2 * AUX_FLOATS, fx, fy, fz, ccol, lane, oc, nullptr);
             raw.x = oc[0]; raw.y = oc[1]; raw.z = oc[2];
         }
         raw.w = occ;
@@ -754,10 +808,11 @@ NSR_DEV double wave_sum_d(double v) {
 
 // ------------------------------------------------------------------------------------------------
 // forward kernel
-// LDS: aux[3*AUX] | ztmp[npts] f64 | zbuf[npts] f64 | rawbuf[npts] F4
+// LDS: aux[3*AUX] | ztmp[npts] f64 | zbuf[npts] f64 | rawbuf[npts] F4 | wl: packed weights of the decoder in flight
+// The three decoders of a stage are evaluated one after the other; before each one the block stages that
+// decoder's packed operand stream (61-82 KB) in LDS so that every MFMA operand is an LDS read (~100 cycles)
+// instead of an L2 round trip.  The gathers of the next decoder's features are issued before the barrier.
 // ------------------------------------------------------------------------------------------------
-NSR_DEV int lds_fwd_floats(int npts) { return 3 * AUX_FLOATS + 4 * npts + 4 * npts; }
-
 template <int STAGE>
 NSR_KERNEL NSR_BOUNDS(768) void render_fwd_kernel(const RenderParams P) {
     char *lds = lds_base();
@@ -766,48 +821,88 @@ NSR_KERNEL NSR_BOUNDS(768) void render_fwd_kernel(const RenderParams P) {
     double *ztmp = reinterpret_cast<double *>(lds + sizeof(float) * (3 * AUX_FLOATS + (3 * AUX_FLOATS & 1)));
     double *zbuf = ztmp + npts;
     F4 *rawbuf = reinterpret_cast<F4 *>(zbuf + npts);
-    const int lane = tid() & 63, wave = tid() >> 6, nwaves = nthreads() >> 6;
+    float *wl = reinterpret_cast<float *>(rawbuf + npts);
+    const int lane = tid() & 63, wave = tid() >> 6, nwaves = nthreads() >> 6, g = lane >> 4;
     const int S = P.S;
 
     load_stage_aux<STAGE>(P, aux);
+    if (STAGE == NSR_STAGE_COARSE) load_packed<NSR_COARSE>(wl, P.dec[NSR_COARSE].packed);     // only one decoder: staged once
     for (long long grp = bid_x(); grp < P.n_groups; grp += nblk_x()) {
-        loop_fence();       // weights are loop-invariant: keep LICM from hoisting ~250 operand loads into registers
+        loop_fence();
         const long long ray0 = grp * P.rays_per_block;
-        compute_z(P, ray0, ztmp, zbuf);            // ends with block_sync (also covers the aux load)
-        {   // decode the tile of this wave
-            const int pidx = wave * kTile + (lane & 15);
-            const int r = pidx / S, k = pidx - r * S;
-            const long long ray = ray0 + r;
-            const bool active = (pidx < npts) && (ray < P.n_rays);
-            const long long rr = active ? ray : 0;
-            const double z = active ? zbuf[pidx] : 0.0;
-            // pts = o + d*z in fp64 (Renderer.py:172-174)
-            const double px = (double)P.rays_o[rr * 3 + 0] + (double)P.rays_d[rr * 3 + 0] * z;
-            const double py = (double)P.rays_o[rr * 3 + 1] + (double)P.rays_d[rr * 3 + 1] * z;
-            const double pz = (double)P.rays_o[rr * 3 + 2] + (double)P.rays_d[rr * 3 + 2] * z;
-            const F4 raw = decode_point<STAGE>(P, aux, px, py, pz, lane);
-            if (active && (lane >> 4) == 0) {
-                rawbuf[pidx] = raw;
-                if (P.raw) st4(P.raw + (ray * S + k) * 4, raw);
+        if (STAGE != NSR_STAGE_COARSE) load_packed<NSR_MIDDLE>(wl, P.dec[NSR_MIDDLE].packed);
+        compute_z(P, ray0, ztmp, zbuf);            // ends with block_sync (also covers the aux / weight staging)
+        const int pidx = wave * kTile + (lane & 15);
+        const int r = pidx / S, k = pidx - r * S;
+        const long long ray = ray0 + r;
+        const bool active = (pidx < npts) && (ray < P.n_rays);
+        const long long rr = active ? ray : 0;
+        const double z = active ? zbuf[pidx] : 0.0;
+        // pts = o + d*z in fp64 (Renderer.py:172-174)
+        const double px = (double)P.rays_o[rr * 3 + 0] + (double)P.rays_d[rr * 3 + 0] * z;
+        const double py = (double)P.rays_o[rr * 3 + 1] + (double)P.rays_d[rr * 3 + 1] * z;
+        const double pz = (double)P.rays_o[rr * 3 + 2] + (double)P.rays_d[rr * 3 + 2] * z;
+        const bool inside = (px > P.blo[0]) && (px < P.bhi[0]) && (py > P.blo[1]) && (py < P.bhi[1]) &&
+                            (pz > P.blo[2]) && (pz < P.bhi[2]);
+        F4 raw = F4{0.f, 0.f, 0.f, 0.f};
+        if (STAGE == NSR_STAGE_COARSE) {
+            const Lvl L = make_level(P.grid[NSR_COARSE], px, py, pz);
+            const Act<2> c = gather_feat(P.grid[NSR_COARSE], L, g);
+            float o[1];
+            mlp_nox_fwd<false, true>(wl, aux, c, lane, o, nullptr);
+            raw.w = o[0];
+        } else {
+            const float fx = (float)px, fy = (float)py, fz = (float)pz;     // decoder.py:189
+            const Lvl Lm = make_level(P.grid[NSR_MIDDLE], px, py, pz);
+            const Act<2> cm = gather_feat(P.grid[NSR_MIDDLE], Lm, g);
+            float om[1];
+            mlp_xyz_fwd<NSR_MIDDLE, false, true>(wl, aux, fx, fy, fz, cm, lane, om, nullptr);
+            float occ = om[0];
+            if (STAGE >= NSR_STAGE_FINE) {
+                const Lvl Lf = make_level(P.grid[NSR_FINE], px, py, pz);
+                const Act<2> cf = gather_feat(P.grid[NSR_FINE], Lf, g);
+                block_sync();                                               // everyone is done with the middle weights
+                load_packed<NSR_FINE>(wl, P.dec[NSR_FINE].packed);
+                block_sync();
+                Act<4> cc;
+                cc.t[0] = cf.t[0]; cc.t[1] = cf.t[1]; cc.t[2] = cm.t[0]; cc.t[3] = cm.t[1];    // decoder.py:182-187
+                float of[1];
+                mlp_xyz_fwd<NSR_FINE, false, true>(wl, aux + AUX_FLOATS, fx, fy, fz, cc, lane, of, nullptr);
+                occ = of[0] + om[0];                                                            // decoder.py:333,341
             }
-            (void)k;
+            if (STAGE == NSR_STAGE_COLOR) {
+                const Lvl Lc = make_level(P.grid[NSR_COLOR], px, py, pz);
+                const Act<2> ccol = gather_feat(P.grid[NSR_COLOR], Lc, g);
+                block_sync();
+                load_packed<NSR_COLOR>(wl, P.dec[NSR_COLOR].packed);
+                block_sync();
+                float oc[4];
+                mlp_xyz_fwd<NSR_COLOR, false, true>(wl, aux + 2 * AUX_FLOATS, fx, fy, fz, ccol, lane, oc, nullptr);
+                raw.x = oc[0]; raw.y = oc[1]; raw.z = oc[2];
+            }
+            raw.w = occ;
+        }
+        if (!inside) raw.w = 100.f;                                         // Renderer.py:57
+        if (active && g == 0) {
+            rawbuf[pidx] = raw;
+            if (P.raw) st4(P.raw + (ray * S + k) * 4, raw);
         }
         block_sync();
-        for (int r = wave; r < P.rays_per_block; r += nwaves) {
-            const long long ray = ray0 + r;
-            if (ray >= P.n_rays) break;
+        for (int rq = wave; rq < P.rays_per_block; rq += nwaves) {
+            const long long rayq = ray0 + rq;
+            if (rayq >= P.n_rays) break;
             const bool act = lane < S;
-            const F4 rw = act ? rawbuf[r * S + lane] : F4{0.f, 0.f, 0.f, 0.f};
-            const double z = act ? zbuf[r * S + lane] : 0.0;
+            const F4 rw = act ? rawbuf[rq * S + lane] : F4{0.f, 0.f, 0.f, 0.f};
+            const double zq = act ? zbuf[rq * S + lane] : 0.0;
             const Comp c = comp_weights(rw.w, act, lane);
             const float cr = wave_sum(c.w * rw.x), cg = wave_sum(c.w * rw.y), cb = wave_sum(c.w * rw.z);
-            const double depth = wave_sum_d((double)c.w * z);
-            const double dz = z - depth;
+            const double depth = wave_sum_d((double)c.w * zq);
+            const double dz = zq - depth;
             const double var = wave_sum_d(((double)c.w * dz) * dz);
             if (lane == 0) {
-                P.depth[ray] = depth;
-                P.var[ray] = var;
-                P.rgb[ray * 3 + 0] = cr; P.rgb[ray * 3 + 1] = cg; P.rgb[ray * 3 + 2] = cb;
+                P.depth[rayq] = depth;
+                P.var[rayq] = var;
+                P.rgb[rayq * 3 + 0] = cr; P.rgb[rayq * 3 + 1] = cg; P.rgb[rayq * 3 + 2] = cb;
             }
         }
         block_sync();
@@ -850,7 +945,7 @@ constexpr int xyz_pair_base(int cd, int I) {
 template <int KIND>
 struct XyzBwd {
     static constexpr int CD = cdim_of(KIND), NTC = CD / 16;
-    const float *flat;
+    const float *wl;     // packed operand stream of this decoder, staged in LDS
     const float *aux;
     Own O;
     float *S;            // this wave's staging region
@@ -868,7 +963,7 @@ struct XyzBwd {
         constexpr int hid = I == 1 ? XW1 : (I == 2 ? XW2 : (I == 3 ? XW3H : XW4));
         const Mat mu = xyz_mat(CD, uid);
         if (F.params) st_store(S + kStA0, dh, i16, g);                      // dH_i: gradient of (U_i c + v_i) is dh itself
-        if (F.grid || F.rays) gemv_bwd<2>(dc.t, dh, flat, mu, i16, g);      // first 32 feature columns only
+        if (F.grid || F.rays) gemv_bwd<2, true>(dc.t, dh, wl + mu.pk, mu, i16, g);      // first 32 feature columns only
         const Act<2> dY = apply_mask(dh, K.mask[I]);
         if (I == 3) dY3 = dY;
         if (I == 0) dY0 = dY;
@@ -897,7 +992,7 @@ struct XyzBwd {
         if (I > 0) {
             Act<2> nd;
             act_zero(nd);
-            gemv_bwd<2>(nd.t, dY, flat, xyz_mat(CD, hid), i16, g);
+            gemv_bwd<2, true>(nd.t, dY, wl + xyz_mat(CD, hid).pk, xyz_mat(CD, hid), i16, g);
             dh = nd;
         }
     }
@@ -908,14 +1003,14 @@ struct XyzBwd {
 // the fp32 world position through the embedding (already reduced over g).
 // With F.params every wave of the block must call this function (it contains block barriers).
 template <int KIND>
-NSR_DEV void mlp_xyz_bwd(const float *flat, const float *pk, const float *aux, const Own &O, float *S,
+NSR_DEV void mlp_xyz_bwd(const float *pk, const float *aux, const Own &O, float *S,
                          float px, float py, float pz, const Act<cdim_of(KIND) / 16> &c,
                          const float (&d_out)[nout_of(KIND)], BwdFlags F, int lane, Act<2> &dc, float (&dp)[3]) {
     constexpr int CD = cdim_of(KIND), NOUT = nout_of(KIND), NTC = CD / 16;
     const int i16 = lane & 15, g = lane >> 4;
     Kept<KIND> K;
     float out[NOUT];
-    mlp_xyz_fwd<KIND, true>(pk, aux, px, py, pz, c, lane, out, &K);
+    mlp_xyz_fwd<KIND, true, true>(pk, aux, px, py, pz, c, lane, out, &K);
     (void)out;
 
     // output layer
@@ -950,7 +1045,7 @@ NSR_DEV void mlp_xyz_bwd(const float *flat, const float *pk, const float *aux, c
     }
 
     act_zero(dc);
-    XyzBwd<KIND> X{flat, aux, O, S, K, F, lane, dc, dh};
+    XyzBwd<KIND> X{pk, aux, O, S, K, F, lane, dc, dh};
     act_zero(X.dY3);
     act_zero(X.dY0);
     X.template layer<4>();
@@ -965,19 +1060,17 @@ NSR_DEV void mlp_xyz_bwd(const float *flat, const float *pk, const float *aux, c
     const bool need_dB = F.params;
     if (F.rays || need_dB) {
         const Mat m0 = xyz_mat(CD, XW0), m3 = xyz_mat(CD, XW3E);
-        const Stream st0 = make_stream(flat + m0.off), st3 = make_stream(flat + m3.off);
+        const int lo = (i16 & 3) * 128 + 16 * (i16 >> 2) + 4 * g;       // packed-stream position of W[.][16Tk+i16], see gemv_bwd
         float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
         for (int Tk = 0; Tk < kET; ++Tk) {
             f32x4 dE = f4zero(), dE2 = f4zero();
-            const int k = 16 * Tk + i16;
 #pragma unroll
             for (int To = 0; To < 2; ++To)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float w0 = stream_ld(st0, 4 * g * m0.stride + i16, (16 * To + r) * m0.stride + 16 * Tk);
-                    const float w3 = stream_ld(st3, 4 * g * m3.stride + i16, (16 * To + r) * m3.stride + 16 * Tk);
-                    const float a0 = (k < kE) ? w0 : 0.f, a3 = (k < kE) ? w3 : 0.f;
+                    const float a0 = pk[m0.pk + Tk * 512 + To * 64 + r + lo];
+                    const float a3 = pk[m3.pk + Tk * 512 + To * 64 + r + lo];
                     dE = mfma16(a0, dY0.t[To][r], dE);
                     dE2 = mfma16(a3, dY3.t[To][r], dE2);
                 }
@@ -1005,7 +1098,7 @@ NSR_DEV void mlp_xyz_bwd(const float *flat, const float *pk, const float *aux, c
 }
 
 struct NoxBwd {
-    const float *flat;
+    const float *wl;     // packed operand stream of the coarse decoder, staged in LDS
     Own O;
     float *S;
     const Act<2> &c;
@@ -1037,25 +1130,25 @@ struct NoxBwd {
             if ((4 - I + 3) % O.nw == O.wave) own_colsum(O, nox_b(I), kStA1);
             block_sync();
         }
-        if (I == 3) gemv_bwd<2>(dc.t, dY, flat, nox_mat(NW3C), i16, g);
+        if (I == 3) gemv_bwd<2, true>(dc.t, dY, wl + nox_mat(NW3C).pk, nox_mat(NW3C), i16, g);
         if (I == 0) {
-            gemv_bwd<2>(dc.t, dY, flat, mh, i16, g);
+            gemv_bwd<2, true>(dc.t, dY, wl + mh.pk, mh, i16, g);
         } else {
             Act<2> nd;
             act_zero(nd);
-            gemv_bwd<2>(nd.t, dY, flat, mh, i16, g);
+            gemv_bwd<2, true>(nd.t, dY, wl + mh.pk, mh, i16, g);
             dh = nd;
         }
     }
 };
 
 // coarse decoder backward (MLP_no_xyz)
-NSR_DEV void mlp_nox_bwd(const float *flat, const float *pk, const float *aux, const Own &O, float *S,
+NSR_DEV void mlp_nox_bwd(const float *pk, const float *aux, const Own &O, float *S,
                          const Act<2> &c, float d_out, BwdFlags F, int lane, Act<2> &dc) {
     const int i16 = lane & 15, g = lane >> 4;
     Kept<0> K;
     float out[1];
-    mlp_nox_fwd<true>(pk, aux, c, lane, out, &K);
+    mlp_nox_fwd<true, true>(pk, aux, c, lane, out, &K);
     (void)out;
     Act<2> dh;
 #pragma unroll
@@ -1073,7 +1166,7 @@ NSR_DEV void mlp_nox_bwd(const float *flat, const float *pk, const float *aux, c
         block_sync();
     }
     act_zero(dc);
-    NoxBwd X{flat, O, S, c, K, F, lane, dc, dh};
+    NoxBwd X{pk, O, S, c, K, F, lane, dc, dh};
     X.layer<4>();
     X.layer<3>();
     X.layer<2>();
@@ -1084,8 +1177,10 @@ NSR_DEV void mlp_nox_bwd(const float *flat, const float *pk, const float *aux, c
 // ------------------------------------------------------------------------------------------------
 // backward kernel.  grid = (blocks, passes); pass p handles one decoder:
 //   coarse stage: p0 = coarse.   otherwise: p0 = middle, p1 = fine, p2 = color.
-// LDS: aux[AUX] | acc[param_total] | ztmp f64[npts] | zbuf f64[npts] | draw F4[npts] | dpb f64[npts*3]
+// LDS: aux[AUX] | packed weights of the decoder | ztmp f64[npts] | zbuf f64[npts] | draw F4[npts] | dpb f64[npts*3]
 //      | per-wave staging regions (stg_floats(KIND) each)
+// The per-block image of the parameter gradients lives in the global partial buffer (stays in L2; exclusive owner
+// per element, first ray group stores, later groups accumulate), summed over blocks by reduce_partials_kernel.
 // ------------------------------------------------------------------------------------------------
 template <int KIND>
 NSR_DEV void bwd_pass(const RenderParams &P) {
@@ -1094,8 +1189,8 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
     const int npts = P.rays_per_block * P.S, S = P.S;
     const int lane = tid() & 63, wave = tid() >> 6, nwaves = nthreads() >> 6;
     float *aux = reinterpret_cast<float *>(lds);
-    float *acc = aux + AUX_FLOATS;
-    constexpr int head = (AUX_FLOATS + NPAR + 3) & ~3;
+    float *wl = aux + AUX_FLOATS;                          // this decoder's packed operand stream
+    constexpr int head = (AUX_FLOATS + packed_total(KIND) + 3) & ~3;
     double *ztmp = reinterpret_cast<double *>(aux + head);
     double *zbuf = ztmp + npts;
     F4 *draw = reinterpret_cast<F4 *>(zbuf + npts);
@@ -1113,11 +1208,13 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
     if (!F.grid && !F.params && !F.rays) return;
 
     load_aux<KIND>(aux, D.params);
-    if (F.params) for (int t = tid(); t < NPAR; t += nthreads()) acc[t] = 0.f;
-    const Own O{acc, stg, stg_floats(KIND), nwaves, wave, lane};
+    load_packed<KIND>(wl, D.packed);                       // visible after the first barrier inside compute_z
+    float *img = F.params ? P.partials + ((long long)bid_y() * nblk_x() + bid_x()) * P.partial_stride : nullptr;
+    (void)NPAR;
 
     for (long long grp = bid_x(); grp < P.n_groups; grp += nblk_x()) {
-        loop_fence();       // weights are loop-invariant: keep LICM from hoisting ~250 operand loads into registers
+        loop_fence();
+        const Own O{make_stream(img), stg, stg_floats(KIND), nwaves, wave, lane, grp == (long long)bid_x()};
         const long long ray0 = grp * P.rays_per_block;
         compute_z(P, ray0, ztmp, zbuf);
         // ---- compositor backward: d raw per sample (common.py:231-244 differentiated)
@@ -1169,20 +1266,20 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
             Act<2> dc;
             float dpe[3] = {0.f, 0.f, 0.f};
             if (KIND == NSR_COARSE) {
-                mlp_nox_bwd(D.params, D.packed, aux, O, Sw, c, dr.w, F, lane, dc);
+                mlp_nox_bwd(wl, aux, O, Sw, c, dr.w, F, lane, dc);
             } else if (KIND == NSR_MIDDLE) {
                 float d_out[1] = {dr.w};
-                mlp_xyz_bwd<NSR_MIDDLE>(D.params, D.packed, aux, O, Sw, (float)px, (float)py, (float)pz, c, d_out, F, lane, dc, dpe);
+                mlp_xyz_bwd<NSR_MIDDLE>(wl, aux, O, Sw, (float)px, (float)py, (float)pz, c, d_out, F, lane, dc, dpe);
             } else if (KIND == NSR_FINE) {
                 const Lvl Lm = make_level(P.grid[NSR_MIDDLE], px, py, pz);
                 const Act<2> cm = gather_feat(P.grid[NSR_MIDDLE], Lm, g);
                 Act<4> cc;
                 cc.t[0] = c.t[0]; cc.t[1] = c.t[1]; cc.t[2] = cm.t[0]; cc.t[3] = cm.t[1];
                 float d_out[1] = {dr.w};
-                mlp_xyz_bwd<NSR_FINE>(D.params, D.packed, aux, O, Sw, (float)px, (float)py, (float)pz, cc, d_out, F, lane, dc, dpe);
+                mlp_xyz_bwd<NSR_FINE>(wl, aux, O, Sw, (float)px, (float)py, (float)pz, cc, d_out, F, lane, dc, dpe);
             } else {
                 float d_out[4] = {dr.x, dr.y, dr.z, 0.f};          // decoder.py:341 overwrites the 4th colour output
-                mlp_xyz_bwd<NSR_COLOR>(D.params, D.packed, aux, O, Sw, (float)px, (float)py, (float)pz, c, d_out, F, lane, dc, dpe);
+                mlp_xyz_bwd<NSR_COLOR>(wl, aux, O, Sw, (float)px, (float)py, (float)pz, c, d_out, F, lane, dc, dpe);
             }
             float dux = 0.f, duy = 0.f, duz = 0.f;
             if (F.rays) coord_grad(G, L, g, dc, dux, duy, duz);
@@ -1209,12 +1306,6 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
             }
         }
         block_sync();
-    }
-    if (F.params) {
-        block_sync();
-        const int pass = bid_y();
-        float *dst = P.partials + ((long long)pass * nblk_x() + bid_x()) * P.partial_stride;
-        for (int t = tid(); t < NPAR; t += nthreads()) dst[t] = acc[t];
     }
 }
 

@@ -174,6 +174,7 @@ NSR_DEV void atomic_add_lds(float *p, float v) { *p += v; }
 NSR_DEV char *lds_base() { return emu::B->lds; }
 
 struct Stream { const float *base; };
+NSR_DEV void stream_st(const Stream &s, int lane_off, int const_off, float v) { const_cast<float *>(s.base)[lane_off + const_off] = v; }
 NSR_DEV Stream make_stream(const float *base) { return Stream{base}; }
 NSR_DEV float stream_ld(const Stream &s, int lane_off, int const_off) { return s.base[lane_off + const_off]; }
 
