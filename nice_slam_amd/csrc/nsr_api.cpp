@@ -16,7 +16,7 @@ int fail(const std::string &msg) {
 }
 
 constexpr int kMaxTiles = 12;            // 12 waves = 768 threads per block
-constexpr int kDefaultBwdBlocks = 512;   // persistent-grid cap of the backward kernel
+constexpr int kDefaultBwdBlocks = 256;   // persistent-grid cap of the backward kernel: one block per CU (LDS-bound), fewer partial images
 constexpr int kLdsLimit = 160 * 1024;
 
 inline int round16(int bytes) { return (bytes + 15) & ~15; }
@@ -119,7 +119,7 @@ int bwd_lds_bytes(int stage, int npts, int tiles) {
     const int npk = stage == NSR_STAGE_COARSE ? nsr::packed_total(0) : nsr::packed_total(2);   // largest packed stream of the stage
     const int head = (nsr::AUX_FLOATS + npk + 3) & ~3;
     const int stg = stage == NSR_STAGE_COARSE ? nsr::stg_floats(0) : nsr::stg_floats(2);     // largest staging region of the stage
-    return round16(head * 4 + npts * (8 + 8 + 16 + 24)) + tiles * stg * 4;
+    return round16(head * 4 + npts * (8 + 8 + 16 + 24) + 132 * 4) + tiles * stg * 4;
 }
 
 }  // namespace

@@ -44,6 +44,10 @@ NSR_DEV void wave_fence() {
 NSR_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // compiler-only memory clobber: stops loop-invariant code motion of loads across loop iterations
 NSR_DEV void loop_fence() { asm volatile("" ::: "memory"); }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter
+// (s_waitcnt vmcnt(0)), i.e. every barrier would wait for all outstanding global loads, stores and fire-and-forget
+// atomics of the wave (grid scatter, gradient-image stores: microseconds each).  No barrier in these kernels hands
+// global data from one wave to another, so only lgkmcnt is drained (cdna_hip_programming.md, "pipelining across barriers").
 NSR_DEV void block_sync() { __syncthreads(); }
 
 NSR_DEV void atomic_add_global(float *p, float v) { unsafeAtomicAdd(p, v); }

@@ -188,7 +188,8 @@ NSR_DEV void compute_z(const RenderParams &P, long long ray0, double *ztmp, doub
             const int r = t / S, k = t - r * S;
             const double v = ztmp[t];
             int rank = 0;
-            for (int j = 0; j < S; ++j) {
+#pragma unroll 16
+            for (int j = 0; j < S; ++j) {      // unrolled: 16 LDS reads in flight instead of one latency per compare
                 const double u = ztmp[r * S + j];
                 rank += (u < v || (u == v && j < k)) ? 1 : 0;
             }
@@ -327,17 +328,24 @@ NSR_DEV void scatter_merged(const GridDev &G, const Lvl &L, int lane, const Act<
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
         const int k = 2 * q + h;
+        int v[16];
+        float w[16], x[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {        // all LDS reads of the round in flight at once
+            v[p] = vt[p * 8 + k];
+            w[p] = wt[p * 8 + k];
+            x[p] = Tx[p * kTxS + ch];
+        }
         float acc = 0.f;
         int cur = -1;
-#pragma unroll 4
+#pragma unroll
         for (int p = 0; p < 16; ++p) {
-            const int v = vt[p * 8 + k];
-            if (v != cur) {
+            if (v[p] != cur) {
                 if (cur >= 0) atomic_add_global(G.dfeat + (long long)cur * kC + ch, acc);
                 acc = 0.f;
-                cur = v;
+                cur = v[p];
             }
-            acc = fmaf(Tx[p * kTxS + ch], wt[p * 8 + k], acc);
+            acc = fmaf(x[p], w[p], acc);
         }
         if (cur >= 0) atomic_add_global(G.dfeat + (long long)cur * kC + ch, acc);
     }
@@ -473,6 +481,7 @@ struct Own {
     const float *stg;    // staging regions of all waves
     int stride, nw, wave, lane;
     bool first;          // first ray group of this block: store instead of accumulate (no zero-fill needed)
+    float *small;        // block-level LDS accumulators of the output layer: wo[4][32] | bo[4]
 };
 NSR_DEV void img_add(const Own &O, int lane_off, int const_off, float v) {
     if (!O.first) v += stream_ld(O.img, lane_off, const_off);
@@ -529,28 +538,27 @@ NSR_DEV void own_colsum(const Own &O, int off, int a_off) {
     s += shfl_xor(s, 32);
     if (half == 0) img_add(O, ch, off, s);
 }
-// output layer: img[wo + n*32 + ch] += sum d_out[p][n] * h4[p][ch];  img[bo + n] += sum d_out[p][n]
+// output layer, wave-local (no block barrier): small[n*32 + ch] += sum_p d_out[p][n] * h4[p][ch], small[128 + n] += sum_p d_out[p][n]
+// over the 16 points of THIS wave's tile (DO and X0 = h4 staged in its own region).  NOUT+1 LDS atomics per tile; the
+// block flushes `small` into the gradient image once per ray group (bwd_pass).
 template <int NOUT>
-NSR_DEV void own_out(const Own &O, int wo, int bo) {
+NSR_DEV void out_layer_local(const Own &O, const float *S) {
     const int ch = O.lane & 31, half = O.lane >> 5;
     float s[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < O.nw; ++t) {
-        const float *S = O.stg + t * O.stride;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int p = half * 8 + q;
-            const F4 d = ld4(S + kStDO + p * 4);
-            const float h = st_at(S + kStX0, p, ch);
-            s[0] = fmaf(d.x, h, s[0]); sb[0] += d.x;
-            if (NOUT > 1) { s[1] = fmaf(d.y, h, s[1]); s[2] = fmaf(d.z, h, s[2]); s[3] = fmaf(d.w, h, s[3]); sb[1] += d.y; sb[2] += d.z; sb[3] += d.w; }
-        }
+    for (int q = 0; q < 8; ++q) {
+        const int p = half * 8 + q;
+        const F4 d = ld4(S + kStDO + p * 4);
+        const float h = st_at(S + kStX0, p, ch);
+        s[0] = fmaf(d.x, h, s[0]); sb[0] += d.x;
+        if (NOUT > 1) { s[1] = fmaf(d.y, h, s[1]); s[2] = fmaf(d.z, h, s[2]); s[3] = fmaf(d.w, h, s[3]); sb[1] += d.y; sb[2] += d.z; sb[3] += d.w; }
     }
 #pragma unroll
     for (int n = 0; n < NOUT; ++n) {
         const float v = s[n] + shfl_xor(s[n], 32);
         const float bsum = sb[n] + shfl_xor(sb[n], 32);
-        if (half == 0) img_add(O, ch, wo + n * 32, v);
-        if (O.lane == 0) img_add(O, 0, bo + n, bsum);
+        if (half == 0) atomic_add_lds(O.small + n * 32 + ch, v);
+        if (O.lane == 0) atomic_add_lds(O.small + 128 + n, bsum);
     }
 }
 // Fourier matrix: img[B + d*93 + ch] += sum darg[p][ch] * p[p][d]  for the 16 channels of k-tile Tk
@@ -1039,9 +1047,9 @@ NSR_DEV void mlp_xyz_bwd(const float *pk, const float *aux, const Own &O, float 
             st_store(S + kStC + q * 512, cq, i16, g);
         }
         st_store(S + kStX0, K.h[4], i16, g);
-        block_sync();
-        if (O.wave == O.nw - 1) own_out<NOUT>(O, wo_off(KIND), bo_off(KIND));
-        block_sync();
+        wave_fence();
+        out_layer_local<NOUT>(O, S);
+        wave_fence();
     }
 
     act_zero(dc);
@@ -1161,9 +1169,9 @@ NSR_DEV void mlp_nox_bwd(const float *pk, const float *aux, const Own &O, float 
         if (g == 0) st4(S + kStDO + i16 * 4, F4{d_out, 0.f, 0.f, 0.f});
         st_store(S + kStC, c, i16, g);
         st_store(S + kStX0, K.h[4], i16, g);
-        block_sync();
-        if (O.wave == O.nw - 1) own_out<1>(O, nox_wo(), nox_bo());
-        block_sync();
+        wave_fence();
+        out_layer_local<1>(O, S);
+        wave_fence();
     }
     act_zero(dc);
     NoxBwd X{pk, O, S, c, K, F, lane, dc, dh};
@@ -1195,7 +1203,8 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
     double *zbuf = ztmp + npts;
     F4 *draw = reinterpret_cast<F4 *>(zbuf + npts);
     double *dpb = reinterpret_cast<double *>(draw + npts);
-    const int stg_off = (head * 4 + npts * (8 + 8 + 16 + 24) + 15) & ~15;
+    float *small = reinterpret_cast<float *>(dpb + 3 * npts);              // 132 floats (wo[4][32] | bo[4])
+    const int stg_off = (head * 4 + npts * (8 + 8 + 16 + 24) + 132 * 4 + 15) & ~15;
     float *stg = reinterpret_cast<float *>(lds + stg_off);
     float *Sw = stg + wave * stg_floats(KIND);             // this wave's staging region (also Tx / tab of the scatter)
 
@@ -1209,14 +1218,34 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
 
     load_aux<KIND>(aux, D.params);
     load_packed<KIND>(wl, D.packed);                       // visible after the first barrier inside compute_z
+    for (int t = tid(); t < 132; t += nthreads()) small[t] = 0.f;
     float *img = F.params ? P.partials + ((long long)bid_y() * nblk_x() + bid_x()) * P.partial_stride : nullptr;
     (void)NPAR;
 
     for (long long grp = bid_x(); grp < P.n_groups; grp += nblk_x()) {
         loop_fence();
-        const Own O{make_stream(img), stg, stg_floats(KIND), nwaves, wave, lane, grp == (long long)bid_x()};
+        const Own O{make_stream(img), stg, stg_floats(KIND), nwaves, wave, lane, grp == (long long)bid_x(), small};
         const long long ray0 = grp * P.rays_per_block;
         compute_z(P, ray0, ztmp, zbuf);
+        // ---- tile set-up first: the feature gathers (L2 / Infinity-Cache latency) fly while the compositor runs
+        const int pidx = wave * kTile + (lane & 15);
+        const int g = lane >> 4;
+        const long long ray_t = ray0 + pidx / S;
+        const bool active = (pidx < npts) && (ray_t < P.n_rays);
+        const long long rr = active ? ray_t : 0;
+        const double zt = active ? zbuf[pidx] : 0.0;
+        const double px = (double)P.rays_o[rr * 3 + 0] + (double)P.rays_d[rr * 3 + 0] * zt;
+        const double py = (double)P.rays_o[rr * 3 + 1] + (double)P.rays_d[rr * 3 + 1] * zt;
+        const double pz = (double)P.rays_o[rr * 3 + 2] + (double)P.rays_d[rr * 3 + 2] * zt;
+        const bool inside = (px > P.blo[0]) && (px < P.bhi[0]) && (py > P.blo[1]) && (py < P.bhi[1]) &&
+                            (pz > P.blo[2]) && (pz < P.bhi[2]);
+        const Lvl L = make_level(G, px, py, pz);
+        const Act<2> c = gather_feat(G, L, g);
+        Act<2> cm;
+        if (KIND == NSR_FINE) {
+            const Lvl Lm = make_level(P.grid[NSR_MIDDLE], px, py, pz);
+            cm = gather_feat(P.grid[NSR_MIDDLE], Lm, g);
+        }
         // ---- compositor backward: d raw per sample (common.py:231-244 differentiated)
         for (int r = wave; r < P.rays_per_block; r += nwaves) {
             const long long ray = ray0 + r;
@@ -1247,22 +1276,8 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
         }
         block_sync();
         {   // ---- decoder backward for the tile of this wave
-            const int pidx = wave * kTile + (lane & 15);
-            const int g = lane >> 4;
-            const int r = pidx / S;
-            const long long ray = ray0 + r;
-            const bool active = (pidx < npts) && (ray < P.n_rays);
-            const long long rr = active ? ray : 0;
-            const double z = active ? zbuf[pidx] : 0.0;
-            const double px = (double)P.rays_o[rr * 3 + 0] + (double)P.rays_d[rr * 3 + 0] * z;
-            const double py = (double)P.rays_o[rr * 3 + 1] + (double)P.rays_d[rr * 3 + 1] * z;
-            const double pz = (double)P.rays_o[rr * 3 + 2] + (double)P.rays_d[rr * 3 + 2] * z;
-            const bool inside = (px > P.blo[0]) && (px < P.bhi[0]) && (py > P.blo[1]) && (py < P.bhi[1]) &&
-                                (pz > P.blo[2]) && (pz < P.bhi[2]);
             F4 dr = active ? draw[pidx] : F4{0.f, 0.f, 0.f, 0.f};
             if (!inside) dr.w = 0.f;                               // Renderer.py:57 cuts the occupancy gradient
-            const Lvl L = make_level(G, px, py, pz);
-            const Act<2> c = gather_feat(G, L, g);
             Act<2> dc;
             float dpe[3] = {0.f, 0.f, 0.f};
             if (KIND == NSR_COARSE) {
@@ -1271,8 +1286,6 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
                 float d_out[1] = {dr.w};
                 mlp_xyz_bwd<NSR_MIDDLE>(wl, aux, O, Sw, (float)px, (float)py, (float)pz, c, d_out, F, lane, dc, dpe);
             } else if (KIND == NSR_FINE) {
-                const Lvl Lm = make_level(P.grid[NSR_MIDDLE], px, py, pz);
-                const Act<2> cm = gather_feat(P.grid[NSR_MIDDLE], Lm, g);
                 Act<4> cc;
                 cc.t[0] = c.t[0]; cc.t[1] = c.t[1]; cc.t[2] = cm.t[0]; cc.t[3] = cm.t[1];
                 float d_out[1] = {dr.w};
@@ -1292,6 +1305,12 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
             }
         }
         block_sync();
+        if (F.params) {          // output-layer gradients of the whole block -> gradient image
+            constexpr int NO = nout_of(KIND);
+            const int t = tid();
+            if (t < NO * 32) { img_add(O, t, wo_off(KIND), small[t]); small[t] = 0.f; }
+            else if (t >= 128 && t < 128 + NO) { img_add(O, t - 128, bo_off(KIND), small[t]); small[t] = 0.f; }
+        }
         if (F.rays) {
             for (int t = tid(); t < P.rays_per_block * 6; t += nthreads()) {
                 const int r = t / 6, q = t - r * 6, a = q % 3;
