@@ -102,8 +102,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_dist = os.environ.get("NSR_FORCE_SHARDED") == "1"        # exercise the RCCL path with a single rank (CI on a 1-GPU box)
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from scene_util import make_scene, build_product
@@ -121,7 +123,7 @@ def main():
     params = list(dec.parameters())
     ev = HipEvents()
     renderer.profile_events = ev.pair_for
-    rend = ShardedRenderer(renderer) if world > 1 else renderer
+    rend = ShardedRenderer(renderer) if (world > 1 or force_dist) else renderer
     torch.manual_seed(1234)                                       # identical index draws on every rank
     per_frame = n_total // WINDOW
 
@@ -158,7 +160,7 @@ def main():
         for _ in range(5):
             step(st_i, True)
     torch.cuda.synchronize()
-    use_graph = (world == 1) and not args.eager
+    use_graph = (world == 1) and not args.eager and not force_dist
     graphs = {}
     if use_graph:
         # The mapping iteration is launch-bound on the host (~25 small launches around three big kernels): capture one
@@ -229,7 +231,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(sc)
         print(json.dumps(res))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -80,6 +80,8 @@ typedef struct nsr_render_args {
     float *rgb;               /* [N][3] */
     float *raw;               /* [N][S][4] decoder output after the out-of-bound override, S = n_samples+n_surface;
                                  written by fwd, read by bwd.  May be NULL for a forward-only call.  */
+    double *zvals;            /* [N][S] sorted sample depths; optional: written by fwd when non-NULL, and when non-NULL in
+                                 bwd they are loaded instead of being recomputed by each decoder pass                  */
 } nsr_render_args;
 
 typedef struct nsr_bwd_args {

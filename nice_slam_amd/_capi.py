@@ -36,7 +36,8 @@ class NsrRenderArgs(C.Structure):
                 ("bound_lo", C.c_double * 3), ("bound_hi", C.c_double * 3),
                 ("t_uniform", C.c_float * MAX_SAMPLES), ("t_surface", C.c_double * MAX_SAMPLES),
                 ("grid", NsrGrid * 4), ("dec", NsrDecoder * 4),
-                ("depth", C.c_void_p), ("var", C.c_void_p), ("rgb", C.c_void_p), ("raw", C.c_void_p)]
+                ("depth", C.c_void_p), ("var", C.c_void_p), ("rgb", C.c_void_p), ("raw", C.c_void_p),
+                ("zvals", C.c_void_p)]
 
 
 class NsrBwdArgs(C.Structure):

@@ -88,7 +88,7 @@ int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays,
         if (!d.params || !d.packed) return fail("nsr: missing decoder parameters / packed stream for this stage");
         P.dec[s].params = d.params; P.dec[s].packed = d.packed; P.dec[s].dparams = d.dparams;
     }
-    P.depth = a->depth; P.var = a->var; P.rgb = a->rgb; P.raw = a->raw;
+    P.depth = a->depth; P.var = a->var; P.rgb = a->rgb; P.raw = a->raw; P.zvals = a->zvals;
     return 0;
 }
 
@@ -119,7 +119,7 @@ int bwd_lds_bytes(int stage, int npts, int tiles) {
     const int npk = stage == NSR_STAGE_COARSE ? nsr::packed_total(0) : nsr::packed_total(2);   // largest packed stream of the stage
     const int head = (nsr::AUX_FLOATS + npk + 3) & ~3;
     const int stg = stage == NSR_STAGE_COARSE ? nsr::stg_floats(0) : nsr::stg_floats(2);     // largest staging region of the stage
-    return round16(head * 4 + npts * (8 + 8 + 16 + 24) + 132 * 4) + tiles * stg * 4;
+    return round16(head * 4 + npts * (8 + 8 + 16 + 24) + tiles * 132 * 4) + tiles * stg * 4;
 }
 
 }  // namespace

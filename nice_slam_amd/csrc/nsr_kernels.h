@@ -70,6 +70,7 @@ struct RenderParams {
     DecDev dec[4];
     double *depth, *var;
     float *rgb, *raw;
+    double *zvals;            // [N][S] saved sample depths (optional)
     // backward only
     const double *d_depth, *d_var, *g_depth;
     const float *d_rgb;
@@ -481,7 +482,7 @@ struct Own {
     const float *stg;    // staging regions of all waves
     int stride, nw, wave, lane;
     bool first;          // first ray group of this block: store instead of accumulate (no zero-fill needed)
-    float *small;        // block-level LDS accumulators of the output layer: wo[4][32] | bo[4]
+    float *small;        // per-wave LDS accumulators of the output layer: [wave][wo[4][32] | bo[4]]
 };
 NSR_DEV void img_add(const Own &O, int lane_off, int const_off, float v) {
     if (!O.first) v += stream_ld(O.img, lane_off, const_off);
@@ -496,25 +497,40 @@ NSR_DEV void own_pair(const Own &O, const Mat m, int Tk, int a_off, int x_off, i
     f32x4 d0 = f4zero(), d1 = f4zero();
     F4 b = F4{0.f, 0.f, 0.f, 0.f};
     if (XSRC == 2) b = ld4(aux + AUX_BM + (16 * Tk + i) * 4);
-#pragma unroll 2
+    // software pipeline over the block's tiles: the LDS reads (and, for the embedding, the sines) of tile t+1 are
+    // issued before the 8 MFMAs of tile t
+    const float *S = O.stg;
+    f32x4 a0 = st_load_cm(S + a_off, 0, i, g), a1 = st_load_cm(S + a_off, 1, i, g), x;
+    if (XSRC == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const F4 pp = ld4(S + kStP + (4 * q + g) * 4);
+            x[q] = sin_acc(fmaf(pp.z, b.z, fmaf(pp.y, b.y, pp.x * b.x)));
+        }
+    } else {
+        x = st_load_cm(S + x_off, x_sub, i, g);
+    }
     for (int t = 0; t < O.nw; ++t) {
-        const float *S = O.stg + t * O.stride;
-        const f32x4 a0 = st_load_cm(S + a_off, 0, i, g), a1 = st_load_cm(S + a_off, 1, i, g);
-        f32x4 x;
+        const float *Sn = O.stg + (t + 1 < O.nw ? t + 1 : t) * O.stride;
+        const f32x4 na0 = st_load_cm(Sn + a_off, 0, i, g), na1 = st_load_cm(Sn + a_off, 1, i, g);
+        f32x4 nx;
+        F4 pp[4];
         if (XSRC == 2) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const F4 pp = ld4(S + kStP + (4 * q + g) * 4);
-                x[q] = sin_acc(fmaf(pp.z, b.z, fmaf(pp.y, b.y, pp.x * b.x)));
-            }
+            for (int q = 0; q < 4; ++q) pp[q] = ld4(Sn + kStP + (4 * q + g) * 4);
         } else {
-            x = st_load_cm(S + x_off, x_sub, i, g);
+            nx = st_load_cm(Sn + x_off, x_sub, i, g);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             d0 = mfma16(a0[q], x[q], d0);
             d1 = mfma16(a1[q], x[q], d1);
         }
+        if (XSRC == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nx[q] = sin_acc(fmaf(pp[q].z, b.z, fmaf(pp[q].y, b.y, pp[q].x * b.x)));
+        }
+        a0 = na0; a1 = na1; x = nx;
     }
     const int k = 16 * Tk + i;
     if (k < m.kcols) {
@@ -538,9 +554,10 @@ NSR_DEV void own_colsum(const Own &O, int off, int a_off) {
     s += shfl_xor(s, 32);
     if (half == 0) img_add(O, ch, off, s);
 }
-// output layer, wave-local (no block barrier): small[n*32 + ch] += sum_p d_out[p][n] * h4[p][ch], small[128 + n] += sum_p d_out[p][n]
-// over the 16 points of THIS wave's tile (DO and X0 = h4 staged in its own region).  NOUT+1 LDS atomics per tile; the
-// block flushes `small` into the gradient image once per ray group (bwd_pass).
+// output layer, wave-local (no block barrier, no atomics): slot[n*32 + ch] += sum_p d_out[p][n] * h4[p][ch],
+// slot[128 + n] += sum_p d_out[p][n] over the 16 points of THIS wave's tile (DO and X0 = h4 staged in its own region);
+// `slot` is this wave's private 132-float accumulator; the block sums the slots into the gradient image once per
+// ray group (bwd_pass).
 template <int NOUT>
 NSR_DEV void out_layer_local(const Own &O, const float *S) {
     const int ch = O.lane & 31, half = O.lane >> 5;
@@ -557,8 +574,9 @@ NSR_DEV void out_layer_local(const Own &O, const float *S) {
     for (int n = 0; n < NOUT; ++n) {
         const float v = s[n] + shfl_xor(s[n], 32);
         const float bsum = sb[n] + shfl_xor(sb[n], 32);
-        if (half == 0) atomic_add_lds(O.small + n * 32 + ch, v);
-        if (O.lane == 0) atomic_add_lds(O.small + 128 + n, bsum);
+        float *slot = O.small + O.wave * 132;
+        if (half == 0) slot[n * 32 + ch] += v;
+        if (O.lane == 0) slot[128 + n] += bsum;
     }
 }
 // Fourier matrix: img[B + d*93 + ch] += sum darg[p][ch] * p[p][d]  for the 16 channels of k-tile Tk
@@ -894,6 +912,7 @@ NSR_KERNEL NSR_BOUNDS(768) void render_fwd_kernel(const RenderParams P) {
         if (active && g == 0) {
             rawbuf[pidx] = raw;
             if (P.raw) st4(P.raw + (ray * S + k) * 4, raw);
+            if (P.zvals) P.zvals[ray * S + k] = z;
         }
         block_sync();
         for (int rq = wave; rq < P.rays_per_block; rq += nwaves) {
@@ -1203,8 +1222,8 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
     double *zbuf = ztmp + npts;
     F4 *draw = reinterpret_cast<F4 *>(zbuf + npts);
     double *dpb = reinterpret_cast<double *>(draw + npts);
-    float *small = reinterpret_cast<float *>(dpb + 3 * npts);              // 132 floats (wo[4][32] | bo[4])
-    const int stg_off = (head * 4 + npts * (8 + 8 + 16 + 24) + 132 * 4 + 15) & ~15;
+    float *small = reinterpret_cast<float *>(dpb + 3 * npts);              // [waves][132] floats (wo[4][32] | bo[4])
+    const int stg_off = (head * 4 + npts * (8 + 8 + 16 + 24) + nwaves * 132 * 4 + 15) & ~15;
     float *stg = reinterpret_cast<float *>(lds + stg_off);
     float *Sw = stg + wave * stg_floats(KIND);             // this wave's staging region (also Tx / tab of the scatter)
 
@@ -1218,7 +1237,7 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
 
     load_aux<KIND>(aux, D.params);
     load_packed<KIND>(wl, D.packed);                       // visible after the first barrier inside compute_z
-    for (int t = tid(); t < 132; t += nthreads()) small[t] = 0.f;
+    for (int t = tid(); t < 132 * nwaves; t += nthreads()) small[t] = 0.f;
     float *img = F.params ? P.partials + ((long long)bid_y() * nblk_x() + bid_x()) * P.partial_stride : nullptr;
     (void)NPAR;
 
@@ -1226,7 +1245,13 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
         loop_fence();
         const Own O{make_stream(img), stg, stg_floats(KIND), nwaves, wave, lane, grp == (long long)bid_x(), small};
         const long long ray0 = grp * P.rays_per_block;
-        compute_z(P, ray0, ztmp, zbuf);
+        if (P.zvals) {            // sample depths saved by the forward pass: one coalesced load instead of re-deriving them
+            for (int t = tid(); t < npts; t += nthreads())
+                zbuf[t] = (ray0 + t / S < P.n_rays) ? P.zvals[ray0 * S + t] : 0.0;
+            block_sync();
+        } else {
+            compute_z(P, ray0, ztmp, zbuf);
+        }
         // ---- tile set-up first: the feature gathers (L2 / Infinity-Cache latency) fly while the compositor runs
         const int pidx = wave * kTile + (lane & 15);
         const int g = lane >> 4;
@@ -1308,8 +1333,11 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
         if (F.params) {          // output-layer gradients of the whole block -> gradient image
             constexpr int NO = nout_of(KIND);
             const int t = tid();
-            if (t < NO * 32) { img_add(O, t, wo_off(KIND), small[t]); small[t] = 0.f; }
-            else if (t >= 128 && t < 128 + NO) { img_add(O, t - 128, bo_off(KIND), small[t]); small[t] = 0.f; }
+            if (t < NO * 32 || (t >= 128 && t < 128 + NO)) {
+                float v = 0.f;
+                for (int w = 0; w < nwaves; ++w) { v += small[w * 132 + t]; small[w * 132 + t] = 0.f; }
+                if (t < 128) img_add(O, t, wo_off(KIND), v); else img_add(O, t - 128, bo_off(KIND), v);
+            }
         }
         if (F.rays) {
             for (int t = tid(); t < P.rays_per_block * 6; t += nthreads()) {

@@ -123,6 +123,9 @@ class _RenderFn(torch.autograd.Function):
         raw = torch.empty((n, S, 4), dtype=torch.float32, device=dev) if need_bwd else None
         a.depth, a.var, a.rgb = depth.data_ptr(), var.data_ptr(), rgb.data_ptr()
         a.raw = raw.data_ptr() if raw is not None else None
+        zsave = torch.empty((n, S), dtype=torch.float64, device=dev) if need_bwd else None
+        a.zvals = zsave.data_ptr() if zsave is not None else None
+        keep.append(zsave)
         lib.check(lib.nsr_render_fwd(C.byref(a), stream), "nsr_render_fwd")
         if need_bwd:
             ctx.args, ctx.keep = a, (keep, rays_o, rays_d, gt_depth, grids, flats, packed, raw, depth)

@@ -65,6 +65,7 @@ class HostScene:
         self.bound = np.asarray(bound, dtype=np.float64)
         self.enl = float(coarse_enlarge)
         self.n_samples, self.n_surface = n_samples, n_surface
+        self.save_z = True          # exercise the saved-depth path of the backward; False = recompute
         self.grids = {}
         for k, v in grids.items():          # [1,32,Z,Y,X] -> [Z,Y,X,32] contiguous
             a = v.detach().numpy()[0].transpose(1, 2, 3, 0)
@@ -120,6 +121,9 @@ class HostScene:
         out = {"depth": np.full(n, np.nan), "var": np.full(n, np.nan),
                "rgb": np.full((n, 3), np.nan, dtype=np.float32), "raw": np.full((n, S, 4), np.nan, dtype=np.float32)}
         a.depth, a.var, a.rgb, a.raw = ptr(out["depth"]), ptr(out["var"]), ptr(out["rgb"]), ptr(out["raw"])
+        if self.save_z:
+            out["zvals"] = np.full((n, S), np.nan)
+            a.zvals = ptr(out["zvals"])
         self.lib.check(self.lib.nsr_render_fwd(C.byref(a), None), "fwd")
         out["_ctx"] = (a, keep, rays_o, rays_d, gt, S)
         return out

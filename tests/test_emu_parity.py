@@ -88,6 +88,13 @@ def test_backward_flag_subsets(emu):
         assert rel_err(rays[k], full[k]) < 1e-6
     for k in grid:
         assert rel_err(grid[k], full[k]) < 1e-6
+    # backward that re-derives the sample depths instead of loading the ones the forward saved
+    sc.save_z = False
+    fwd2 = sc.forward("color", s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy())
+    again = sc.backward("color", fwd2, w["depth"].numpy(), w["var"].numpy(), w["rgb"].numpy())
+    for k in full:
+        assert rel_err(again[k], full[k]) < 1e-6, k
+    sc.save_z = True
     # depth-only upstream gradient (d_var = d_rgb = NULL)
     dd = sc.backward("fine", sc.forward("fine", s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy()),
                      w["depth"].numpy(), None, None)

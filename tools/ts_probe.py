@@ -18,9 +18,9 @@ for it in range(3):
     ((gd - depth).abs().sum() + 0.2 * (gc - col).abs().sum()).backward()
     torch.cuda.synchronize()
 t = buf.cpu().numpy().reshape(NB, 8, 32)
-names = {0: "start", 1: "z done", 2: "compositor+sync", 3: "gather", 4: "fwd recompute", 5: "out layer(+own_out)", 6: "L4", 7: "L3", 8: "L2", 9: "L1", 10: "L0", 11: "E-stage", 12: "dB owners", 20: "mlp done", 21: "scatter", 22: "end sync"}
+names = {0: "start", 1: "z done", 2: "setup+compositor+sync", 3: "draw read", 4: "fwd recompute", 5: "out layer(+own_out)", 6: "L4", 7: "L3", 8: "L2", 9: "L1", 10: "L0", 11: "E-stage", 12: "dB owners", 20: "mlp done", 21: "scatter", 22: "end sync"}
 order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 20, 21, 22]
-nblk = 500
+nblk = 256
 for p_, nm in ((0, "middle"), (1, "fine"), (2, "color")):
     blk = t[p_ * nblk:(p_ + 1) * nblk, :6, :]
     ok = blk[:, :, 0] > 0
@@ -36,3 +36,5 @@ for p_, nm in ((0, "middle"), (1, "fine"), (2, "color")):
     print("   total per group %8.0f cycles (p90 %8.0f)" % (tot.mean(), np.percentile(tot, 90)))
     l3 = blk[:, :, 13:17][ok]
     print("   L3 detail: stage->bar %6.0f | owners %6.0f | 2nd bar wait %6.0f" % ((l3[:,1]-l3[:,0]).mean(), (l3[:,2]-l3[:,1]).mean(), (l3[:,3]-l3[:,2]).mean()))
+    l2 = blk[:, :, 23:27][ok]
+    print("   L2 detail: stage->bar %6.0f | owners %6.0f (min %6.0f max %6.0f) | 2nd bar wait %6.0f" % ((l2[:,1]-l2[:,0]).mean(), (l2[:,2]-l2[:,1]).mean(), (l2[:,2]-l2[:,1]).min(), (l2[:,2]-l2[:,1]).max(), (l2[:,3]-l2[:,2]).mean()))
