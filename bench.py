@@ -160,7 +160,8 @@ def main():
         for _ in range(5):
             step(st_i, True)
     torch.cuda.synchronize()
-    use_graph = (world == 1) and not args.eager and not force_dist
+    # RCCL collectives are capturable too; NSR_DIST_GRAPH=0 forces the eager path for multi-rank runs
+    use_graph = not args.eager and ((world == 1 and not force_dist) or os.environ.get("NSR_DIST_GRAPH", "1") == "1")
     graphs = {}
     if use_graph:
         # The mapping iteration is launch-bound on the host (~25 small launches around three big kernels): capture one
@@ -174,12 +175,19 @@ def main():
                     step(st_i, False)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        for st_i in reps:
-            gph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gph):
-                st_name = step(st_i, False)
-            graphs[st_name] = gph
-        torch.cuda.synchronize()
+        try:
+            for st_i in reps:
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gph):
+                    st_name = step(st_i, False)
+                graphs[st_name] = gph
+            torch.cuda.synchronize()
+        except Exception as e:                      # e.g. a collective that cannot be captured: run eagerly instead
+            if rank == 0:
+                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); falling back to eager", file=sys.stderr)
+            graphs.clear()
+            use_graph = False
+            torch.cuda.synchronize()
 
     def timed_step(i):
         if not use_graph:

@@ -61,8 +61,14 @@ class _SumGrad(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        g = g.contiguous() if not g.is_contiguous(memory_format=torch.channels_last_3d) else g
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        if g.is_contiguous():
+            buf = g
+        elif g.dim() == 5 and g.is_contiguous(memory_format=torch.channels_last_3d):
+            buf = g.permute(0, 2, 3, 4, 1)            # the same dense memory, viewed as a standard-contiguous tensor
+        else:
+            g = g.contiguous()
+            buf = g
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=ctx.group)
         return g, None
 
 
