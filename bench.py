@@ -229,8 +229,13 @@ def main():
             ms, cnt = ksum["color"]
             rays_launch = args.rays
             ach = rays_launch * BWD_COLOR_FLOP_PER_RAY / (ms * 1e-3)
+            traffic, tsrc = None, None
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")      # from a separate rocprofv3 --pmc run (tools/pmc_summary.py)
+            if os.path.exists(tpath) and args.rays == RAYS_PER_GPU:
+                tj = json.load(open(tpath)).get("nsr::render_bwd_kernel<3>", {})
+                traffic, tsrc = tj.get("hbm_bytes_per_launch"), "profiles/r01_traffic.json: " + tj.get("note", "")
             res["roofline"] = {"bound": "mfma", "kernel": "render_bwd_kernel<color>", "achieved": ach / 1e12, "peak": FP32_PEAK / 1e12,
-                               "unit": "TFLOP/s", "frac": ach / FP32_PEAK, "traffic": None,
+                               "unit": "TFLOP/s", "frac": ach / FP32_PEAK, "traffic": traffic, "traffic_source": tsrc,
                                "avg_kernel_ms": ms, "launches": cnt,
                                "measured": "HIP events recorded inside nsr_render_bwd on the launch stream, eager iterations of this process"
                                            + (" (the timed region replays the captured graph of the same kernels)" if use_graph else ""),

@@ -167,9 +167,10 @@ def sample_depths(rays_o: torch.Tensor, rays_d: torch.Tensor, gt_depth: Optional
     with torch.no_grad():
         o = rays_o.detach().to(hi)[:, :, None]
         d = rays_d.detach().to(hi)[:, :, None]
-        t = (bound.to(hi)[None] - o) / d                    # (N,3,2)   Renderer.py:98-103
+        t = (bound.to(device=o.device, dtype=hi)[None] - o) / d     # (N,3,2)   Renderer.py:98-103
         far_bb = t.max(dim=2)[0].min(dim=1)[0][:, None] + 0.01
-        tv = torch.linspace(0.0, 1.0, n_samples, dtype=lo_dt)
+        dev = rays_o.device
+        tv = torch.linspace(0.0, 1.0, n_samples, dtype=lo_dt).to(dev)          # CPU linspace values, like the host tables of the kernels
         if gt_depth is None:                                # Renderer.py:90-92,110-111
             near_part = 0.01 * (1.0 - tv)                   # fp32 scalar*tensor
             far = far_bb
@@ -177,12 +178,12 @@ def sample_depths(rays_o: torch.Tensor, rays_d: torch.Tensor, gt_depth: Optional
             return z
         g = gt_depth.detach().reshape(-1, 1)
         gmax12 = torch.max(g * 1.2)                         # Renderer.py:109 (input dtype)
-        far = torch.minimum(torch.maximum(far_bb, torch.zeros((), dtype=hi)), gmax12.to(hi))
+        far = torch.minimum(torch.maximum(far_bb, torch.zeros((), dtype=hi, device=dev)), gmax12.to(hi))
         near = g.repeat(1, n_samples) * 0.01                # Renderer.py:94-96 (input dtype)
         z_uni = (near * (1.0 - tv)).to(hi) + far * tv.to(hi)        # Renderer.py:154-155
         if n_surface == 0:
             return z_uni
-        ts = torch.linspace(0.0, 1.0, n_surface, dtype=lo_dt).to(hi)  # Renderer.py:132-133
+        ts = torch.linspace(0.0, 1.0, n_surface, dtype=lo_dt).to(hi).to(dev)  # Renderer.py:132-133
         lo_edge = (0.95 * g).to(hi)                         # rounded in input dtype first
         hi_edge = (1.05 * g).to(hi)
         z_hit = lo_edge * (1.0 - ts) + hi_edge * ts         # Renderer.py:135-137
@@ -209,7 +210,7 @@ def trilinear(grid: torch.Tensor, p: torch.Tensor, bound: torch.Tensor, lo=F32) 
     Returns (M, C) in ``lo``.
     """
     _, C, Z, Y, X = grid.shape
-    b = bound.to(p.dtype)
+    b = bound.to(device=p.device, dtype=p.dtype)
     g = ((p - b[:, 0]) / (b[:, 1] - b[:, 0])) * 2 - 1.0
     g = g.to(lo)
     gv = grid[0].to(lo).permute(1, 2, 3, 0)                  # (Z,Y,X,C) view
@@ -274,7 +275,7 @@ def nice_decode(p: torch.Tensor, grids: Dict[str, torch.Tensor], P: Dict[str, to
                 bounds: Dict[str, torch.Tensor], stage: str, lo=F32) -> torch.Tensor:
     """``NICE.forward`` (decoder.py:312-342): (M,3) world points -> (M,4) [r,g,b,occ-logit]."""
     M = p.shape[0]
-    raw = torch.zeros((M, 4), dtype=lo)
+    raw = torch.zeros((M, 4), dtype=lo, device=p.device)
     if stage == "coarse":
         c = trilinear(grids["grid_coarse"], p, bounds["coarse"], lo)
         occ = mlp_no_xyz(c, P)[:, 0]
@@ -297,7 +298,7 @@ def nice_decode(p: torch.Tensor, grids: Dict[str, torch.Tensor], P: Dict[str, to
 def eval_points(p: torch.Tensor, grids, P, bounds, bound: torch.Tensor, stage: str, lo=F32):
     """``Renderer.eval_points`` (Renderer.py:23-61): decode + force occ=100 outside the open box.
     The test uses the renderer's un-enlarged bound for every stage."""
-    b = bound.to(p.dtype)
+    b = bound.to(device=p.device, dtype=p.dtype)
     inside = ((p > b[:, 0]) & (p < b[:, 1])).all(-1)
     raw = nice_decode(p, grids, P, bounds, stage, lo)
     occ = torch.where(inside, raw[:, 3], torch.full_like(raw[:, 3], 100.0))
@@ -310,7 +311,7 @@ def eval_points(p: torch.Tensor, grids, P, bounds, bound: torch.Tensor, stage: s
 def composite(raw: torch.Tensor, z: torch.Tensor, lo=F32):
     """raw (N,S,4), z (N,S) -> depth (N,) hi, var (N,) hi, rgb (N,3) lo, weights (N,S) lo."""
     alpha = torch.sigmoid(10 * raw[..., 3])
-    ones = torch.ones((alpha.shape[0], 1), dtype=lo)
+    ones = torch.ones((alpha.shape[0], 1), dtype=lo, device=raw.device)
     trans = torch.cumprod(torch.cat([ones, (1.0 - alpha + 1e-10).to(lo)], -1), -1)[:, :-1]
     w = alpha * trans
     rgb = torch.sum(w[..., None] * raw[..., :3], -2)
