@@ -106,9 +106,16 @@ class _FlatDecoder(nn.Module):
             self._packed = None
         return self._flat
 
+    def _pack_key(self):
+        f = self.flat_params()
+        # in-place updates (optimizer steps, load_state_dict) bump the version counter of the Parameter they touch --
+        # not necessarily the one of the flat buffer (``p.data = view`` gives p its own counter) -- so the cache key
+        # is the tuple of all of them
+        return (f.data_ptr(), f.device, f._version, tuple(p._version for p in self._views))
+
     def packed_params(self, lib, stream) -> torch.Tensor:
         f = self.flat_params()
-        key = (f.data_ptr(), f._version, f.device)
+        key = self._pack_key()
         if self._packed is None or self._packed[0] != key:
             slot = _capi.SLOT_NAMES.index(self.slot)
             pk = torch.empty(lib.nsr_packed_count(slot), dtype=torch.float32, device=f.device)
