@@ -5,18 +5,22 @@ import numpy as np
 import pytest
 import torch
 
-from scene_util import build_product, hip_render, make_scene, oracle_render, rel_err
+from scene_util import build_product, hip_render, make_scene, oracle_render, parity_failures, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 STAGES = ("coarse", "middle", "fine", "color")
 
 
-def _compare(got, ref, tag):
+def _compare(got, ref, tag, sc=None, stage=None, **kw):
     assert set(ref) <= set(got), (tag, sorted(set(ref) - set(got)))
-    for k, v in ref.items():
-        e = rel_err(got[k], v)
-        assert e < TOL, (tag, k, e)
+    if sc is not None:
+        bad = parity_failures(got, sc, stage, tol=TOL, ref=ref, **kw)      # fp32 gate, then the reference's own noise floor
+        assert not bad, (tag, bad)
+    else:
+        for k, v in ref.items():
+            e = rel_err(got[k], v)
+            assert e < TOL, (tag, k, e)
     for k in set(got) - set(ref):       # anything extra the product returns must be zero
         assert float(got[k].abs().max()) == 0.0, (tag, k)
 
@@ -59,7 +63,7 @@ def test_golden_fixture_through_hip(golden):
 @pytest.mark.parametrize("stage", STAGES)
 def test_forward_backward_small(stage):
     sc = make_scene(seed=11, n_rays=203, small=True)          # 203: not a multiple of rays-per-block
-    _compare(hip_render(sc, stage, backward=True), oracle_render(sc, stage, backward=True), stage)
+    _compare(hip_render(sc, stage, backward=True), oracle_render(sc, stage, backward=True), stage, sc, stage)
 
 
 @pytest.mark.parametrize("stage", ("middle", "color"))
@@ -73,13 +77,13 @@ def test_forward_without_depth(stage):
 def test_replica_room0_config(stage):
     """BASELINE configs[0]/[1]: Replica room0 grid shapes, 1000 rays (1024 for the coarse-only config)."""
     sc = make_scene(seed=21, n_rays=1024 if stage == "coarse" else 1000, scene="replica_room0", fine_scale=1.0)
-    _compare(hip_render(sc, stage, backward=True), oracle_render(sc, stage, backward=True), "room0/" + stage)
+    _compare(hip_render(sc, stage, backward=True), oracle_render(sc, stage, backward=True), "room0/" + stage, sc, stage)
 
 
 def test_scannet_config_color():
     """BASELINE configs[2]: ScanNet scene0000 shapes, 5000 rays (oracle ~10 s)."""
     sc = make_scene(seed=22, n_rays=5000, scene="scannet_0000", fine_scale=1.0)
-    _compare(hip_render(sc, "color", backward=True), oracle_render(sc, "color", backward=True), "scannet/color")
+    _compare(hip_render(sc, "color", backward=True), oracle_render(sc, "color", backward=True), "scannet/color", sc, "color")
 
 
 def test_edge_cases():
