@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--stage", default=None, help="pin every step to one stage (profiling)")
     ap.add_argument("--rays", type=int, default=RAYS_PER_GPU)
     ap.add_argument("--eager", action="store_true", help="do not capture the iteration in a hipGraph")
+    ap.add_argument("--stepped-grads-only", action="store_true",
+                    help="parameter gradients only for the decoder the reference's optimiser steps (colour); default: all, like the reference autograd")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,6 +120,8 @@ def main():
     grids = {k: v.requires_grad_(True) for k, v in grids.items()}
     for n_, p in dec.named_parameters():                          # reference: every decoder parameter has requires_grad=True
         p.requires_grad_(True)
+    if args.stepped_grads_only:
+        renderer.decoder_grads = ("color",)
     H, W, fx, fy, cx, cy = sc["intr"]
     depth_img, color_img, c2w = sc["depth_img"].to(dev), sc["color_img"].to(dev), sc["c2w"].to(dev)
     params = list(dec.parameters())
@@ -222,6 +226,7 @@ def main():
                                    "random-init decoders, 680x1200 synthetic RGB-D, 5x200 pixels/iter, S=32+16",
                        "rays_per_gpu": args.rays, "stage_mix": {s: stages.count(s) for s in sorted(set(stages))},
                        "timed_region": "get_samples x5 + render_batch_ray + mapping loss (sync-free form) + backward (all grid + all decoder grads, like the reference autograd), no optimiser",
+                       "decoder_grads": "colour decoder only (what Mapper's optimiser steps)" if args.stepped_grads_only else "all decoders (reference autograd semantics)",
                        "launch": "hipGraph replay (one captured graph per stage)" if use_graph else "eager",
                        "parallelism": f"ray-sharded x{world}, dense RCCL all-reduce of grid grads" if world > 1 else "single GPU"},
         }

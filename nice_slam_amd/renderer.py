@@ -230,6 +230,10 @@ class Renderer(object):
             tmpl.t_surface[i] = v
         self._arg_template = bytes(tmpl)
         self.bwd_max_blocks = 0                 # 0 = library default persistent-grid cap
+        # Optional: restrict parameter gradients to these decoders, e.g. ("color",).  The reference's autograd
+        # produces dW for every decoder in every stage although src/Mapper.py:335-341 only ever steps the colour
+        # decoder (and the fine one when fix_fine is False); None = reference semantics (requires_grad decides).
+        self.decoder_grads = None
         self.profile_events = None              # optional callable(stage) -> (hipEvent_t start, hipEvent_t stop)
         self._gt_max = None                     # set by the multi-GPU wrapper: batch-global max(gt_depth)
         self._reduce_hook = None
@@ -272,7 +276,8 @@ class Renderer(object):
         grids = _prep_grids(c, stage, dev)
         gates = []
         for s in slots:
-            want = torch.is_grad_enabled() and decoders.sub(s).wants_grad()
+            want = torch.is_grad_enabled() and decoders.sub(s).wants_grad() and \
+                (self.decoder_grads is None or s in self.decoder_grads)
             gates.append(torch.zeros((), device=dev, requires_grad=True) if want else torch.zeros((), device=dev))
         meta = (self, decoders, stage, gt_depth, self._reduce_hook)
         return _RenderFn.apply(meta, rays_o, rays_d, *[grids[s] for s in slots], *gates)
