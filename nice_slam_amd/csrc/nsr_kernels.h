@@ -273,14 +273,6 @@ NSR_DEV void tx_store(float *Tx, const Act<2> &v, int pt, int g) {
     st4(Tx + pt * kTxS + 4 * g, to_F4(v.t[0]));
     st4(Tx + pt * kTxS + 16 + 4 * g, to_F4(v.t[1]));
 }
-// element s = Tx[4s+g][16T + i]: the MFMA operand "lane = channel i of tile T, k = point 4s+g"
-NSR_DEV f32x4 tx_load_cm(const float *Tx, int T, int i, int g) {
-    f32x4 r;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) r[s] = Tx[(4 * s + g) * kTxS + 16 * T + i];
-    return r;
-}
-
 // backward of the gather, part 1: coordinate gradient (d value / d u per axis, ATen
 // grid_sampler_3d_backward), returned already reduced over g.
 NSR_DEV void coord_grad(const GridDev &G, const Lvl &L, int g, const Act<2> &dc, float &dux, float &duy, float &duz) {

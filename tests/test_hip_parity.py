@@ -86,6 +86,19 @@ def test_scannet_config_color():
     _compare(hip_render(sc, "color", backward=True), oracle_render(sc, "color", backward=True), "scannet/color", sc, "color")
 
 
+def test_apartment_config_fine():
+    """BASELINE configs[3]: Apartment grid shapes (81x53x107 fine/colour, 125 MB of grids), 5000 rays."""
+    sc = make_scene(seed=24, n_rays=5000, scene="apartment", fine_scale=1.0)
+    _compare(hip_render(sc, "fine", backward=True), oracle_render(sc, "fine", backward=True), "apartment/fine", sc, "fine")
+
+
+def test_synthetic_stress_shapes_color():
+    """BASELINE configs[4] geometry: bound +-5.12 m, 1024x1024 pinhole; parity at 2000 rays (the 100k-ray size is
+    covered by the property test below)."""
+    sc = make_scene(seed=25, n_rays=2000, scene="synthetic", fine_scale=1.0)
+    _compare(hip_render(sc, "color", backward=True), oracle_render(sc, "color", backward=True), "synthetic/color", sc, "color")
+
+
 def test_edge_cases():
     sc = make_scene(seed=13, n_rays=5, small=True, zero_frac=0.0)
     sc["gt_depth"][0] = 0.0          # zero-depth ray -> surface samples spread over [0.001, max]
