@@ -11,6 +11,7 @@
  *                           raw2outputs_nerf_color (src/common.py:204-245)
  *   nsr_render_bwd       <- the autograd backward of the above (src/Mapper.py:503, src/Tracker.py:125)
  *   nsr_eval_points_fwd  <- src/utils/Renderer.py:23-61   Renderer.eval_points (forward only)
+ *   nsr_masked_adam      <- src/Mapper.py:368-379,394-401,504,511-519  masked write-back + Adam on one feature grid
  *
  * Conventions
  *   - all pointers are DEVICE pointers owned by the caller (PyTorch); the library never frees or
@@ -123,6 +124,18 @@ int nsr_get_samples(const int64_t *indices, int64_t n, int32_t H0, int32_t H1, i
                     int32_t W_full, float fx, float fy, float cx, float cy,
                     const float *c2w, int32_t c2w_stride, const float *depth, const float *color,
                     float *rays_o, float *rays_d, float *out_depth, float *out_color, void *stream);
+
+/* --- the per-iteration grid update of Mapper.optimize_map, fused ---------------------------------
+ * Replaces, for one feature grid, `val[mask] = val_grad` (src/Mapper.py:394-401), the Adam step on the masked leaf
+ * (:368-379,504, torch.optim.Adam defaults) and the write-back `val[mask] = val_grad.detach()` (:511-519) by one in-place
+ * pass over the grid: for every voxel whose mask byte is non-zero (mask == NULL: every voxel) and each of its 32 channels
+ *     m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  p -= step_size * m / (sqrt(v)/bias2_sqrt + eps)
+ * with step_size = lr/(1-b1^t) and bias2_sqrt = sqrt(1-b2^t) evaluated by the caller in double precision, exactly the two
+ * host scalars torch.optim.Adam forms (t = number of steps in which this grid received a gradient).
+ * p, g, m, v: [Z][Y][X][32] fp32 (channels-last, like every grid of this ABI); voxel_mask: [Z][Y][X] uint8.
+ * lr == 0 still updates the moments, exactly like torch.optim.Adam. */
+int nsr_masked_adam(float *p, const float *g, float *m, float *v, const uint8_t *voxel_mask, int64_t n_voxels,
+                    float step_size, float beta1, float beta2, float eps, float bias2_sqrt, void *stream);
 
 #ifdef __cplusplus
 }

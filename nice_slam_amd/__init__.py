@@ -8,6 +8,7 @@ No CPU / PyTorch fallback exists: every arithmetic entry point goes through libn
 from .common import get_samples, get_rays, grid_init, load_bound, to_channels_last  # noqa: F401
 from .decoders import NICE, MLP, MLP_no_xyz  # noqa: F401
 from .renderer import Renderer  # noqa: F401
+from .optim import MaskedGridAdam  # noqa: F401
 
 __all__ = ["Renderer", "NICE", "MLP", "MLP_no_xyz", "get_samples", "get_rays", "grid_init", "load_bound",
-           "to_channels_last"]
+           "to_channels_last", "MaskedGridAdam"]

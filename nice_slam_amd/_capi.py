@@ -59,6 +59,8 @@ SYMBOLS = (
     ("nsr_render_fwd", C.c_int, [C.POINTER(NsrRenderArgs), C.c_void_p]),
     ("nsr_render_bwd", C.c_int, [C.POINTER(NsrRenderArgs), C.POINTER(NsrBwdArgs), C.c_void_p]),
     ("nsr_eval_points_fwd", C.c_int, [C.POINTER(NsrRenderArgs), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("nsr_masked_adam", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     ("nsr_get_samples", C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

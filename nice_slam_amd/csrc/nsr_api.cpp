@@ -239,6 +239,21 @@ int nsr_eval_points_fwd(const nsr_render_args *a, const double *points, int64_t 
     return finish("nsr_eval_points_fwd");
 }
 
+int nsr_masked_adam(float *p, const float *g, float *m, float *v, const uint8_t *voxel_mask, int64_t n_voxels,
+                    float step_size, float beta1, float beta2, float eps, float bias2_sqrt, void *stream) {
+    if (n_voxels < 0) return fail("nsr_masked_adam: negative voxel count");
+    if (n_voxels == 0) return 0;
+    if (!p || !g || !m || !v) return fail("nsr_masked_adam: null pointer");
+    if (!(bias2_sqrt > 0.f)) return fail("nsr_masked_adam: bias2_sqrt must be positive (step >= 1)");
+    nsr::AdamParams A;
+    A.p = p; A.g = g; A.m = m; A.v = v; A.mask = voxel_mask; A.n_vox = n_voxels;
+    A.step = step_size; A.b1 = beta1; A.b2 = beta2; A.eps = eps; A.rs2 = bias2_sqrt;
+    const int tb = 256;
+    const long long nthreads = n_voxels * 8;
+    NSR_LAUNCH(nsr::masked_adam_kernel, dim3((unsigned)((nthreads + tb - 1) / tb)), dim3(tb), 0, stream, A);
+    return finish("nsr_masked_adam");
+}
+
 int nsr_get_samples(const int64_t *indices, int64_t n, int32_t H0, int32_t H1, int32_t W0, int32_t W1,
                     int32_t W_full, float fx, float fy, float cx, float cy,
                     const float *c2w, int32_t c2w_stride, const float *depth, const float *color,

@@ -1378,6 +1378,42 @@ NSR_KERNEL void reduce_partials_kernel(const float *__restrict__ partials, int n
 }
 
 // ------------------------------------------------------------------------------------------------
+// masked Adam on a channels-last feature grid (Mapper.py:368-379,394-401,504,511-519 fused; torch.optim.Adam
+// single-tensor formulas).  One thread = 4 channels of one voxel (16-byte accesses, a voxel = 8 threads = one
+// 128-byte line per array); HBM-bound: 896 B per updated voxel.
+// ------------------------------------------------------------------------------------------------
+struct AdamParams {
+    float *p;
+    const float *g;
+    float *m, *v;
+    const unsigned char *mask;
+    long long n_vox;
+    float step, b1, b2, eps, rs2;     // step = lr / (1 - b1^t), rs2 = sqrt(1 - b2^t)
+};
+
+NSR_KERNEL void masked_adam_kernel(const AdamParams A) {
+    const long long t = (long long)bid_x() * nthreads() + tid();
+    const long long vox = t >> 3;
+    if (vox >= A.n_vox) return;
+    if (A.mask && A.mask[vox] == 0) return;
+    const long long o = vox * kC + (t & 7) * 4;
+    const F4 g = ld4(A.g + o);
+    F4 m = ld4(A.m + o), v = ld4(A.v + o), p = ld4(A.p + o);
+    const float step = A.step, rs2 = A.rs2, omb1 = 1.f - A.b1, omb2 = 1.f - A.b2;
+    // exp_avg.lerp_(grad, 1-beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2);
+    // denom = exp_avg_sq.sqrt() / sqrt(bias2) + eps; param.addcdiv_(exp_avg, denom, value=-step)
+#define NSR_ADAM1(c)                                                    \
+    m.c = m.c + omb1 * (g.c - m.c);                                      \
+    v.c = v.c * A.b2 + (omb2 * g.c) * g.c;                               \
+    p.c = p.c - step * (m.c / (sqrtf(v.c) / rs2 + A.eps));
+    NSR_ADAM1(x) NSR_ADAM1(y) NSR_ADAM1(z) NSR_ADAM1(w)
+#undef NSR_ADAM1
+    st4(A.m + o, m);
+    st4(A.v + o, v);
+    st4(A.p + o, p);
+}
+
+// ------------------------------------------------------------------------------------------------
 // get_samples after the index draw (common.py:74-134)
 // ------------------------------------------------------------------------------------------------
 struct SampleParams {

@@ -187,6 +187,7 @@ using ::fminf;
 using ::floorf;
 using ::rintf;
 using ::expf;
+using ::sqrtf;
 
 }  // namespace nsr
 

@@ -128,3 +128,44 @@ def test_eval_points_and_get_samples(emu, golden):
                                   ptr(golden["depth_img"]), ptr(golden["color_img"]), ptr(o), ptr(d), ptr(sd), ptr(scol), None))
     assert np.array_equal(o, golden["gs/rays_o"]) and np.array_equal(d, golden["gs/rays_d"])      # bit-exact
     assert np.array_equal(sd, golden["gs/depth"]) and np.array_equal(scol, golden["gs/color"])
+
+
+def test_masked_adam_matches_reference_flow(emu):
+    """`val[mask] = val_grad` + torch.optim.Adam on the masked leaf + write-back
+    (src/Mapper.py:303-333,368-379,394-401,504,511-519) against ONE in-place nsr_masked_adam per step."""
+    from emu_harness import ptr
+    g = torch.Generator().manual_seed(9)
+    Z, Y, X = 5, 4, 7
+    val0 = torch.randn((1, 32, Z, Y, X), generator=g) * 0.01
+    vmask = torch.rand((Z, Y, X), generator=g) < 0.6
+    mask = vmask[None, None].expand(1, 32, Z, Y, X)
+    lrs = [0.1, 0.0, 0.005, None, 0.005, 0.02]                # None: the grid got no gradient in that iteration (skipped)
+    grads = [torch.randn((1, 32, Z, Y, X), generator=g) * (10.0 ** -i) for i in range(len(lrs))]
+    # reference flow
+    val = val0.clone()
+    leaf = val[mask].clone().requires_grad_(True)
+    opt = torch.optim.Adam([{"params": [leaf], "lr": 0.0}])
+    for lr, gr in zip(lrs, grads):
+        if lr is None:
+            continue
+        opt.param_groups[0]["lr"] = lr
+        leaf.grad = gr[mask].clone()
+        opt.step()
+        val = val.detach()
+        val[mask] = leaf.detach()
+    # fused
+    cl = lambda t: np.ascontiguousarray(t.numpy()[0].transpose(1, 2, 3, 0))          # [Z][Y][X][32]
+    p = cl(val0.clone()); m = np.zeros_like(p); v = np.zeros_like(p)
+    vm = np.ascontiguousarray(vmask.numpy().astype(np.uint8))
+    t = 0
+    for lr, gr in zip(lrs, grads):
+        if lr is None:
+            continue
+        t += 1
+        gg = cl(gr)
+        emu.check(emu.nsr_masked_adam(ptr(p), ptr(gg), ptr(m), ptr(v), ptr(vm), Z * Y * X,
+                                      lr / (1 - 0.9 ** t), 0.9, 0.999, 1e-8, (1 - 0.999 ** t) ** 0.5, None))
+    got = torch.from_numpy(p.transpose(3, 0, 1, 2)[None])
+    assert torch.equal(got[~mask], val0[~mask])                # untouched outside the mask
+    assert rel_err(got, val) < 2e-5                            # fp32 rounding-order differences of the Adam arithmetic
+    assert float((got - val0).abs().max()) > 1e-3              # and it did move

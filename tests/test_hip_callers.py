@@ -147,3 +147,55 @@ def test_ncdhw_grids_are_accepted():
     for k in ("grid_middle", "grid_fine", "grid_color"):
         assert grids[k].grad.shape == grids[k].shape
         assert rel_err(grids[k].grad, ref["d_" + k]) < 1e-4, k
+
+
+def test_masked_grid_adam_replaces_masked_leaf_flow():
+    """§8(f) rank 1 on the GPU: nice_slam_amd.MaskedGridAdam (one in-place kernel per grid) against the reference's
+    masked-leaf + torch.optim.Adam + write-back flow, driven by real render gradients for a few mapping iterations."""
+    import nice_slam_amd as nsa
+    sc = make_scene(seed=41, n_rays=300, small=True)
+    renderer, dec, grids_dev = build_product(sc, DEV)
+    for p in dec.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator().manual_seed(6)
+    vmasks = {k: (torch.rand(v.shape[2:], generator=g) < 0.7) for k, v in sc["grids"].items()}
+    keys = ("grid_middle", "grid_fine", "grid_color")
+    stages = ["middle", "fine", "color", "color"]
+    lr = {"middle": {"grid_middle": 0.1}, "fine": {"grid_middle": 0.005, "grid_fine": 0.005},
+          "color": {"grid_middle": 0.005, "grid_fine": 0.005, "grid_color": 0.005}}
+    o, d, gd, gc = (sc[k].to(DEV) for k in ("rays_o", "rays_d", "gt_depth", "gt_color"))
+
+    def loss_of(c, stage):
+        depth, unc, col = renderer.render_batch_ray(c, dec, d, o, DEV, stage, gt_depth=gd)
+        loss = (torch.abs(gd - depth) * (gd > 0)).sum()
+        return loss + 0.2 * torch.abs(gc - col).sum() if stage == "color" else loss
+
+    # (A) reference flow: masked 1-D leaves + torch Adam + index_put write-back (Mapper.py:303-333,394-401,504,511-519)
+    cA = {k: v.detach().clone(memory_format=torch.preserve_format) for k, v in grids_dev.items()}
+    full = {k: vmasks[k][None, None].expand_as(cA[k]).to(DEV) for k in keys}
+    leaves = {k: cA[k][full[k]].clone().requires_grad_(True) for k in keys}
+    opt = torch.optim.Adam([{"params": [leaves[k]], "lr": 0.0} for k in keys])
+    for stage in stages:
+        for k in keys:
+            val = cA[k]; val[full[k]] = leaves[k]; cA[k] = val
+        for gi, k in enumerate(keys):
+            opt.param_groups[gi]["lr"] = lr[stage].get(k, 0.0)
+        opt.zero_grad()
+        loss_of(cA, stage).backward()
+        opt.step()
+        for k in keys:
+            val = cA[k].detach(); val[full[k]] = leaves[k].detach().clone(); cA[k] = val
+    # (B) fused: dense grids are the parameters
+    cB = {k: v.detach().clone(memory_format=torch.preserve_format).requires_grad_(k in keys) for k, v in grids_dev.items()}
+    fused = nsa.MaskedGridAdam({k: cB[k] for k in keys}, {k: vmasks[k] for k in keys})
+    for stage in stages:
+        for k in keys:
+            cB[k].grad = None
+        loss_of(cB, stage).backward()
+        with torch.no_grad():
+            fused.step({k: lr[stage].get(k, 0.0) for k in keys})
+    for k in keys:
+        a, b = cA[k].detach().cpu(), cB[k].detach().cpu()
+        assert torch.equal(b[~full[k].cpu()], sc["grids"][k][~full[k].cpu()]), k          # unmasked voxels untouched
+        assert float((a - b).abs().mean()) < 2e-5 * float(a.abs().max()) + 1e-7, (k, float((a - b).abs().mean()))
+        assert float((b - sc["grids"][k]).abs().max()) > 1e-4, k
