@@ -227,13 +227,18 @@ int nsr_eval_points_fwd(const nsr_render_args *a, const double *points, int64_t 
     if (n_points < 0 || (n_points > 0 && (!points || !out))) return fail("nsr_eval_points_fwd: bad points / out");
     if (n_points == 0) return 0;
     P.points = points; P.n_points = n_points; P.out_points = out;
-    const int waves = 8, lds = round16(3 * nsr::AUX_FLOATS * 4);
+    const int waves = kMaxTiles;
+    const int wlf = P.stage == NSR_STAGE_COARSE ? nsr::packed_total(0) : (P.stage == NSR_STAGE_MIDDLE ? nsr::packed_total(1) : nsr::packed_total(2));
+    const int lds = round16(3 * nsr::AUX_FLOATS * 4) + 16 + wlf * 4;
     const long long tiles = (n_points + nsr::kTile - 1) / nsr::kTile;
     long long nb = (tiles + waves - 1) / waves;
-    if (nb > 4096) nb = 4096;
+    if (nb > 2048) nb = 2048;
     const dim3 grid((unsigned)nb), block(64 * waves);
 #define NSR_EVP(ST)                                                                              \
-    case ST: NSR_LAUNCH(nsr::eval_points_kernel<ST>, grid, block, lds, stream, P); break;
+    case ST:                                                                                     \
+        if (int rc = launch_cfg(nsr::eval_points_kernel<ST>, lds, "nsr_eval_points_fwd")) return rc; \
+        NSR_LAUNCH(nsr::eval_points_kernel<ST>, grid, block, lds, stream, P);                     \
+        break;
     switch (P.stage) { NSR_EVP(0) NSR_EVP(1) NSR_EVP(2) NSR_EVP(3) }
 #undef NSR_EVP
     return finish("nsr_eval_points_fwd");

@@ -736,51 +736,6 @@ NSR_DEV void mlp_nox_fwd(const float *pk, const float *aux, const Act<2> &c, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// NICE.forward for the point of this lane (decoder.py:312-342) + the out-of-bound override of
-// Renderer.eval_points (Renderer.py:43-46,57).  Returns (r,g,b,occ); every lane of a point gets
-// the same value.
-// ------------------------------------------------------------------------------------------------
-template <int STAGE>
-NSR_DEV F4 decode_point(const RenderParams &P, const float *aux, double px, double py, double pz, int lane) {
-    const int g = lane >> 4;
-    const bool inside = (px > P.blo[0]) && (px < P.bhi[0]) && (py > P.blo[1]) && (py < P.bhi[1]) &&
-                        (pz > P.blo[2]) && (pz < P.bhi[2]);
-    F4 raw = F4{0.f, 0.f, 0.f, 0.f};
-    if (STAGE == NSR_STAGE_COARSE) {
-        const Lvl L = make_level(P.grid[NSR_COARSE], px, py, pz);
-        const Act<2> c = gather_feat(P.grid[NSR_COARSE], L, g);
-        float o[1];
-        mlp_nox_fwd<false, false>(P.dec[NSR_COARSE].packed, aux, c, lane, o, nullptr);
-        raw.w = o[0];
-    } else {
-        const float fx = (float)px, fy = (float)py, fz = (float)pz;     // decoder.py:189
-        const Lvl Lm = make_level(P.grid[NSR_MIDDLE], px, py, pz);
-        const Act<2> cm = gather_feat(P.grid[NSR_MIDDLE], Lm, g);
-        float om[1];
-        mlp_xyz_fwd<NSR_MIDDLE, false, false>(P.dec[NSR_MIDDLE].packed, aux, fx, fy, fz, cm, lane, om, nullptr);
-        float occ = om[0];
-        if (STAGE >= NSR_STAGE_FINE) {
-            const Lvl Lf = make_level(P.grid[NSR_FINE], px, py, pz);
-            const Act<2> cf = gather_feat(P.grid[NSR_FINE], Lf, g);
-            Act<4> cc;
-            cc.t[0] = cf.t[0]; cc.t[1] = cf.t[1]; cc.t[2] = cm.t[0]; cc.t[3] = cm.t[1];    // decoder.py:182-187
-            float of[1];
-            mlp_xyz_fwd<NSR_FINE, false, false>(P.dec[NSR_FINE].packed, aux + AUX_FLOATS, fx, fy, fz, cc, lane, of, nullptr);
-            occ = of[0] + om[0];                                                            // decoder.py:333,341
-        }
-        if (STAGE == NSR_STAGE_COLOR) {
-            const Lvl Lc = make_level(P.grid[NSR_COLOR], px, py, pz);
-            const Act<2> ccol = gather_feat(P.grid[NSR_COLOR], Lc, g);
-            float oc[4];
-            mlp_xyz_fwd<NSR_COLOR, false, false>(P.dec[NSR_COLOR].packed, aux + 2 * AUX_FLOATS, fx, fy, fz, ccol, lane, oc, nullptr);
-            raw.x = oc[0]; raw.y = oc[1]; raw.z = oc[2];
-        }
-        raw.w = occ;
-    }
-    if (!inside) raw.w = 100.f;
-    return raw;
-}
-
 template <int STAGE>
 NSR_DEV void load_stage_aux(const RenderParams &P, float *aux) {
     if (STAGE == NSR_STAGE_COARSE) {
@@ -824,6 +779,53 @@ NSR_DEV double wave_sum_d(double v) {
     return v;
 }
 
+// NICE.forward for the tile of this wave with the packed weights staged in LDS, one decoder after the other
+// (block-wide barriers inside: EVERY wave of the block must call it).  On entry `wl` holds the first decoder of the
+// stage (coarse or middle); on exit the last one.  Returns (r,g,b,occ) before the out-of-bound override.
+template <int STAGE>
+NSR_DEV F4 decode_tile_lds(const RenderParams &P, const float *aux, float *wl, double px, double py, double pz, int lane) {
+    const int g = lane >> 4;
+    F4 raw = F4{0.f, 0.f, 0.f, 0.f};
+    if (STAGE == NSR_STAGE_COARSE) {
+        const Lvl L = make_level(P.grid[NSR_COARSE], px, py, pz);
+        const Act<2> c = gather_feat(P.grid[NSR_COARSE], L, g);
+        float o[1];
+        mlp_nox_fwd<false, true>(wl, aux, c, lane, o, nullptr);
+        raw.w = o[0];
+    } else {
+        const float fx = (float)px, fy = (float)py, fz = (float)pz;     // decoder.py:189
+        const Lvl Lm = make_level(P.grid[NSR_MIDDLE], px, py, pz);
+        const Act<2> cm = gather_feat(P.grid[NSR_MIDDLE], Lm, g);
+        float om[1];
+        mlp_xyz_fwd<NSR_MIDDLE, false, true>(wl, aux, fx, fy, fz, cm, lane, om, nullptr);
+        float occ = om[0];
+        if (STAGE >= NSR_STAGE_FINE) {
+            const Lvl Lf = make_level(P.grid[NSR_FINE], px, py, pz);
+            const Act<2> cf = gather_feat(P.grid[NSR_FINE], Lf, g);
+            block_sync();                                               // everyone is done with the middle weights
+            load_packed<NSR_FINE>(wl, P.dec[NSR_FINE].packed);
+            block_sync();
+            Act<4> cc;
+            cc.t[0] = cf.t[0]; cc.t[1] = cf.t[1]; cc.t[2] = cm.t[0]; cc.t[3] = cm.t[1];    // decoder.py:182-187
+            float of[1];
+            mlp_xyz_fwd<NSR_FINE, false, true>(wl, aux + AUX_FLOATS, fx, fy, fz, cc, lane, of, nullptr);
+            occ = of[0] + om[0];                                                            // decoder.py:333,341
+        }
+        if (STAGE == NSR_STAGE_COLOR) {
+            const Lvl Lc = make_level(P.grid[NSR_COLOR], px, py, pz);
+            const Act<2> ccol = gather_feat(P.grid[NSR_COLOR], Lc, g);
+            block_sync();
+            load_packed<NSR_COLOR>(wl, P.dec[NSR_COLOR].packed);
+            block_sync();
+            float oc[4];
+            mlp_xyz_fwd<NSR_COLOR, false, true>(wl, aux + 2 * AUX_FLOATS, fx, fy, fz, ccol, lane, oc, nullptr);
+            raw.x = oc[0]; raw.y = oc[1]; raw.z = oc[2];
+        }
+        raw.w = occ;
+    }
+    return raw;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward kernel
 // LDS: aux[3*AUX] | ztmp[npts] f64 | zbuf[npts] f64 | rawbuf[npts] F4 | wl: packed weights of the decoder in flight
@@ -845,10 +847,11 @@ NSR_KERNEL NSR_BOUNDS(768) void render_fwd_kernel(const RenderParams P) {
 
     load_stage_aux<STAGE>(P, aux);
     if (STAGE == NSR_STAGE_COARSE) load_packed<NSR_COARSE>(wl, P.dec[NSR_COARSE].packed);     // only one decoder: staged once
+    if (STAGE == NSR_STAGE_MIDDLE) load_packed<NSR_MIDDLE>(wl, P.dec[NSR_MIDDLE].packed);
     for (long long grp = bid_x(); grp < P.n_groups; grp += nblk_x()) {
         loop_fence();
         const long long ray0 = grp * P.rays_per_block;
-        if (STAGE != NSR_STAGE_COARSE) load_packed<NSR_MIDDLE>(wl, P.dec[NSR_MIDDLE].packed);
+        if (STAGE > NSR_STAGE_MIDDLE) load_packed<NSR_MIDDLE>(wl, P.dec[NSR_MIDDLE].packed);   // fine / colour overwrote it
         compute_z(P, ray0, ztmp, zbuf);            // ends with block_sync (also covers the aux / weight staging)
         const int pidx = wave * kTile + (lane & 15);
         const int r = pidx / S, k = pidx - r * S;
@@ -862,44 +865,7 @@ NSR_KERNEL NSR_BOUNDS(768) void render_fwd_kernel(const RenderParams P) {
         const double pz = (double)P.rays_o[rr * 3 + 2] + (double)P.rays_d[rr * 3 + 2] * z;
         const bool inside = (px > P.blo[0]) && (px < P.bhi[0]) && (py > P.blo[1]) && (py < P.bhi[1]) &&
                             (pz > P.blo[2]) && (pz < P.bhi[2]);
-        F4 raw = F4{0.f, 0.f, 0.f, 0.f};
-        if (STAGE == NSR_STAGE_COARSE) {
-            const Lvl L = make_level(P.grid[NSR_COARSE], px, py, pz);
-            const Act<2> c = gather_feat(P.grid[NSR_COARSE], L, g);
-            float o[1];
-            mlp_nox_fwd<false, true>(wl, aux, c, lane, o, nullptr);
-            raw.w = o[0];
-        } else {
-            const float fx = (float)px, fy = (float)py, fz = (float)pz;     // decoder.py:189
-            const Lvl Lm = make_level(P.grid[NSR_MIDDLE], px, py, pz);
-            const Act<2> cm = gather_feat(P.grid[NSR_MIDDLE], Lm, g);
-            float om[1];
-            mlp_xyz_fwd<NSR_MIDDLE, false, true>(wl, aux, fx, fy, fz, cm, lane, om, nullptr);
-            float occ = om[0];
-            if (STAGE >= NSR_STAGE_FINE) {
-                const Lvl Lf = make_level(P.grid[NSR_FINE], px, py, pz);
-                const Act<2> cf = gather_feat(P.grid[NSR_FINE], Lf, g);
-                block_sync();                                               // everyone is done with the middle weights
-                load_packed<NSR_FINE>(wl, P.dec[NSR_FINE].packed);
-                block_sync();
-                Act<4> cc;
-                cc.t[0] = cf.t[0]; cc.t[1] = cf.t[1]; cc.t[2] = cm.t[0]; cc.t[3] = cm.t[1];    // decoder.py:182-187
-                float of[1];
-                mlp_xyz_fwd<NSR_FINE, false, true>(wl, aux + AUX_FLOATS, fx, fy, fz, cc, lane, of, nullptr);
-                occ = of[0] + om[0];                                                            // decoder.py:333,341
-            }
-            if (STAGE == NSR_STAGE_COLOR) {
-                const Lvl Lc = make_level(P.grid[NSR_COLOR], px, py, pz);
-                const Act<2> ccol = gather_feat(P.grid[NSR_COLOR], Lc, g);
-                block_sync();
-                load_packed<NSR_COLOR>(wl, P.dec[NSR_COLOR].packed);
-                block_sync();
-                float oc[4];
-                mlp_xyz_fwd<NSR_COLOR, false, true>(wl, aux + 2 * AUX_FLOATS, fx, fy, fz, ccol, lane, oc, nullptr);
-                raw.x = oc[0]; raw.y = oc[1]; raw.z = oc[2];
-            }
-            raw.w = occ;
-        }
+        F4 raw = decode_tile_lds<STAGE>(P, aux, wl, px, py, pz, lane);
         if (!inside) raw.w = 100.f;                                         // Renderer.py:57
         if (active && g == 0) {
             rawbuf[pidx] = raw;
@@ -928,21 +894,32 @@ NSR_KERNEL NSR_BOUNDS(768) void render_fwd_kernel(const RenderParams P) {
     }
 }
 
-// Renderer.eval_points forward over a flat list of points (Renderer.py:23-61)
+// Renderer.eval_points forward over a flat list of points (Renderer.py:23-61).  Same decoder phases as the render
+// kernel (packed weights staged in LDS per decoder); a block takes groups of `nwaves` tiles.
 template <int STAGE>
-NSR_KERNEL NSR_BOUNDS(512) void eval_points_kernel(const RenderParams P) {
+NSR_KERNEL NSR_BOUNDS(768) void eval_points_kernel(const RenderParams P) {
     float *aux = reinterpret_cast<float *>(lds_base());
+    float *wl = aux + 3 * AUX_FLOATS + ((3 * AUX_FLOATS) & 3 ? 4 - ((3 * AUX_FLOATS) & 3) : 0);
     const int lane = tid() & 63, wave = tid() >> 6, nwaves = nthreads() >> 6;
     load_stage_aux<STAGE>(P, aux);
-    block_sync();
+    if (STAGE == NSR_STAGE_COARSE) load_packed<NSR_COARSE>(wl, P.dec[NSR_COARSE].packed);
+    if (STAGE == NSR_STAGE_MIDDLE) load_packed<NSR_MIDDLE>(wl, P.dec[NSR_MIDDLE].packed);
     const long long ntiles = (P.n_points + kTile - 1) / kTile;
-    for (long long tile = (long long)bid_x() * nwaves + wave; tile < ntiles; tile += (long long)nblk_x() * nwaves) {
+    const long long ngroups = (ntiles + nwaves - 1) / nwaves;
+    for (long long grp = bid_x(); grp < ngroups; grp += nblk_x()) {
         loop_fence();
-        const long long pi = tile * kTile + (lane & 15);
+        if (STAGE > NSR_STAGE_MIDDLE) load_packed<NSR_MIDDLE>(wl, P.dec[NSR_MIDDLE].packed);   // fine / colour overwrote it
+        block_sync();
+        const long long pi = (grp * nwaves + wave) * kTile + (lane & 15);
         const bool active = pi < P.n_points;
         const long long pp = active ? pi : 0;
-        const F4 raw = decode_point<STAGE>(P, aux, P.points[pp * 3 + 0], P.points[pp * 3 + 1], P.points[pp * 3 + 2], lane);
+        const double px = P.points[pp * 3 + 0], py = P.points[pp * 3 + 1], pz = P.points[pp * 3 + 2];
+        F4 raw = decode_tile_lds<STAGE>(P, aux, wl, px, py, pz, lane);
+        const bool inside = (px > P.blo[0]) && (px < P.bhi[0]) && (py > P.blo[1]) && (py < P.bhi[1]) &&
+                            (pz > P.blo[2]) && (pz < P.bhi[2]);
+        if (!inside) raw.w = 100.f;                                         // Renderer.py:57
         if (active && (lane >> 4) == 0) st4(P.out_points + pi * 4, raw);
+        block_sync();                                                       // before the next group re-stages the weights
     }
 }
 
