@@ -169,3 +169,29 @@ def test_masked_adam_matches_reference_flow(emu):
     assert torch.equal(got[~mask], val0[~mask])                # untouched outside the mask
     assert rel_err(got, val) < 2e-5                            # fp32 rounding-order differences of the Adam arithmetic
     assert float((got - val0).abs().max()) > 1e-3              # and it did move
+
+
+@pytest.mark.parametrize("ns,nsurf", [(20, 5), (16, 0), (40, 24)])
+def test_other_sample_counts(emu, ns, nsurf):
+    """rendering.N_samples / N_surface other than 32 + 16: S = 25 (tiles straddle rays, padded last tile), 16, 64"""
+    from emu_harness import HostScene
+    from oracle import nice_oracle as orc
+    s = make_scene(seed=200 + ns, n_rays=7, small=True)
+    sc = HostScene(emu, s["grids"], s["params"], s["bound"].numpy(), 2.0, n_samples=ns, n_surface=nsurf)
+    stage = "color"
+    fwd = sc.forward(stage, s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy())
+    grids = {k: v.clone().requires_grad_(True) for k, v in s["grids"].items()}
+    params = {k: v.clone().requires_grad_(True) for k, v in s["params"].items()}
+    o = s["rays_o"].clone().requires_grad_(True); d = s["rays_d"].clone().requires_grad_(True)
+    depth, var, rgb = orc.render_batch_ray(grids, params, d, o, stage, s["gt_depth"], s["bound"], n_samples=ns, n_surface=nsurf)
+    assert fwd["raw"].shape[1] == ns + nsurf
+    for k, v in (("depth", depth), ("var", var), ("rgb", rgb)):
+        assert rel_err(fwd[k], v.detach()) < TOL, k
+    w = s["w"]
+    ((depth * w["depth"]).sum() + (var * w["var"]).sum() + (rgb * w["rgb"]).sum()).backward()
+    res = sc.backward(stage, fwd, w["depth"].numpy(), w["var"].numpy(), w["rgb"].numpy())
+    assert rel_err(res["d_rays_d"], d.grad) < TOL and rel_err(res["d_rays_o"], o.grad) < TOL
+    for k in ("grid_middle", "grid_fine", "grid_color"):
+        assert rel_err(res["d_" + k], grids[k].grad) < TOL, k
+    for k in ("color_decoder.pts_linears.3.weight", "color_decoder.embedder._B", "fine_decoder.fc_c.2.weight", "middle_decoder.pts_linears.0.bias"):
+        assert rel_err(res["dparam/" + k], params[k].grad) < TOL, k
