@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--eager", action="store_true", help="do not capture the iteration in a hipGraph")
     ap.add_argument("--stepped-grads-only", action="store_true",
                     help="parameter gradients only for the decoder the reference's optimiser steps (colour); default: all, like the reference autograd")
+    ap.add_argument("--dense-exchange", action="store_true",
+                    help="multi-GPU: all-reduce the whole feature-grid gradients instead of the frustum-selected voxel rows")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,6 +130,20 @@ def main():
     ev = HipEvents()
     renderer.profile_events = ev.pair_for
     rend = ShardedRenderer(renderer) if (world > 1 or force_dist) else renderer
+    exchange = "single GPU"
+    if world > 1 or force_dist:
+        exchange = f"ray-sharded x{world}, dense RCCL all-reduce of grid grads"
+        if not args.dense_exchange:
+            # The mapper optimises only the voxels inside the current frame's frustum mask (Mapper.py:315-333), identical
+            # on every rank: exchange those voxel rows only (parallel.ShardedRenderer.set_voxel_masks).
+            sel = nsa.FrustumSelector(sc["bound"], H, W, fx, fy, cx, cy)
+            pose = torch.eye(4)
+            pose[:3] = sc["c2w"][:3].detach().cpu().float()
+            masks = {k: sel.voxel_mask(pose, k, v.shape[2:], depth_img) for k, v in grids.items() if k != "grid_coarse"}
+            rend.set_voxel_masks(masks)
+            frac = {k[5:]: round(float(m.float().mean()), 3) for k, m in masks.items()}
+            exchange = (f"ray-sharded x{world}, one packed RCCL all-reduce per iteration over the frustum-selected voxel rows "
+                        f"(selected fraction {frac}) + decoder grads")
     torch.manual_seed(1234)                                       # identical index draws on every rank
     per_frame = n_total // WINDOW
 
@@ -228,7 +244,7 @@ def main():
                        "timed_region": "get_samples x5 + render_batch_ray + mapping loss (sync-free form) + backward (all grid + all decoder grads, like the reference autograd), no optimiser",
                        "decoder_grads": "colour decoder only (what Mapper's optimiser steps)" if args.stepped_grads_only else "all decoders (reference autograd semantics)",
                        "launch": "hipGraph replay (one captured graph per stage)" if use_graph else "eager",
-                       "parallelism": f"ray-sharded x{world}, dense RCCL all-reduce of grid grads" if world > 1 else "single GPU"},
+                       "parallelism": exchange},
         }
         if "color" in ksum:
             ms, cnt = ksum["color"]
@@ -245,6 +261,8 @@ def main():
                                "measured": "HIP events recorded inside nsr_render_bwd on the launch stream, eager iterations of this process"
                                            + (" (the timed region replays the captured graph of the same kernels)" if use_graph else ""),
                                "algorithmic_flop_per_launch": rays_launch * BWD_COLOR_FLOP_PER_RAY}
+        if world > 1 or force_dist:
+            res["config"]["grad_exchange_MB_last_iter"] = round(rend.last_exchange_floats * 4 / 1e6, 2)
         res["kernel_ms"] = {f"render_bwd<{s}>": round(v[0], 4) for s, v in ksum.items()}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(sc)

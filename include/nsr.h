@@ -137,6 +137,21 @@ int nsr_get_samples(const int64_t *indices, int64_t n, int32_t H0, int32_t H1, i
 int nsr_masked_adam(float *p, const float *g, float *m, float *v, const uint8_t *voxel_mask, int64_t n_voxels,
                     float step_size, float beta1, float beta2, float eps, float bias2_sqrt, void *stream);
 
+/* --- frustum feature selection ---------------------------------------------------------------------
+ * Replaces Mapper.get_mask_from_c2w (src/Mapper.py:93-164) for one non-coarse feature grid: every voxel centre (xs[ix],
+ * ys[iy], zs[iz]: the per-axis torch.linspace over the scene bound, :111-113, device arrays) is projected with
+ * w2c = inv(c2w) (HOST array, 12 floats = rows 0..2; :120-131), its depth is looked up in the current depth image with
+ * cv2.remap INTER_LINEAR semantics (:133-140), zero depths are replaced by the maximum remapped depth (:147-148), and the
+ * voxel is selected when it projects inside the image with 0 <= -z <= depth + 0.5 (:142-151) or lies within 0.5 m of the
+ * camera centre cam_center (HOST array, 3 floats; :155-161).
+ * depth: [H][W] fp32 device; voxel_mask: [Z][Y][X] uint8 device (the layout nsr_masked_adam takes; the reference's
+ * (X,Y,Z) return value is its transpose, which Mapper.py:318 undoes); workspace: nsr_frustum_workspace_floats(nx*ny*nz)
+ * floats of device scratch. */
+int64_t nsr_frustum_workspace_floats(int64_t n_voxels);
+int nsr_frustum_mask(const float *w2c, const float *cam_center, double fx, double fy, double cx, double cy,
+                     int32_t H, int32_t W, const float *depth, const float *xs, const float *ys, const float *zs,
+                     int32_t nx, int32_t ny, int32_t nz, float *workspace, uint8_t *voxel_mask, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

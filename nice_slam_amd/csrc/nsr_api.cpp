@@ -278,4 +278,30 @@ int nsr_get_samples(const int64_t *indices, int64_t n, int32_t H0, int32_t H1, i
     return finish("nsr_get_samples");
 }
 
+int64_t nsr_frustum_workspace_floats(int64_t n_voxels) {
+    return n_voxels < 0 ? -1 : n_voxels + (n_voxels + 255) / 256;
+}
+
+int nsr_frustum_mask(const float *w2c, const float *cam_center, double fx, double fy, double cx, double cy,
+                     int32_t H, int32_t W, const float *depth, const float *xs, const float *ys, const float *zs,
+                     int32_t nx, int32_t ny, int32_t nz, float *workspace, uint8_t *voxel_mask, void *stream) {
+    if (nx < 0 || ny < 0 || nz < 0 || H <= 0 || W <= 0) return fail("nsr_frustum_mask: bad shape");
+    const int64_t n_vox = (int64_t)nx * ny * nz;
+    if (n_vox == 0) return 0;
+    if (H > 32766 || W > 32766) return fail("nsr_frustum_mask: image larger than 32766 pixels per side");
+    if (!w2c || !cam_center || !depth || !xs || !ys || !zs || !workspace || !voxel_mask)
+        return fail("nsr_frustum_mask: null pointer");
+    nsr::FrustumParams P;
+    for (int i = 0; i < 12; ++i) P.w2c[i] = w2c[i];
+    for (int i = 0; i < 3; ++i) P.cam_o[i] = cam_center[i];
+    P.fx = fx; P.fy = fy; P.cx = cx; P.cy = cy; P.H = H; P.W = W;
+    P.depth = depth; P.xs = xs; P.ys = ys; P.zs = zs; P.nx = nx; P.ny = ny; P.nz = nz;
+    const int tb = 256;
+    P.nblocks = (int)((n_vox + tb - 1) / tb);
+    P.n_vox = n_vox; P.ws = workspace; P.mask = voxel_mask;
+    NSR_LAUNCH(nsr::frustum_mask_kernel<0>, dim3((unsigned)P.nblocks), dim3(tb), tb * sizeof(float), stream, P);
+    NSR_LAUNCH(nsr::frustum_mask_kernel<1>, dim3((unsigned)P.nblocks), dim3(tb), tb * sizeof(float), stream, P);
+    return finish("nsr_frustum_mask");
+}
+
 }  // extern "C"

@@ -23,6 +23,7 @@ NSR_DEV f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f
 NSR_DEV int tid() { return (int)threadIdx.x; }
 NSR_DEV int nthreads() { return (int)blockDim.x; }
 NSR_DEV int bid_x() { return (int)blockIdx.x; }
+NSR_DEV int f2i_rn(float x) { return __float2int_rn(x); }      // round half to even (cvRound)
 NSR_DEV int bid_y() { return (int)blockIdx.y; }
 NSR_DEV int nblk_x() { return (int)gridDim.x; }
 

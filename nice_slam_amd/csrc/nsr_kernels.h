@@ -1424,4 +1424,102 @@ NSR_KERNEL void get_samples_kernel(const SampleParams P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// frustum feature selection (Mapper.get_mask_from_c2w, Mapper.py:93-164): one thread per voxel of a
+// [Z][Y][X] grid.  phase 0: project the voxel centre, bilinear depth lookup (cv2.remap INTER_LINEAR semantics: 1/32-pixel
+// fixed-point coordinates, zero border), store it, block maximum -> ws[n_vox + block].  phase 1: max over the block
+// maxima (= np.max(depths), the fill value of zero-depth pixels, :147-148), depth test, near-camera sphere, mask byte.
+// HBM-trivial (one depth gather + 5 B per voxel); exists to keep the per-frame mask on the device and off cv2/numpy.
+// ------------------------------------------------------------------------------------------------
+struct FrustumParams {
+    float w2c[12];                 // rows 0..2 of inv(c2w), fp32 (Mapper.py:120)
+    float cam_o[3];                // c2w[:3,3]
+    double fx, fy, cx, cy;
+    int H, W;
+    const float *depth;            // [H][W]
+    const float *xs, *ys, *zs;     // voxel-centre coordinates per axis (torch.linspace over the bound, :111-113)
+    int nx, ny, nz, nblocks;
+    long long n_vox;
+    float *ws;                     // [n_vox] remapped depths | [nblocks] block maxima
+    unsigned char *mask;           // [Z][Y][X]
+};
+
+struct FrustumProj {
+    float u, v, px, py, pz;
+    double zc;                     // camera z + 1e-5 (:129)
+};
+
+NSR_DEV FrustumProj frustum_project(const FrustumParams &P, long long vox) {
+    FrustumProj R;
+    const int ix = (int)(vox % P.nx), iy = (int)((vox / P.nx) % P.ny), iz = (int)(vox / ((long long)P.nx * P.ny));
+    R.px = P.xs[ix]; R.py = P.ys[iy]; R.pz = P.zs[iz];
+    float cam[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)    // w2c @ [p,1] in fp32, sequential sum (oracle/frustum_oracle.py header)
+        cam[r] = ((P.w2c[r * 4 + 0] * R.px + P.w2c[r * 4 + 1] * R.py) + P.w2c[r * 4 + 2] * R.pz) + P.w2c[r * 4 + 3];
+    const double X = (double)(cam[0] * -1.f), Y = (double)cam[1], Z = (double)cam[2];
+    const double uh = (P.fx * X + 0.0 * Y) + P.cx * Z;      // K @ cam_cord, fp64 (:126-128)
+    const double vh = (0.0 * X + P.fy * Y) + P.cy * Z;
+    R.zc = Z + 1e-5;
+    R.u = (float)(uh / R.zc);
+    R.v = (float)(vh / R.zc);
+    return R;
+}
+
+NSR_DEV float frustum_pixel(const FrustumParams &P, int y, int x) {
+    return (y >= 0 && y < P.H && x >= 0 && x < P.W) ? P.depth[(long long)y * P.W + x] : 0.f;
+}
+
+NSR_DEV float frustum_remap(const FrustumParams &P, float u, float v) {
+    const float fu = u * 32.f, fv = v * 32.f;
+    if (!(fabsf(fu) < 1.0e9f) || !(fabsf(fv) < 1.0e9f)) return 0.f;      // far outside / NaN: every tap is border
+    const int sx = f2i_rn(fu), sy = f2i_rn(fv);
+    const int x0 = sx >> 5, y0 = sy >> 5;
+    const float ax = (float)(sx & 31) / 32.f, ay = (float)(sy & 31) / 32.f;
+    float out = frustum_pixel(P, y0, x0) * ((1.f - ay) * (1.f - ax));
+    out = out + frustum_pixel(P, y0, x0 + 1) * ((1.f - ay) * ax);
+    out = out + frustum_pixel(P, y0 + 1, x0) * (ay * (1.f - ax));
+    out = out + frustum_pixel(P, y0 + 1, x0 + 1) * (ay * ax);
+    return out;
+}
+
+template <int PHASE>
+NSR_KERNEL void frustum_mask_kernel(const FrustumParams P) {
+    float *red = reinterpret_cast<float *>(lds_base());
+    const long long vox = (long long)bid_x() * nthreads() + tid();
+    const bool live = vox < P.n_vox;
+    if (PHASE == 0) {
+        float d = -INFINITY;
+        if (live) {
+            const FrustumProj R = frustum_project(P, vox);
+            d = frustum_remap(P, R.u, R.v);
+            P.ws[vox] = d;
+        }
+        red[tid()] = d;
+        block_sync();
+        if (tid() == 0) {
+            float m = red[0];
+            for (int k = 1; k < nthreads(); ++k) m = fmaxf(m, red[k]);
+            P.ws[P.n_vox + bid_x()] = m;
+        }
+    } else {
+        float m = -INFINITY;
+        for (int k = tid(); k < P.nblocks; k += nthreads()) m = fmaxf(m, P.ws[P.n_vox + k]);
+        red[tid()] = m;
+        block_sync();
+        if (!live) return;
+        float dmax = red[0];
+        for (int k = 1; k < nthreads(); ++k) dmax = fmaxf(dmax, red[k]);
+        const FrustumProj R = frustum_project(P, vox);
+        float d = P.ws[vox];
+        if (d == 0.f) d = dmax;
+        bool in = (R.u < (float)P.W) && (R.u > 0.f) && (R.v < (float)P.H) && (R.v > 0.f);
+        const double zn = -R.zc;
+        in = in && (0.0 <= zn) && (zn <= (double)(d + 0.5f));
+        const float dx = R.px - P.cam_o[0], dy = R.py - P.cam_o[1], dz = R.pz - P.cam_o[2];
+        const float dist = (dx * dx + dy * dy) + dz * dz;
+        P.mask[vox] = (in || dist < 0.25f) ? 1 : 0;
+    }
+}
+
 }  // namespace nsr

@@ -168,3 +168,21 @@ def hip_render(sc, stage, device="cuda:0", backward=False, with_depth=True, rays
                 out["dparam/" + k] = p.grad
     torch.cuda.synchronize()
     return out
+
+
+def frustum_case(seed, H=68, W=120, shape=(9, 11, 13), zero_frac=0.05, bound=None):
+    """Synthetic frame for the frustum-mask tests: camera inside the volume with a random orientation, depth image with
+    smooth structure + noise + zero pixels.  Returns dict of numpy inputs (c2w fp32 4x4, depth fp32 HxW, intrinsics)."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.RandomState(seed)
+    bound = np.array([[-2.0, 2.4], [-1.6, 1.9], [-2.2, 2.1]]) if bound is None else np.asarray(bound, dtype=np.float64)
+    c2w = np.eye(4, dtype=np.float32)
+    c2w[:3, :3] = Rotation.from_rotvec(rng.randn(3) * 0.7).as_matrix().astype(np.float32)
+    ctr = bound.mean(1)
+    ext = bound[:, 1] - bound[:, 0]
+    c2w[:3, 3] = (ctr + (rng.rand(3) - 0.5) * 0.3 * ext).astype(np.float32)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    depth = (1.5 + 0.8 * np.sin(xx / W * 5.0) * np.cos(yy / H * 4.0) + 0.1 * rng.rand(H, W)).astype(np.float32)
+    depth[rng.rand(H, W) < zero_frac] = 0.0
+    f = 0.5 * W
+    return dict(c2w=c2w, depth=depth, H=H, W=W, fx=f, fy=f, cx=(W - 1) / 2.0, cy=(H - 1) / 2.0, bound=bound, shape=tuple(shape))

@@ -42,7 +42,12 @@ class OracleRenderer:
         return orc.render_batch_ray(c, decoders, rays_d, rays_o, stage, gt_depth, self.sc["bound"])
 
 
-def _worker(rank, world, port, stage, q):
+def _voxel_masks(sc, frac=0.4):
+    g = torch.Generator().manual_seed(77)
+    return {k: torch.rand(tuple(v.shape[2:]), generator=g) < frac for k, v in sc["grids"].items()}
+
+
+def _worker(rank, world, port, stage, q, masked=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -56,6 +61,8 @@ def _worker(rank, world, port, stage, q):
     o = sc["rays_o"].clone().requires_grad_(True)
     d = sc["rays_d"].clone().requires_grad_(True)
     rend = ShardedRenderer(OracleRenderer(sc))
+    if masked:
+        rend.set_voxel_masks(_voxel_masks(sc))
     depth, var, rgb = rend.render_batch_ray(grids, params, d, o, "cpu", stage, gt_depth=sc["gt_depth"])
     w = sc["w"]
     ((depth * w["depth"]).sum() + (var * w["var"]).sum() + (rgb * w["rgb"]).sum()).backward()
@@ -67,6 +74,7 @@ def _worker(rank, world, port, stage, q):
     out.update({"d_" + k: v.grad for k, v in grids.items() if v.grad is not None})
     out.update({"dparam/" + k: v.grad for k, v in params.items() if v.grad is not None})
     out["shard"] = torch.tensor(shard_range(23, world, rank))
+    out["exchange_floats"] = torch.tensor(rend.last_exchange_floats)
     q.put((rank, {k: v.detach().numpy().copy() for k, v in out.items()}))   # by value: the worker may exit first
     dist.barrier()
     dist.destroy_process_group()
@@ -90,6 +98,42 @@ def test_two_rank_sharding_matches_single_process(stage):
     for rank in (0, 1):
         for k, v in ref.items():
             assert rel_err(res[rank][k], v) < 2e-5, (rank, k)
+
+
+def test_two_rank_masked_gradient_exchange():
+    """With the frame's frustum masks set, only the selected voxel rows travel (one packed all-reduce); inside the masks
+    the gradients equal the single-process ones, outside they are left rank-local (nothing reads them)."""
+    from scene_util import make_scene, oracle_render, rel_err
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, "color", q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sc = make_scene(seed=5, n_rays=23, small=True)
+    ref = oracle_render(sc, "color", backward=True)
+    masks = _voxel_masks(sc)
+    used = [k for k in masks if "d_" + k in ref]
+    assert sorted(used) == ["grid_color", "grid_fine", "grid_middle"]
+    expect = sum(int(masks[k].sum()) * 32 for k in used)
+    dense = sum(sc["grids"][k].numel() for k in used)
+    for rank in (0, 1):
+        assert int(res[rank]["exchange_floats"]) == expect < 0.5 * dense
+        for k, v in ref.items():
+            if k.startswith("d_grid"):
+                m = masks[k[2:]].numpy()[None, None].repeat(32, 1)
+                assert rel_err(res[rank][k][m], v.numpy()[m] if hasattr(v, "numpy") else v[m]) < 2e-5, (rank, k)
+            else:
+                assert rel_err(res[rank][k], v) < 2e-5, (rank, k)
+    k = "d_grid_fine"                     # outside the mask: rank-local partial sums, which add up to the full gradient
+    m = ~masks["grid_fine"].numpy()[None, None].repeat(32, 1)
+    full = ref[k].numpy() if hasattr(ref[k], "numpy") else ref[k]
+    assert rel_err((res[0][k] + res[1][k])[m], full[m]) < 2e-5
+    assert rel_err(res[0][k][m], full[m]) > 1e-2
 
 
 def test_shard_range_partition():

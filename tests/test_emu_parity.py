@@ -195,3 +195,29 @@ def test_other_sample_counts(emu, ns, nsurf):
         assert rel_err(res["d_" + k], grids[k].grad) < TOL, k
     for k in ("color_decoder.pts_linears.3.weight", "color_decoder.embedder._B", "fine_decoder.fc_c.2.weight", "middle_decoder.pts_linears.0.bias"):
         assert rel_err(res["dparam/" + k], params[k].grad) < TOL, k
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_frustum_mask(emu, seed):
+    """nsr_frustum_mask (same kernel source, host-compiled) against the numpy restatement of
+    Mapper.get_mask_from_c2w (oracle/frustum_oracle.py; unpinned: cv2 is not installed).  Bit-exact masks."""
+    import ctypes as C
+    from emu_harness import ptr
+    from scene_util import frustum_case
+    from oracle import frustum_oracle as fo
+    fc = frustum_case(seed)
+    nz, ny, nx = fc["shape"]
+    ref = fo.get_mask_from_c2w(fc["c2w"], "grid_fine", fc["shape"], fc["depth"], fc["bound"], fc["H"], fc["W"],
+                               fc["fx"], fc["fy"], fc["cx"], fc["cy"])
+    assert ref.shape == (nx, ny, nz) and 0.02 < ref.mean() < 0.9
+    xs, ys, zs = fo.voxel_axes(fc["bound"], fc["shape"])
+    w2c = np.ascontiguousarray(np.linalg.inv(fc["c2w"])[:3].astype(np.float32))
+    o = np.ascontiguousarray(fc["c2w"][:3, 3])
+    n = nx * ny * nz
+    ws = np.zeros(emu.nsr_frustum_workspace_floats(n), dtype=np.float32)
+    out = np.full((nz, ny, nx), 7, dtype=np.uint8)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    emu.check(emu.nsr_frustum_mask(fp(w2c), fp(o), fc["fx"], fc["fy"], fc["cx"], fc["cy"], fc["H"], fc["W"], ptr(fc["depth"]),
+                                   ptr(xs), ptr(ys), ptr(zs), nx, ny, nz, ptr(ws), ptr(out), None))
+    assert set(np.unique(out)) <= {0, 1}
+    assert np.array_equal(out.astype(bool), ref.transpose(2, 1, 0))

@@ -1,0 +1,54 @@
+"""Frustum feature selection at Replica room0 scale: nsr_frustum_mask on the GPU vs the numpy restatement of
+Mapper.get_mask_from_c2w on the host (what the reference runs once per grid per optimize_map call).
+Run on the GPU box:  python tools/frustum_bench.py > gpurun_out/frustum.txt"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import nice_slam_amd as nsa
+    from scene_util import frustum_case
+    from oracle import frustum_oracle as fo
+    shapes = json.load(open(os.path.join(ROOT, "tests", "golden", "scene_shapes.json")))
+    for name in ("configs/Replica/room0.yaml", "configs/Apartment/apartment.yaml"):
+        r = shapes[name]
+        bound = np.array(r["bound"])
+        for key in ("grid_middle", "grid_fine"):
+            shape = tuple(r["shapes"][key])
+            fc = frustum_case(5, H=680, W=1200, shape=shape, bound=bound)
+            fc.update(fx=600.0, fy=600.0, cx=599.5, cy=339.5)
+            sel = nsa.FrustumSelector(bound, 680, 1200, 600.0, 600.0, 599.5, 339.5)
+            depth = torch.from_numpy(fc["depth"]).cuda()
+            for _ in range(3):
+                m = sel.voxel_mask(fc["c2w"], key, shape, depth)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 50
+            for _ in range(n):
+                m = sel.voxel_mask(fc["c2w"], key, shape, depth)
+            torch.cuda.synchronize()
+            t_gpu = (time.perf_counter() - t0) / n
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                m = sel.voxel_mask(fc["c2w"], key, shape, depth)
+            e1.record(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ref = fo.get_mask_from_c2w(fc["c2w"], key, shape, fc["depth"], bound, 680, 1200, 600.0, 600.0, 599.5, 339.5)
+            t_cpu = time.perf_counter() - t0
+            same = bool(np.array_equal(m.cpu().numpy().astype(bool), ref.transpose(2, 1, 0)))
+            print(f"{name.split('/')[1]:10s} {key:11s} {shape} voxels={np.prod(shape):7d} selected={ref.mean():.3f}  "
+                  f"nsr wall {t_gpu*1e6:7.1f} us/call (device {e0.elapsed_time(e1)/n*1e3:6.1f} us)  numpy restatement {t_cpu*1e3:7.1f} ms  equal={same}")
+
+
+if __name__ == "__main__":
+    main()
