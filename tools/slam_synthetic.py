@@ -1,0 +1,455 @@
+"""NICE-SLAM on a synthetic RGB-D sequence, end to end through the drop-in surface.
+
+There is no dataset and there are no pretrained decoders in this environment, so the only way to obtain
+a trajectory error is to generate a sequence: an analytic room (box + two cuboids, procedural texture) ray-cast along a
+smooth camera path gives depth / colour / ground-truth poses.  The tracker and the mapper below restate the reference's
+loops -- Tracker.run / optimize_cam_in_batch (src/Tracker.py:71-128,150-260) and Mapper.run / optimize_map /
+keyframe_selection_overlap (src/Mapper.py:166-228,230-545,547-657), strict synchronisation, single process -- on top of
+the product: get_samples, Renderer.render_batch_ray, NICE decoders, FrustumSelector and MaskedGridAdam.  The coarse-level
+mapper (a separate process in the reference, not read by the tracker's 'color' stage), meshing, visualisation and the
+final colour refinement are not part of this loop.  Decoders are random-init (the reference loads pretrained
+middle/fine decoders), so the absolute ATE is not comparable with published numbers; what it shows is that the hot path
+carries a complete tracking + mapping run.
+
+    python tools/slam_synthetic.py --frames 100            # on the GPU box; prints one JSON line
+
+``MiniSLAM`` takes an ``ops`` object so that tests/test_slam_synthetic.py can drive the same loop on the CPU with the
+oracle as the renderer (test infrastructure); ``ProductOps`` is the nice_slam_amd binding and has no CPU path.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+from ate import ate_rmse  # noqa: E402
+
+# nice_slam.yaml / Replica/replica.yaml values (mapping.stage, tracking, rendering)
+DEFAULT_CFG = {
+    "tracking": {"ignore_edge_W": 20, "ignore_edge_H": 20, "use_color_in_tracking": True, "handle_dynamic": True,
+                 "w_color_loss": 0.5, "const_speed_assumption": True, "lr": 0.001, "pixels": 200, "iters": 10},
+    "mapping": {"middle_iter_ratio": 0.4, "fine_iter_ratio": 0.6, "every_frame": 5, "BA": True, "BA_cam_lr": 0.001,
+                "keyframe_every": 50, "mapping_window_size": 5, "w_color_loss": 0.2, "lr_first_factor": 5, "lr_factor": 1,
+                "pixels": 1000, "iters_first": 1500, "iters": 60,
+                "stage": {"middle": {"decoders_lr": 0.0, "middle_lr": 0.1, "fine_lr": 0.0, "color_lr": 0.0},
+                          "fine": {"decoders_lr": 0.0, "middle_lr": 0.005, "fine_lr": 0.005, "color_lr": 0.0},
+                          "color": {"decoders_lr": 0.005, "middle_lr": 0.005, "fine_lr": 0.005, "color_lr": 0.005}}},
+}
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# camera parametrisation (src/common.py:137-201)
+# --------------------------------------------------------------------------------------------------------------------
+def quad2rotation(q: torch.Tensor) -> torch.Tensor:
+    qr, qi, qj, qk = q[0], q[1], q[2], q[3]
+    two_s = 2.0 / (q * q).sum()
+    return torch.stack([
+        torch.stack([1 - two_s * (qj ** 2 + qk ** 2), two_s * (qi * qj - qk * qr), two_s * (qi * qk + qj * qr)]),
+        torch.stack([two_s * (qi * qj + qk * qr), 1 - two_s * (qi ** 2 + qk ** 2), two_s * (qj * qk - qi * qr)]),
+        torch.stack([two_s * (qi * qk - qj * qr), two_s * (qj * qk + qi * qr), 1 - two_s * (qi ** 2 + qj ** 2)])])
+
+
+def get_camera_from_tensor(t: torch.Tensor) -> torch.Tensor:
+    """[quaternion (w,x,y,z), translation] -> 3x4 (common.py:163-176)."""
+    return torch.cat([quad2rotation(t[:4]), t[4:, None]], 1)
+
+
+def get_tensor_from_camera(c2w: torch.Tensor) -> torch.Tensor:
+    """3x4 / 4x4 -> [quaternion (w,x,y,z), translation] (common.py:179-201; mathutils replaced by scipy)."""
+    from scipy.spatial.transform import Rotation
+    m = c2w.detach().cpu().double().numpy()
+    x, y, z, w = Rotation.from_matrix(m[:3, :3]).as_quat()
+    return torch.tensor([w, x, y, z, m[0, 3], m[1, 3], m[2, 3]], dtype=torch.float32, device=c2w.device)
+
+
+def to44(c2w: torch.Tensor) -> torch.Tensor:
+    if c2w.shape[0] == 4:
+        return c2w
+    return torch.cat([c2w, torch.tensor([[0.0, 0.0, 0.0, 1.0]], dtype=c2w.dtype, device=c2w.device)], 0)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# synthetic sequence
+# --------------------------------------------------------------------------------------------------------------------
+class SyntheticSequence:
+    """Room = inside of an axis-aligned box, plus solid cuboids; camera convention of the reference
+    (common.py:82-88: dirs = ((i-cx)/fx, -(j-cy)/fy, -1), depth = z-depth = the ray parameter)."""
+
+    def __init__(self, n_frames=100, H=240, W=320, device="cpu", room=((-2.0, 2.0), (-1.4, 1.4), (-2.0, 2.0)),
+                 step_deg=0.9, seed=0):
+        self.n, self.H, self.W, self.device = n_frames, H, W, torch.device(device)
+        self.fx = self.fy = 0.5 * W
+        self.cx, self.cy = (W - 1) / 2.0, (H - 1) / 2.0
+        self.room = torch.tensor(room, dtype=torch.float32, device=self.device)
+        self.boxes = torch.tensor([[[-1.9, -1.0], [-1.4, -0.5], [0.6, 1.7]],
+                                   [[0.7, 1.6], [-1.4, -0.2], [-1.8, -0.9]],
+                                   [[-0.4, 0.5], [-1.4, -0.9], [-0.3, 0.4]]], dtype=torch.float32, device=self.device)
+        # scene bound handed to the SLAM system: the room with a margin (cfg['mapping']['bound'])
+        self.bound_cfg = [[lo - 0.3, hi + 0.3] for lo, hi in room]
+        rng = np.random.RandomState(seed)
+        self.freq = torch.tensor(rng.uniform(2.0, 4.5, (3, 3)), dtype=torch.float32, device=self.device)
+        self.phase = torch.tensor(rng.uniform(0, 6.28, (3,)), dtype=torch.float32, device=self.device)
+        self.poses = [self._pose(k, step_deg) for k in range(n_frames)]
+        ii, jj = torch.meshgrid(torch.arange(W, dtype=torch.float32, device=self.device),
+                                torch.arange(H, dtype=torch.float32, device=self.device), indexing="xy")
+        self.dirs = torch.stack([(ii - self.cx) / self.fx, -(jj - self.cy) / self.fy, -torch.ones_like(ii)], -1)   # (H,W,3)
+
+    def _pose(self, k, step_deg):
+        """Smooth path: the camera circles slowly around the room centre at radius 0.5 m, looking outwards-sideways,
+        with a gentle vertical bob; ~1.5 cm and `step_deg` degrees per frame."""
+        from scipy.spatial.transform import Rotation
+        a = np.deg2rad(step_deg) * k
+        pos = np.array([0.5 * np.cos(a), 0.15 * np.sin(2.3 * a), 0.5 * np.sin(a)])
+        R = Rotation.from_euler("yxz", [-(a + 0.9), 0.12 * np.sin(1.7 * a), 0.05 * np.sin(1.1 * a)]).as_matrix()
+        c2w = np.eye(4, dtype=np.float32)
+        c2w[:3, :3], c2w[:3, 3] = R, pos
+        return torch.tensor(c2w, device=self.device)
+
+    def _texture(self, p, nrm_axis):
+        base = 0.5 + 0.5 * torch.sin(p @ self.freq.T + self.phase)                       # smooth, position dependent
+        checker = ((torch.floor(p[..., 0] * 2.0) + torch.floor(p[..., 1] * 2.0) + torch.floor(p[..., 2] * 2.0)) % 2.0)
+        tint = torch.nn.functional.one_hot(nrm_axis, 3).float() * 0.25
+        return (0.75 * base + 0.15 * checker[..., None] + tint).clamp(0.0, 1.0)
+
+    def frame(self, k):
+        """(color (H,W,3) fp32, depth (H,W) fp32, c2w 4x4) of frame k."""
+        c2w = self.poses[k]
+        d = self.dirs @ c2w[:3, :3].T                               # (H,W,3), z-depth parametrisation (not normalised)
+        o = c2w[:3, 3]
+        inv = 1.0 / torch.where(d.abs() < 1e-9, torch.full_like(d, 1e-9), d)
+        # room: exit distance of a ray starting inside the box
+        t_hi = (torch.where(d > 0, self.room[:, 1], self.room[:, 0]) - o) * inv
+        t_room, ax_room = t_hi.min(-1)
+        depth, axis = t_room, ax_room
+        for b in self.boxes:                                        # solid cuboids: entry distance (slab test)
+            t0, t1 = (b[:, 0] - o) * inv, (b[:, 1] - o) * inv
+            tn, tf = torch.minimum(t0, t1), torch.maximum(t0, t1)
+            t_in, ax_in = tn.max(-1)
+            hit = (t_in < tf.min(-1)[0]) & (t_in > 0) & (t_in < depth)
+            depth = torch.where(hit, t_in, depth)
+            axis = torch.where(hit, ax_in, axis)
+        p = o + d * depth[..., None]
+        return self._texture(p, axis), depth.contiguous(), c2w
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# the product binding
+# --------------------------------------------------------------------------------------------------------------------
+class ProductOps:
+    """nice_slam_amd on an AMD GPU: channels-last grids, NICE decoders (random init), HIP renderer, fused grid Adam."""
+
+    def __init__(self, seq: SyntheticSequence, device, seed=0):
+        import types
+        import nice_slam_amd as nsa
+        from nice_slam_amd.common import set_decoder_bounds
+        self.nsa, self.device = nsa, torch.device(device)
+        cfg = {"scale": 1, "occupancy": True, "coarse": True, "mapping": {"bound": seq.bound_cfg},
+               "grid_len": {"coarse": 2.0, "middle": 0.32, "fine": 0.16, "color": 0.16, "bound_divisible": 0.32},
+               "model": {"c_dim": 32, "coarse_bound_enlarge": 2},
+               "rendering": {"lindisp": False, "perturb": 0.0, "N_samples": 32, "N_surface": 16, "N_importance": 0}}
+        torch.manual_seed(seed)
+        self.bound = nsa.load_bound(cfg)
+        self.H, self.W, self.fx, self.fy, self.cx, self.cy = seq.H, seq.W, seq.fx, seq.fy, seq.cx, seq.cy
+        slam = types.SimpleNamespace(nice=True, bound=self.bound, H=seq.H, W=seq.W, fx=seq.fx, fy=seq.fy, cx=seq.cx, cy=seq.cy)
+        self.renderer = nsa.Renderer(cfg, None, slam)
+        self.decoders = nsa.NICE(coarse=True).to(self.device)
+        set_decoder_bounds(self.decoders, self.bound, 2.0)
+        self.c = {k: v.to(self.device).requires_grad_(True) for k, v in nsa.grid_init(cfg, self.bound).items()}
+        self.selector = nsa.FrustumSelector(self.bound, seq.H, seq.W, seq.fx, seq.fy, seq.cx, seq.cy)
+        self.bound_dev = self.bound.to(self.device)
+
+    def get_samples(self, H0, H1, W0, W1, n, c2w, depth, color):
+        return self.nsa.get_samples(H0, H1, W0, W1, n, self.H, self.W, self.fx, self.fy, self.cx, self.cy, c2w, depth, color, self.device)
+
+    def render(self, stage, rays_d, rays_o, gt_depth):
+        return self.renderer.render_batch_ray(self.c, self.decoders, rays_d, rays_o, self.device, stage, gt_depth=gt_depth)
+
+    def color_decoder_params(self):
+        return list(self.decoders.color_decoder.parameters())
+
+    def all_decoder_params(self):
+        return list(self.decoders.parameters())
+
+    def frustum_masks(self, c2w, depth):
+        return {k: self.selector.voxel_mask(to44(c2w), k, v.shape[2:], depth) for k, v in self.c.items() if k != "grid_coarse"}
+
+    def grid_optimizer(self, masks):
+        keys = ("grid_middle", "grid_fine", "grid_color")
+        return self.nsa.MaskedGridAdam({k: self.c[k] for k in keys}, masks)
+
+    def zero_grads(self):
+        for g in self.c.values():
+            g.grad = None
+        for p in self.decoders.parameters():
+            p.grad = None
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# tracker + mapper
+# --------------------------------------------------------------------------------------------------------------------
+class MiniSLAM:
+    def __init__(self, ops, seq: SyntheticSequence, cfg=None, seed=0, verbose=False):
+        self.ops, self.seq, self.cfg, self.verbose = ops, seq, cfg or DEFAULT_CFG, verbose
+        self.device = ops.device
+        self.H, self.W = seq.H, seq.W
+        self.est = [None] * seq.n
+        self.gt = [None] * seq.n
+        self.keyframe_list, self.keyframe_dict = [], []
+        self.np_rng = np.random.RandomState(seed)
+        self.counters = {"tracking_iters": 0, "mapping_iters": 0, "tracking_rays": 0, "mapping_rays": 0}
+        self.timers = {"tracking_s": 0.0, "mapping_s": 0.0}
+
+    # -- shared: drop rays whose depth lies outside the bound (Tracker.py:95-104, Mapper.py:471-481)
+    def _inside(self, o, d, depth):
+        with torch.no_grad():
+            t = (self.ops.bound_dev.to(o.dtype)[None] - o.detach()[..., None]) / d.detach()[..., None]      # (N,3,2)
+            t = t.max(2)[0].min(1)[0]
+            return t >= depth
+
+    # -- Tracker.optimize_cam_in_batch (Tracker.py:71-128)
+    def _track_iter(self, cam, color, depth, opt):
+        tc = self.cfg["tracking"]
+        opt.zero_grad()
+        c2w = get_camera_from_tensor(cam)
+        He, We = tc["ignore_edge_H"], tc["ignore_edge_W"]
+        o, d, gd, gc = self.ops.get_samples(He, self.H - He, We, self.W - We, tc["pixels"], c2w, depth, color)
+        m = self._inside(o, d, gd)
+        o, d, gd, gc = o[m], d[m], gd[m], gc[m]
+        self.ops.zero_grads()
+        dep, unc, col = self.ops.render("color", d, o, gd)
+        unc = unc.detach()
+        if tc["handle_dynamic"]:
+            tmp = torch.abs(gd - dep) / torch.sqrt(unc + 1e-10)
+            mask = (tmp < 10 * tmp.median()) & (gd > 0)
+        else:
+            mask = gd > 0
+        loss = (torch.abs(gd - dep) / torch.sqrt(unc + 1e-10))[mask].sum()
+        if tc["use_color_in_tracking"]:
+            loss = loss + tc["w_color_loss"] * torch.abs(gc - col)[mask].sum()
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        self.counters["tracking_iters"] += 1
+        self.counters["tracking_rays"] += int(o.shape[0])
+        return float(loss.item())
+
+    # -- Tracker.run, one frame (Tracker.py:176-256)
+    def track(self, idx, color, depth):
+        tc = self.cfg["tracking"]
+        pre = self.est[idx - 1].to(self.device).float()
+        if tc["const_speed_assumption"] and idx - 2 >= 0:
+            delta = pre @ self.est[idx - 2].to(self.device).float().inverse()
+            init = delta @ pre
+        else:
+            init = pre
+        cam = get_tensor_from_camera(init.detach()).to(self.device).requires_grad_(True)
+        opt = torch.optim.Adam([cam], lr=tc["lr"])
+        best, best_loss = cam.clone().detach(), 1e10          # iters == 0: the motion-model prediction alone
+        for _ in range(tc["iters"]):
+            loss = self._track_iter(cam, color, depth, opt)
+            if loss < best_loss:
+                best_loss, best = loss, cam.clone().detach()
+        return to44(get_camera_from_tensor(best)), init
+
+    # -- Mapper.keyframe_selection_overlap (Mapper.py:166-228)
+    def _select_keyframes(self, color, depth, c2w, keyframes, k, n_samples=16, pixels=100):
+        o, d, gd, _ = self.ops.get_samples(0, self.H, 0, self.W, pixels, c2w, depth, color)
+        gd = gd.reshape(-1, 1).repeat(1, n_samples)
+        tv = torch.linspace(0.0, 1.0, n_samples, device=self.device)
+        z = gd * 0.8 * (1.0 - tv) + (gd + 0.5) * tv
+        pts = (o[:, None, :] + d[:, None, :] * z[..., None]).reshape(-1, 3).detach()
+        K = torch.tensor([[self.seq.fx, 0.0, self.seq.cx], [0.0, self.seq.fy, self.seq.cy], [0.0, 0.0, 1.0]], device=self.device)
+        out = []
+        for kid, kf in enumerate(keyframes):
+            w2c = torch.inverse(to44(kf["est_c2w"].to(self.device).float()))
+            cam = pts @ w2c[:3, :3].T + w2c[:3, 3]
+            cam = cam * torch.tensor([-1.0, 1.0, 1.0], device=self.device)
+            uv = cam @ K.T
+            zc = uv[:, 2:] + 1e-5
+            uv = uv[:, :2] / zc
+            edge = 20
+            m = (uv[:, 0] < self.W - edge) & (uv[:, 0] > edge) & (uv[:, 1] < self.H - edge) & (uv[:, 1] > edge) & (zc[:, 0] < 0)
+            out.append((kid, float(m.float().mean())))
+        out.sort(key=lambda t: t[1], reverse=True)
+        sel = [kid for kid, pct in out if pct > 0.0]
+        return [int(v) for v in self.np_rng.permutation(np.array(sel, dtype=np.int64))[:k]]
+
+    # -- Mapper.optimize_map (Mapper.py:230-545)
+    def optimize_map(self, n_iters, lr_factor, idx, color, depth, cur_c2w):
+        mc = self.cfg["mapping"]
+        ops = self.ops
+        if len(self.keyframe_dict) == 0:
+            frames = []
+        else:
+            frames = self._select_keyframes(color, depth, cur_c2w, self.keyframe_dict[:-1], mc["mapping_window_size"] - 2)
+        oldest = None
+        if len(self.keyframe_list) > 0:
+            frames = frames + [len(self.keyframe_list) - 1]
+            oldest = min(frames)
+        frames = frames + [-1]
+        pix = mc["pixels"] // len(frames)
+        BA = len(self.keyframe_list) > 4 and mc["BA"]
+
+        masks = ops.frustum_masks(cur_c2w, depth)                        # Mapper.py:315-318, once per call
+        opt_grid = ops.grid_optimizer(masks)
+        dec_params = ops.color_decoder_params()
+        groups = [{"params": dec_params, "lr": 0.0}]
+        cams = []
+        if BA:
+            for f in frames:
+                if f != oldest:
+                    c2w = self.keyframe_dict[f]["est_c2w"] if f != -1 else cur_c2w
+                    cams.append(get_tensor_from_camera(c2w.to(self.device)).requires_grad_(True))
+            groups.append({"params": cams, "lr": 0.0})
+        opt = torch.optim.Adam(groups)
+
+        for it in range(n_iters):
+            if it <= int(n_iters * mc["middle_iter_ratio"]):
+                stage = "middle"
+            elif it <= int(n_iters * mc["fine_iter_ratio"]):
+                stage = "fine"
+            else:
+                stage = "color"
+            st = mc["stage"][stage]
+            opt.param_groups[0]["lr"] = st["decoders_lr"] * lr_factor
+            if BA and stage == "color":
+                opt.param_groups[1]["lr"] = mc["BA_cam_lr"]
+            opt.zero_grad()
+            ops.zero_grads()
+            ro, rd, gds, gcs = [], [], [], []
+            cam_id = 0
+            for f in frames:
+                if f != -1:
+                    kf = self.keyframe_dict[f]
+                    f_depth, f_color = kf["depth"].to(self.device), kf["color"].to(self.device)
+                    if BA and f != oldest:
+                        c2w = get_camera_from_tensor(cams[cam_id]); cam_id += 1
+                    else:
+                        c2w = kf["est_c2w"].to(self.device)
+                else:
+                    f_depth, f_color = depth, color
+                    c2w = get_camera_from_tensor(cams[cam_id]) if BA else cur_c2w
+                o, d, gd, gc = ops.get_samples(0, self.H, 0, self.W, pix, c2w, f_depth, f_color)
+                ro.append(o.float()); rd.append(d.float()); gds.append(gd.float()); gcs.append(gc.float())
+            o, d, gd, gc = torch.cat(ro), torch.cat(rd), torch.cat(gds), torch.cat(gcs)
+            m = self._inside(o, d, gd)
+            o, d, gd, gc = o[m], d[m], gd[m], gc[m]
+            dep, _, col = ops.render(stage, d, o, gd)
+            dm = gd > 0
+            loss = torch.abs(gd[dm] - dep[dm]).sum()
+            if stage == "color":
+                loss = loss + mc["w_color_loss"] * torch.abs(gc - col).sum()
+            loss.backward()
+            opt.step()
+            opt_grid.step({"grid_middle": st["middle_lr"] * lr_factor, "grid_fine": st["fine_lr"] * lr_factor,
+                           "grid_color": st["color_lr"] * lr_factor})
+            self.counters["mapping_iters"] += 1
+            self.counters["mapping_rays"] += int(o.shape[0])
+        self.last_map_loss = float(loss.item())
+
+        if BA:                                                             # Mapper.py:527-541
+            cam_id = 0
+            for f in frames:
+                if f != -1:
+                    if f != oldest:
+                        self.keyframe_dict[f]["est_c2w"] = to44(get_camera_from_tensor(cams[cam_id].detach())).clone()
+                        cam_id += 1
+                else:
+                    cur_c2w = to44(get_camera_from_tensor(cams[-1].detach())).clone()
+            return cur_c2w
+        return None
+
+    # -- Tracker.run + Mapper.run, strict synchronisation (Tracker.py:150-260, Mapper.py:547-657)
+    def run(self):
+        mc = self.cfg["mapping"]
+        n = self.seq.n
+        for idx in range(n):
+            color, depth, gt_c2w = self.seq.frame(idx)
+            color, depth, gt_c2w = color.to(self.device), depth.to(self.device), gt_c2w.to(self.device)
+            self.gt[idx] = gt_c2w.cpu()
+            if self.device.type == "cuda":
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if idx == 0:
+                self.est[0] = gt_c2w.clone()
+            else:
+                c2w, _ = self.track(idx, color, depth)
+                self.est[idx] = c2w.detach()
+            if self.device.type == "cuda":
+                torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            self.timers["tracking_s"] += t1 - t0
+            if idx % mc["every_frame"] == 0 or idx == n - 1:
+                first = idx == 0
+                cur = self.est[idx].to(self.device)
+                new = self.optimize_map(mc["iters_first"] if first else mc["iters"],
+                                        mc["lr_first_factor"] if first else mc["lr_factor"], idx, color, depth, cur)
+                if new is not None:
+                    self.est[idx] = new.detach()
+                if (idx % mc["keyframe_every"] == 0 or idx == n - 2) and idx not in self.keyframe_list:
+                    self.keyframe_list.append(idx)
+                    self.keyframe_dict.append({"idx": idx, "color": color, "depth": depth, "gt_c2w": gt_c2w.cpu(),
+                                               "est_c2w": self.est[idx].clone()})
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize()
+                self.timers["mapping_s"] += time.perf_counter() - t1
+                if self.verbose:
+                    e = float((self.est[idx][:3, 3].cpu() - self.gt[idx][:3, 3]).norm())
+                    print(f"[map] frame {idx:4d} loss {self.last_map_loss:9.3f} pose err {e*100:6.2f} cm", file=sys.stderr)
+        return self.result()
+
+    def result(self):
+        est = [e.detach().cpu().numpy() for e in self.est]
+        gt = [g.numpy() for g in self.gt]
+        res = {"ate": ate_rmse(est, gt)}
+        # reference point: the same sequence with tracking replaced by the constant-speed extrapolation alone
+        res["raw_translation_error_cm"] = {"final": float(np.linalg.norm(est[-1][:3, 3] - gt[-1][:3, 3]) * 100),
+                                           "mean": float(np.mean([np.linalg.norm(a[:3, 3] - b[:3, 3]) for a, b in zip(est, gt)]) * 100)}
+        res["path_length_m"] = float(sum(np.linalg.norm(gt[i + 1][:3, 3] - gt[i][:3, 3]) for i in range(len(gt) - 1)))
+        res.update(self.counters)
+        res.update({k: round(v, 3) for k, v in self.timers.items()})
+        return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=100)
+    ap.add_argument("--height", type=int, default=240)
+    ap.add_argument("--width", type=int, default=320)
+    ap.add_argument("--iters-first", type=int, default=DEFAULT_CFG["mapping"]["iters_first"])
+    ap.add_argument("--keyframe-every", type=int, default=10, help="reference: 50 (Replica sequences have 2000 frames)")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    import copy
+    cfg = copy.deepcopy(DEFAULT_CFG)
+    cfg["mapping"]["iters_first"] = args.iters_first
+    cfg["mapping"]["keyframe_every"] = args.keyframe_every
+    torch.manual_seed(args.seed)
+    seq = SyntheticSequence(args.frames, args.height, args.width, device=dev, seed=args.seed)
+    ops = ProductOps(seq, dev, seed=args.seed)
+    slam = MiniSLAM(ops, seq, cfg, seed=args.seed, verbose=args.verbose)
+    t0 = time.perf_counter()
+    res = slam.run()
+    torch.cuda.synchronize()
+    res["wall_s"] = round(time.perf_counter() - t0, 2)
+    res["config"] = {"frames": args.frames, "image": [args.height, args.width], "keyframe_every": args.keyframe_every,
+                     "iters_first": args.iters_first, "decoders": "random init (no pretrained weights in this environment)",
+                     "grids": {k: list(v.shape[2:]) for k, v in ops.c.items()}}
+    res["metric"] = "ATE RMSE [cm] on a synthetic RGB-D sequence"
+    res["value"] = res["ate"]["rmse"] * 100
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
