@@ -208,14 +208,21 @@ int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream
     if (any_params) {
         const int first = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE;
         const int last = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : P.stage;
+        nsr::ReduceParams R;
+        R.nblocks = nblk; R.stride = P.partial_stride;
+        int rows = 0, nmax = 0;
         for (int s = first; s <= last; ++s) {
             if (!P.dec[s].dparams) continue;
             const int pass = P.stage == NSR_STAGE_COARSE ? 0 : s - NSR_MIDDLE;
-            const int n = nsr::param_total(s), tb = 1024;        // 64 parameters x 16 slices of the partial list
-            NSR_LAUNCH(nsr::reduce_partials_kernel, dim3((n + 63) / 64), dim3(tb), tb * 4, stream,
-                       (const float *)(P.partials + (long long)pass * nblk * P.partial_stride), nblk, P.partial_stride, n,
-                       P.dec[s].dparams);
+            R.job[rows].partials = P.partials + (long long)pass * nblk * P.partial_stride;
+            R.job[rows].dparams = P.dec[s].dparams;
+            R.job[rows].n = nsr::param_total(s);
+            nmax = nmax > R.job[rows].n ? nmax : R.job[rows].n;
+            ++rows;
         }
+        for (int r = rows; r < 3; ++r) R.job[r] = nsr::ReduceJob{nullptr, nullptr, 0};
+        const int tb = 1024;                                      // 64 parameters x 16 slices of the partial list
+        NSR_LAUNCH(nsr::reduce_partials_kernel, dim3((nmax + 63) / 64, rows), dim3(tb), tb * 4, stream, R);
         if (int rc = finish("nsr_render_bwd(reduce)")) return rc;
     }
     return 0;

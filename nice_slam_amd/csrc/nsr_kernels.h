@@ -453,20 +453,26 @@ NSR_DEV float sin_acc(float x);
 constexpr int kStP = 0, kStDO = 64, kStA0 = 128, kStA1 = 128 + 512, kStX0 = 128 + 1024, kStC = 128 + 1536;
 constexpr int stg_floats(int kind) { return 128 + 512 * (3 + cdim_of(kind) / 32); }
 
+// Tile layout "channel rows": 32 rows (channels) x 16 floats (points), 512 floats.  Channel ch = 16T + 4g + r lives in
+// row rho = 16T + 4r + g (g and r swapped, so that the four lane groups g of one store instruction hit four different
+// bank quarters); inside a row the four 4-point groups are XOR-permuted by (ch & 3) (so that the 16 lanes of one b128
+// operand read cover all 64 banks).  Stores: 8 conflict-free ds_write_b32 per tile; operand reads: ONE conflict-free
+// ds_read_b128 per (tile, 16-channel k-tile) = the MFMA operand of 4 k-steps, k-step q <-> point 4g + q.
+NSR_DEV int st_row(int ch) { return (ch & ~15) + ((ch & 3) << 2) + ((ch >> 2) & 3); }
 NSR_DEV void st_store(float *T, const Act<2> &v, int pt, int g) {
-    const int sw = (pt & 1) << 4;
-    st4(T + pt * 32 + ((4 * g) ^ sw), to_F4(v.t[0]));
-    st4(T + pt * 32 + ((16 + 4 * g) ^ sw), to_F4(v.t[1]));
-}
-// element s = T[4s+g][16*Tt + i]: MFMA operand "lane = channel i of k-tile Tt, k = point 4s+g"
-NSR_DEV f32x4 st_load_cm(const float *T, int Tt, int i, int g) {
-    f32x4 r;
-    const int sw = (g & 1) << 4;
+    float *B = T + g * 16 + (pt & 3);
+    const int pg = pt >> 2;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) r[s] = T[(4 * s + g) * 32 + ((16 * Tt + i) ^ sw)];
-    return r;
+    for (int Tt = 0; Tt < 2; ++Tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) B[(16 * Tt + 4 * r) * 16 + ((pg ^ r) << 2)] = v.t[Tt][r];
 }
-NSR_DEV float st_at(const float *T, int p, int ch) { return T[p * 32 + (ch ^ ((p & 1) << 4))]; }
+// element q = T[point 4g+q][channel 16*Tt + i]: MFMA operand "lane = channel i of k-tile Tt, k-step q = point 4g+q"
+NSR_DEV f32x4 st_load_cm(const float *T, int Tt, int i, int g) {
+    return to_v(ld4(T + st_row(16 * Tt + i) * 16 + ((g ^ (i & 3)) << 2)));
+}
+// points 4*grp .. 4*grp+3 of one channel
+NSR_DEV F4 st_row4(const float *T, int ch, int grp) { return ld4(T + st_row(ch) * 16 + ((grp ^ (ch & 3)) << 2)); }
 
 struct Own {
     Stream img;          // this block's image of the flat parameter-gradient blob (global partial buffer, L2 resident);
@@ -487,6 +493,19 @@ template <int XSRC>
 NSR_DEV void own_pair(const Own &O, const Mat m, int Tk, int a_off, int x_off, int x_sub, const float *aux) {
     const int i = O.lane & 15, g = O.lane >> 4;
     f32x4 d0 = f4zero(), d1 = f4zero();
+    // the image values this task accumulates into (later ray groups of the block): requested now, consumed after the
+    // MFMA chain, so the L2 round trip hides behind it
+    const int k = 16 * Tk + i;
+    const bool live = k < m.kcols;
+    const int lo = 4 * g * m.stride + i;
+    const int co = m.off + m.kbeg + 16 * Tk;
+    if (!O.first && live) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            d0[r] = stream_ld(O.img, lo, co + r * m.stride);
+            d1[r] = stream_ld(O.img, lo, co + (16 + r) * m.stride);
+        }
+    }
     F4 b = F4{0.f, 0.f, 0.f, 0.f};
     if (XSRC == 2) b = ld4(aux + AUX_BM + (16 * Tk + i) * 4);
     // software pipeline over the block's tiles: the LDS reads (and, for the embedding, the sines) of tile t+1 are
@@ -496,7 +515,7 @@ NSR_DEV void own_pair(const Own &O, const Mat m, int Tk, int a_off, int x_off, i
     if (XSRC == 2) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const F4 pp = ld4(S + kStP + (4 * q + g) * 4);
+            const F4 pp = ld4(S + kStP + (4 * g + q) * 4);
             x[q] = sin_acc(fmaf(pp.z, b.z, fmaf(pp.y, b.y, pp.x * b.x)));
         }
     } else {
@@ -509,7 +528,7 @@ NSR_DEV void own_pair(const Own &O, const Mat m, int Tk, int a_off, int x_off, i
         F4 pp[4];
         if (XSRC == 2) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pp[q] = ld4(Sn + kStP + (4 * q + g) * 4);
+            for (int q = 0; q < 4; ++q) pp[q] = ld4(Sn + kStP + (4 * g + q) * 4);
         } else {
             nx = st_load_cm(Sn + x_off, x_sub, i, g);
         }
@@ -524,13 +543,68 @@ NSR_DEV void own_pair(const Own &O, const Mat m, int Tk, int a_off, int x_off, i
         }
         a0 = na0; a1 = na1; x = nx;
     }
-    const int k = 16 * Tk + i;
-    if (k < m.kcols) {
-        const int lo = 4 * g * m.stride + i;
+    if (live) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            img_add(O, lo, m.off + m.kbeg + 16 * Tk + r * m.stride, d0[r]);
-            img_add(O, lo, m.off + m.kbeg + 16 * Tk + (16 + r) * m.stride, d1[r]);
+            stream_st(O.img, lo, co + r * m.stride, d0[r]);
+            stream_st(O.img, lo, co + (16 + r) * m.stride, d1[r]);
+        }
+    }
+}
+// The two weight blocks that read the Fourier embedding, W0 (layer 0) and W3e (embedding columns of layer 3), in one
+// task: the 16 embedding channels of k-tile Tk are recomputed ONCE per tile (decoder.py:26-30) and contracted with
+// dY0 (staged at a0_off) and dY3 (staged at a3_off):   img[W0 / W3e slice, k-tile Tk] += sum over tiles of dY^T E
+NSR_DEV void own_embed_pair(const Own &O, const Mat m0, const Mat m3, int Tk, int a0_off, int a3_off, const float *aux) {
+    const int i = O.lane & 15, g = O.lane >> 4;
+    f32x4 d00 = f4zero(), d01 = f4zero(), d30 = f4zero(), d31 = f4zero();
+    const int k = 16 * Tk + i;
+    const bool live = k < m0.kcols;
+    const int lo0 = 4 * g * m0.stride + i, lo3 = 4 * g * m3.stride + i;
+    const int co0 = m0.off + m0.kbeg + 16 * Tk, co3 = m3.off + m3.kbeg + 16 * Tk;
+    if (!O.first && live) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            d00[r] = stream_ld(O.img, lo0, co0 + r * m0.stride);
+            d01[r] = stream_ld(O.img, lo0, co0 + (16 + r) * m0.stride);
+            d30[r] = stream_ld(O.img, lo3, co3 + r * m3.stride);
+            d31[r] = stream_ld(O.img, lo3, co3 + (16 + r) * m3.stride);
+        }
+    }
+    const F4 b = ld4(aux + AUX_BM + (16 * Tk + i) * 4);
+    const float *S = O.stg;
+    f32x4 p0 = st_load_cm(S + a0_off, 0, i, g), p1 = st_load_cm(S + a0_off, 1, i, g);
+    f32x4 q0 = st_load_cm(S + a3_off, 0, i, g), q1 = st_load_cm(S + a3_off, 1, i, g), x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const F4 pp = ld4(S + kStP + (4 * g + q) * 4);
+        x[q] = sin_acc(fmaf(pp.z, b.z, fmaf(pp.y, b.y, pp.x * b.x)));
+    }
+    for (int t = 0; t < O.nw; ++t) {
+        const float *Sn = O.stg + (t + 1 < O.nw ? t + 1 : t) * O.stride;
+        const f32x4 np0 = st_load_cm(Sn + a0_off, 0, i, g), np1 = st_load_cm(Sn + a0_off, 1, i, g);
+        const f32x4 nq0 = st_load_cm(Sn + a3_off, 0, i, g), nq1 = st_load_cm(Sn + a3_off, 1, i, g);
+        F4 pp[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pp[q] = ld4(Sn + kStP + (4 * g + q) * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            d00 = mfma16(p0[q], x[q], d00);
+            d01 = mfma16(p1[q], x[q], d01);
+            d30 = mfma16(q0[q], x[q], d30);
+            d31 = mfma16(q1[q], x[q], d31);
+        }
+        f32x4 nx;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nx[q] = sin_acc(fmaf(pp[q].z, b.z, fmaf(pp[q].y, b.y, pp[q].x * b.x)));
+        p0 = np0; p1 = np1; q0 = nq0; q1 = nq1; x = nx;
+    }
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            stream_st(O.img, lo0, co0 + r * m0.stride, d00[r]);
+            stream_st(O.img, lo0, co0 + (16 + r) * m0.stride, d01[r]);
+            stream_st(O.img, lo3, co3 + r * m3.stride, d30[r]);
+            stream_st(O.img, lo3, co3 + (16 + r) * m3.stride, d31[r]);
         }
     }
 }
@@ -540,8 +614,8 @@ NSR_DEV void own_colsum(const Own &O, int off, int a_off) {
     float s = 0.f;
     for (int t = 0; t < O.nw; ++t) {
         const float *T = O.stg + t * O.stride + a_off;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s += st_at(T, half * 8 + q, ch);
+        const F4 u = st_row4(T, ch, 2 * half), v = st_row4(T, ch, 2 * half + 1);      // points 8*half .. 8*half+7
+        s += u.x; s += u.y; s += u.z; s += u.w; s += v.x; s += v.y; s += v.z; s += v.w;
     }
     s += shfl_xor(s, 32);
     if (half == 0) img_add(O, ch, off, s);
@@ -554,11 +628,13 @@ template <int NOUT>
 NSR_DEV void out_layer_local(const Own &O, const float *S) {
     const int ch = O.lane & 31, half = O.lane >> 5;
     float s[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+    const F4 h0 = st_row4(S + kStX0, ch, 2 * half), h1 = st_row4(S + kStX0, ch, 2 * half + 1);
+    const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int p = half * 8 + q;
         const F4 d = ld4(S + kStDO + p * 4);
-        const float h = st_at(S + kStX0, p, ch);
+        const float h = hv[q];
         s[0] = fmaf(d.x, h, s[0]); sb[0] += d.x;
         if (NOUT > 1) { s[1] = fmaf(d.y, h, s[1]); s[2] = fmaf(d.z, h, s[2]); s[3] = fmaf(d.w, h, s[3]); sb[1] += d.y; sb[2] += d.z; sb[3] += d.w; }
     }
@@ -929,7 +1005,7 @@ NSR_KERNEL NSR_BOUNDS(768) void eval_points_kernel(const RenderParams P) {
 struct BwdFlags { bool grid, params, rays; };
 
 // running index of the first (matrix, k-tile) pair of layer I in the owner round-robin (layers are visited 4..0)
-constexpr int xyz_pairs(int cd, int I) { return cd / 16 + (I > 0 ? 2 : 0) + ((I == 0 || I == 3) ? kET : 0); }
+constexpr int xyz_pairs(int cd, int I) { return cd / 16 + (I > 0 ? 2 : 0) + (I == 0 ? kET : 0); }
 constexpr int xyz_pair_base(int cd, int I) {
     int n = 0;
     for (int j = 4; j > I; --j) n += xyz_pairs(cd, j);
@@ -966,6 +1042,7 @@ struct XyzBwd {
         if (F.params) {
             st_store(S + kStA1, dY, i16, g);
             if (I > 0) st_store(S + kStX0, K.h[I > 0 ? I - 1 : 0], i16, g);
+            else st_store(S + kStX0, dY3, i16, g);                           // layer 0: the W0 / W3e task needs dY3 too
             block_sync();
             int P = xyz_pair_base(CD, I);
 #pragma unroll
@@ -976,10 +1053,10 @@ struct XyzBwd {
                 for (int Tk = 0; Tk < 2; ++Tk, ++P)
                     if (P % O.nw == O.wave) own_pair<0>(O, xyz_mat(CD, hid), Tk, kStA1, kStX0, Tk, aux);
             }
-            if (I == 0 || I == 3) {
+            if (I == 0) {
 #pragma unroll
                 for (int Tk = 0; Tk < kET; ++Tk, ++P)
-                    if (P % O.nw == O.wave) own_pair<2>(O, xyz_mat(CD, I == 0 ? XW0 : XW3E), Tk, kStA1, 0, 0, aux);
+                    if (P % O.nw == O.wave) own_embed_pair(O, xyz_mat(CD, XW0), xyz_mat(CD, XW3E), Tk, kStA1, kStX0, aux);
             }
             if ((2 * (4 - I)) % O.nw == O.wave) own_colsum(O, fcb_off(KIND, I), kStA0);
             if ((2 * (4 - I) + 1) % O.nw == O.wave) own_colsum(O, bias_off(KIND, I), kStA1);
@@ -1337,20 +1414,32 @@ NSR_KERNEL NSR_BOUNDS(64 * NSR_BWD_TILES) void render_bwd_kernel(const RenderPar
     }
 }
 
-// sum the per-block partial parameter gradients:  dparams[t] += sum_b partials[b][t]
-// block = 64 parameters x (blockDim/64) slices of the partial list (coalesced 256-byte rows, split serial sum)
-NSR_KERNEL void reduce_partials_kernel(const float *__restrict__ partials, int nblocks, int stride, int n, float *__restrict__ dparams) {
+// sum the per-block partial parameter gradients:  dparams[t] += sum_b partials[b][t], one grid row (blockIdx.y) per
+// decoder pass of the stage.  block = 64 parameters x (blockDim/64) slices of the partial list (coalesced 256-byte
+// rows, split serial sum)
+struct ReduceJob {
+    const float *partials;   // [nblocks][stride] of this pass
+    float *dparams;          // flat gradient blob of the decoder (accumulated into)
+    int n;                   // its parameter count (0: nothing to do for this row)
+};
+struct ReduceParams {
+    ReduceJob job[3];
+    int nblocks, stride;
+};
+NSR_KERNEL void reduce_partials_kernel(const ReduceParams R) {
+    const ReduceJob J = R.job[bid_y()];
     float *red = reinterpret_cast<float *>(lds_base());
     const int lane = tid() & 63, slice = tid() >> 6, nslice = nthreads() >> 6;
     const int t = bid_x() * 64 + lane;
+    if (bid_x() * 64 >= J.n) return;                     // whole block beyond this decoder's blob (uniform)
     float s = 0.f;
-    if (t < n)
-        for (int b = slice; b < nblocks; b += nslice) s += partials[(long long)b * stride + t];
+    if (t < J.n)
+        for (int b = slice; b < R.nblocks; b += nslice) s += J.partials[(long long)b * R.stride + t];
     red[tid()] = s;
     block_sync();
-    if (slice == 0 && t < n) {
+    if (slice == 0 && t < J.n) {
         for (int k = 1; k < nslice; ++k) s += red[k * 64 + lane];
-        dparams[t] += s;
+        J.dparams[t] += s;
     }
 }
 

@@ -151,33 +151,42 @@ class _RenderFn(torch.autograd.Function):
         g_var = g_var.to(torch.float64).contiguous()
         g_rgb = g_rgb.to(torch.float32).contiguous()
         b.d_depth, b.d_var, b.d_rgb, b.depth = g_depth.data_ptr(), g_var.data_ptr(), g_rgb.data_ptr(), depth.data_ptr()
-        d_o = d_d = None
-        if need_o or need_d:
-            d_od = torch.zeros((2, n, 3), dtype=torch.float32, device=dev)
-            d_o, d_d = d_od[0], d_od[1]
-            b.d_rays_o, b.d_rays_d = d_o.data_ptr(), d_d.data_ptr()
+        # every gradient this call produces lives in ONE zero-filled buffer (a single fill kernel): channels-last views for
+        # the dense grid gradients, then the ray gradients, then the flat decoder-gradient blob
+        need_ray = need_o or need_d
+        n_grid = [grids[s].numel() if need else 0 for s, need in zip(slots, need_grid)]
+        n_par = [param_count(s) if need else 0 for s, need in zip(slots, need_par)]
+        buf = torch.zeros((sum(n_grid) + (6 * n if need_ray else 0) + sum(n_par),), dtype=torch.float32, device=dev)
+        off = 0
         d_grids = []
-        for s, need in zip(slots, need_grid):
+        for s, cnt in zip(slots, n_grid):
             i = _SLOT_IDX[s]
-            if need:
-                dg = torch.zeros_like(grids[s], memory_format=torch.preserve_format)
+            if cnt:
+                _, ch, Z, Y, X = grids[s].shape
+                dg = buf[off:off + cnt].view(1, Z, Y, X, ch).permute(0, 4, 1, 2, 3)      # [1,C,Z,Y,X], channels-last strides
+                off += cnt
                 a.grid[i].dfeat = dg.data_ptr()
                 d_grids.append(dg)
             else:
                 a.grid[i].dfeat = None
                 d_grids.append(None)
+        d_o = d_d = None
+        if need_ray:
+            d_od = buf[off:off + 6 * n].view(2, n, 3)
+            off += 6 * n
+            d_o, d_d = d_od[0], d_od[1]
+            b.d_rays_o, b.d_rays_d = d_o.data_ptr(), d_d.data_ptr()
         gflat = None
         offs = {}
         if any(need_par):
-            total = sum(param_count(s) for s, need in zip(slots, need_par) if need)
-            gflat = torch.zeros((total,), dtype=torch.float32, device=dev)
-            off = 0
-            for s, need in zip(slots, need_par):
+            gflat = buf[off:off + sum(n_par)]
+            poff = 0
+            for s, cnt in zip(slots, n_par):
                 i = _SLOT_IDX[s]
-                if need:
-                    offs[s] = off
-                    a.dec[i].dparams = gflat.data_ptr() + 4 * off
-                    off += param_count(s)
+                if cnt:
+                    offs[s] = poff
+                    a.dec[i].dparams = gflat.data_ptr() + 4 * poff
+                    poff += cnt
                 else:
                     a.dec[i].dparams = None
             nws = lib.nsr_bwd_workspace_floats(_capi.STAGE_ID[stage], n, S, renderer.bwd_max_blocks)
