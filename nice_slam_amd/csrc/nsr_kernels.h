@@ -84,8 +84,8 @@ struct RenderParams {
 };
 
 // ------------------------------------------------------------------------------------------------
-// parameter packing: flat blob -> forward operand stream
-//   packed[m.pk + ((T*4 + r)*2 + Tp)*64 + lane] = W[16*Tp + (lane&15)][kbeg + 16T + 4(lane>>4) + r]
+// parameter packing: flat blob -> MFMA operand stream, four k-steps per lane contiguous (one 16-byte read each)
+//   packed[m.pk + ((T*2 + Tp)*64 + lane)*4 + r] = W[16*Tp + (lane&15)][kbeg + 16T + 4(lane>>4) + r]
 // ------------------------------------------------------------------------------------------------
 template <int KIND>
 NSR_KERNEL void pack_kernel(const float *__restrict__ flat, float *__restrict__ packed) {
@@ -97,8 +97,7 @@ NSR_KERNEL void pack_kernel(const float *__restrict__ flat, float *__restrict__ 
         const Mat m = mat_of(KIND, id);
         const int rel = idx - m.pk;
         if (rel >= 0 && rel < m.nt * 512) {
-            const int lane = rel & 63, row = rel >> 6;
-            const int Tp = row & 1, r = (row >> 1) & 3, T = row >> 3;
+            const int r = rel & 3, lane = (rel >> 2) & 63, Tp = (rel >> 8) & 1, T = rel >> 9;
             const int o = 16 * Tp + (lane & 15);
             const int k = 16 * T + 4 * (lane >> 4) + r;
             if (k < m.kcols) v = flat[m.off + o * m.stride + m.kbeg + k];
@@ -348,81 +347,52 @@ NSR_DEV void scatter_merged(const GridDev &G, const Lvl &L, int lane, const Act<
 // ------------------------------------------------------------------------------------------------
 // MFMA building blocks
 // ------------------------------------------------------------------------------------------------
-// acc[Tp] += W(slice) * x          (A from the packed stream, B = x registers)
-// LDSW: `pk` points at the decoder's packed stream staged in LDS (row r, lane l at pk[r*64 + l], conflict-free);
-// otherwise it is the global packed stream, read with buffer loads.
-template <int NT, bool LDSW>
+// acc[Tp] += W(slice) * x          (A from the packed stream staged in LDS, B = x registers)
+// One ds_read_b128 per (k-tile, output tile) feeds four MFMAs; a lane's 16 bytes are consecutive across the wave, so
+// the read is conflict-free at full LDS bandwidth.
+template <int NT>
 NSR_DEV void gemv_fwd(f32x4 (&acc)[2], const Act<NT> &x, const float *pk, int lane) {
-    if (LDSW) {
-        // explicit operand ring, depth kD steps (2 LDS reads each): bounds the reads in flight to 2*kD registers
-        // (the scheduler would otherwise hoist all 2*4*NT reads of the slice and spill) while covering the
-        // ~100-cycle LDS latency behind kD MFMA pairs.
-        constexpr int kD = 4, NS = NT * 4;
-        float ra[kD], rb[kD];
+    // explicit operand ring, depth kD k-tiles (2 reads = 8 registers each): bounds the reads in flight (the scheduler
+    // would otherwise hoist all 2*NT reads of the slice and spill) while covering the LDS latency behind 8 MFMAs
+    constexpr int kD = NT < 2 ? NT : 2;
+    f32x4 ra[kD], rb[kD];
 #pragma unroll
-        for (int q = 0; q < kD; ++q) { ra[q] = pk[(q * 2) * 64 + lane]; rb[q] = pk[(q * 2) * 64 + 64 + lane]; }
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-            acc[0] = mfma16(ra[q % kD], x.t[q >> 2][q & 3], acc[0]);
-            acc[1] = mfma16(rb[q % kD], x.t[q >> 2][q & 3], acc[1]);
-            if (q + kD < NS) { ra[q % kD] = pk[((q + kD) * 2) * 64 + lane]; rb[q % kD] = pk[((q + kD) * 2) * 64 + 64 + lane]; }
-        }
-        sched_fence();
-        return;
-    }
-    const Stream st = make_stream(pk);      // scalar descriptor; the lane offset is the only VGPR
+    for (int T = 0; T < kD; ++T) { ra[T] = to_v(ld4(pk + (T * 128 + lane) * 4)); rb[T] = to_v(ld4(pk + (T * 128 + 64 + lane) * 4)); }
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float a0 = stream_ld(st, lane, ((T * 4 + r) * 2) * 64);
-            const float a1 = stream_ld(st, lane, ((T * 4 + r) * 2) * 64 + 64);
-            acc[0] = mfma16(a0, x.t[T][r], acc[0]);
-            acc[1] = mfma16(a1, x.t[T][r], acc[1]);
+            acc[0] = mfma16(ra[T % kD][r], x.t[T][r], acc[0]);
+            acc[1] = mfma16(rb[T % kD][r], x.t[T][r], acc[1]);
+        }
+        if (T + kD < NT) {
+            ra[T % kD] = to_v(ld4(pk + ((T + kD) * 128 + lane) * 4));
+            rb[T % kD] = to_v(ld4(pk + ((T + kD) * 128 + 64 + lane) * 4));
         }
     }
     sched_fence();
 }
 
 // dx[Tk] += W(slice)^T * dy       (B = dy registers; A = W[16To+4g+r][16Tk+i])
-// LDSW: read from the packed stream in LDS (`w` = LDS base of the slice): element W[o][k] of a slice sits at
-//   Tk*512 + (k&3)*128 + (o>>4)*64 + (o&15) + 16*((k>>2)&3)    -- 8-way bank conflict, ~16 cycles per read, fine
-// next to a 64-cycle MFMA pair; columns beyond kcols are zero in the packed stream.
-// otherwise: W row-major from the flat parameter blob (64-byte runs) with buffer loads.
-template <int NTK, bool LDSW>
-NSR_DEV void gemv_bwd(f32x4 (&dx)[NTK], const Act<2> &dy, const float *w, const Mat m, int i, int g) {
-    if (LDSW) {
-        const int lo = (i & 3) * 128 + 16 * (i >> 2) + 4 * g;
-        constexpr int kD = 4, NS = 8;                     // step q = (To, r); NTK reads + NTK MFMAs per step
-        float ra[kD][NTK];
+// read from the same packed stream (`w` = LDS base of the slice): element W[o][k] of a slice sits at
+//   ((Tk*2 + (o>>4))*64 + (o&15) + 16*((k>>2)&3))*4 + (k&3)    -- scalar reads, 4-way bank conflict, fine next to
+// a 64-cycle MFMA pair; columns beyond kcols are zero in the packed stream.
+template <int NTK>
+NSR_DEV void gemv_bwd(f32x4 (&dx)[NTK], const Act<2> &dy, const float *w, int i, int g) {
+    const int lo = (4 * g + 16 * (i >> 2)) * 4 + (i & 3);
+    constexpr int kD = 4, NS = 8;                     // step q = (To, r); NTK reads + NTK MFMAs per step
+    float ra[kD][NTK];
 #pragma unroll
-        for (int q = 0; q < kD; ++q)
+    for (int q = 0; q < kD; ++q)
 #pragma unroll
-            for (int Tk = 0; Tk < NTK; ++Tk) ra[q][Tk] = w[Tk * 512 + (q >> 2) * 64 + (q & 3) + lo];
+        for (int Tk = 0; Tk < NTK; ++Tk) ra[q][Tk] = w[Tk * 512 + (q >> 2) * 256 + (q & 3) * 4 + lo];
 #pragma unroll
-        for (int q = 0; q < NS; ++q) {
+    for (int q = 0; q < NS; ++q) {
 #pragma unroll
-            for (int Tk = 0; Tk < NTK; ++Tk) dx[Tk] = mfma16(ra[q % kD][Tk], dy.t[q >> 2][q & 3], dx[Tk]);
-            if (q + kD < NS) {
+        for (int Tk = 0; Tk < NTK; ++Tk) dx[Tk] = mfma16(ra[q % kD][Tk], dy.t[q >> 2][q & 3], dx[Tk]);
+        if (q + kD < NS) {
 #pragma unroll
-                for (int Tk = 0; Tk < NTK; ++Tk) ra[q % kD][Tk] = w[Tk * 512 + ((q + kD) >> 2) * 64 + ((q + kD) & 3) + lo];
-            }
-        }
-        sched_fence();
-        return;
-    }
-    const Stream st = make_stream(w + m.off + m.kbeg);
-    const int lo = 4 * g * m.stride + i;
-#pragma unroll
-    for (int To = 0; To < 2; ++To) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int Tk = 0; Tk < NTK; ++Tk) {
-                const int k = 16 * Tk + i;
-                const float v = stream_ld(st, lo, (16 * To + r) * m.stride + 16 * Tk);   // always inside the blob
-                dx[Tk] = mfma16((k < m.kcols) ? v : 0.f, dy.t[To][r], dx[Tk]);
-            }
+            for (int Tk = 0; Tk < NTK; ++Tk) ra[q % kD][Tk] = w[Tk * 512 + ((q + kD) >> 2) * 256 + ((q + kD) & 3) * 4 + lo];
         }
     }
     sched_fence();
@@ -743,7 +713,7 @@ struct Kept {
 };
 
 // MLP (decoder.py:177-203): h_i = relu(W_i x_i + b_i) + (U_i c + v_i), x_3 = [e | h_2]
-template <int KIND, bool KEEP, bool LDSW>
+template <int KIND, bool KEEP>
 NSR_DEV void mlp_xyz_fwd(const float *pk, const float *aux, float px, float py, float pz,
                          const Act<cdim_of(KIND) / 16> &c, int lane, float (&out)[nout_of(KIND)], Kept<KIND> *kept) {
     constexpr int CD = cdim_of(KIND), NOUT = nout_of(KIND), NTC = CD / 16;
@@ -758,17 +728,17 @@ NSR_DEV void mlp_xyz_fwd(const float *pk, const float *aux, float px, float py, 
         acc[0] = to_v(ld4(aux + AUX_B + i * 32 + 4 * g));
         acc[1] = to_v(ld4(aux + AUX_B + i * 32 + 16 + 4 * g));
         if (i == 0) {
-            gemv_fwd<kET, LDSW>(acc, e, pk + xyz_mat(CD, XW0).pk, lane);
+            gemv_fwd<kET>(acc, e, pk + xyz_mat(CD, XW0).pk, lane);
         } else if (i == 3) {
-            gemv_fwd<kET, LDSW>(acc, e, pk + xyz_mat(CD, XW3E).pk, lane);
-            gemv_fwd<2, LDSW>(acc, h, pk + xyz_mat(CD, XW3H).pk, lane);
+            gemv_fwd<kET>(acc, e, pk + xyz_mat(CD, XW3E).pk, lane);
+            gemv_fwd<2>(acc, h, pk + xyz_mat(CD, XW3H).pk, lane);
         } else {
-            gemv_fwd<2, LDSW>(acc, h, pk + xyz_mat(CD, i == 1 ? XW1 : (i == 2 ? XW2 : XW4)).pk, lane);
+            gemv_fwd<2>(acc, h, pk + xyz_mat(CD, i == 1 ? XW1 : (i == 2 ? XW2 : XW4)).pk, lane);
         }
         const unsigned m = relu_mask(acc);
         acc[0] += to_v(ld4(aux + AUX_V + i * 32 + 4 * g));
         acc[1] += to_v(ld4(aux + AUX_V + i * 32 + 16 + 4 * g));
-        gemv_fwd<NTC, LDSW>(acc, c, pk + xyz_mat(CD, i == 0 ? XU0 : (i == 1 ? XU1 : (i == 2 ? XU2 : (i == 3 ? XU3 : XU4)))).pk, lane);
+        gemv_fwd<NTC>(acc, c, pk + xyz_mat(CD, i == 0 ? XU0 : (i == 1 ? XU1 : (i == 2 ? XU2 : (i == 3 ? XU3 : XU4)))).pk, lane);
         h.t[0] = acc[0];
         h.t[1] = acc[1];
         if (KEEP) { kept->h[i] = h; kept->mask[i] = m; }
@@ -784,7 +754,7 @@ NSR_DEV void mlp_xyz_fwd(const float *pk, const float *aux, float px, float py, 
 }
 
 // MLP_no_xyz (decoder.py:262-274): h = c; h = relu(W_i h + b_i); after i == 2: h = [c | h]
-template <bool KEEP, bool LDSW>
+template <bool KEEP>
 NSR_DEV void mlp_nox_fwd(const float *pk, const float *aux, const Act<2> &c, int lane, float (&out)[1], Kept<0> *kept) {
     const int g = lane >> 4;
     Act<2> h = c;
@@ -794,10 +764,10 @@ NSR_DEV void mlp_nox_fwd(const float *pk, const float *aux, const Act<2> &c, int
         acc[0] = to_v(ld4(aux + AUX_B + i * 32 + 4 * g));
         acc[1] = to_v(ld4(aux + AUX_B + i * 32 + 16 + 4 * g));
         if (i == 3) {
-            gemv_fwd<2, LDSW>(acc, c, pk + nox_mat(NW3C).pk, lane);
-            gemv_fwd<2, LDSW>(acc, h, pk + nox_mat(NW3H).pk, lane);
+            gemv_fwd<2>(acc, c, pk + nox_mat(NW3C).pk, lane);
+            gemv_fwd<2>(acc, h, pk + nox_mat(NW3H).pk, lane);
         } else {
-            gemv_fwd<2, LDSW>(acc, h, pk + nox_mat(i == 0 ? NW0 : (i == 1 ? NW1 : (i == 2 ? NW2 : NW4))).pk, lane);
+            gemv_fwd<2>(acc, h, pk + nox_mat(i == 0 ? NW0 : (i == 1 ? NW1 : (i == 2 ? NW2 : NW4))).pk, lane);
         }
         const unsigned m = relu_mask(acc);
         h.t[0] = acc[0];
@@ -866,14 +836,14 @@ NSR_DEV F4 decode_tile_lds(const RenderParams &P, const float *aux, float *wl, d
         const Lvl L = make_level(P.grid[NSR_COARSE], px, py, pz);
         const Act<2> c = gather_feat(P.grid[NSR_COARSE], L, g);
         float o[1];
-        mlp_nox_fwd<false, true>(wl, aux, c, lane, o, nullptr);
+        mlp_nox_fwd<false>(wl, aux, c, lane, o, nullptr);
         raw.w = o[0];
     } else {
         const float fx = (float)px, fy = (float)py, fz = (float)pz;     // decoder.py:189
         const Lvl Lm = make_level(P.grid[NSR_MIDDLE], px, py, pz);
         const Act<2> cm = gather_feat(P.grid[NSR_MIDDLE], Lm, g);
         float om[1];
-        mlp_xyz_fwd<NSR_MIDDLE, false, true>(wl, aux, fx, fy, fz, cm, lane, om, nullptr);
+        mlp_xyz_fwd<NSR_MIDDLE, false>(wl, aux, fx, fy, fz, cm, lane, om, nullptr);
         float occ = om[0];
         if (STAGE >= NSR_STAGE_FINE) {
             const Lvl Lf = make_level(P.grid[NSR_FINE], px, py, pz);
@@ -884,7 +854,7 @@ NSR_DEV F4 decode_tile_lds(const RenderParams &P, const float *aux, float *wl, d
             Act<4> cc;
             cc.t[0] = cf.t[0]; cc.t[1] = cf.t[1]; cc.t[2] = cm.t[0]; cc.t[3] = cm.t[1];    // decoder.py:182-187
             float of[1];
-            mlp_xyz_fwd<NSR_FINE, false, true>(wl, aux + AUX_FLOATS, fx, fy, fz, cc, lane, of, nullptr);
+            mlp_xyz_fwd<NSR_FINE, false>(wl, aux + AUX_FLOATS, fx, fy, fz, cc, lane, of, nullptr);
             occ = of[0] + om[0];                                                            // decoder.py:333,341
         }
         if (STAGE == NSR_STAGE_COLOR) {
@@ -894,7 +864,7 @@ NSR_DEV F4 decode_tile_lds(const RenderParams &P, const float *aux, float *wl, d
             load_packed<NSR_COLOR>(wl, P.dec[NSR_COLOR].packed);
             block_sync();
             float oc[4];
-            mlp_xyz_fwd<NSR_COLOR, false, true>(wl, aux + 2 * AUX_FLOATS, fx, fy, fz, ccol, lane, oc, nullptr);
+            mlp_xyz_fwd<NSR_COLOR, false>(wl, aux + 2 * AUX_FLOATS, fx, fy, fz, ccol, lane, oc, nullptr);
             raw.x = oc[0]; raw.y = oc[1]; raw.z = oc[2];
         }
         raw.w = occ;
@@ -1035,7 +1005,7 @@ struct XyzBwd {
         constexpr int hid = I == 1 ? XW1 : (I == 2 ? XW2 : (I == 3 ? XW3H : XW4));
         const Mat mu = xyz_mat(CD, uid);
         if (F.params) st_store(S + kStA0, dh, i16, g);                      // dH_i: gradient of (U_i c + v_i) is dh itself
-        if (F.grid || F.rays) gemv_bwd<2, true>(dc.t, dh, wl + mu.pk, mu, i16, g);      // first 32 feature columns only
+        if (F.grid || F.rays) gemv_bwd<2>(dc.t, dh, wl + mu.pk, i16, g);      // first 32 feature columns only
         const Act<2> dY = apply_mask(dh, K.mask[I]);
         if (I == 3) dY3 = dY;
         if (I == 0) dY0 = dY;
@@ -1065,7 +1035,7 @@ struct XyzBwd {
         if (I > 0) {
             Act<2> nd;
             act_zero(nd);
-            gemv_bwd<2, true>(nd.t, dY, wl + xyz_mat(CD, hid).pk, xyz_mat(CD, hid), i16, g);
+            gemv_bwd<2>(nd.t, dY, wl + xyz_mat(CD, hid).pk, i16, g);
             dh = nd;
         }
     }
@@ -1083,7 +1053,7 @@ NSR_DEV void mlp_xyz_bwd(const float *pk, const float *aux, const Own &O, float 
     const int i16 = lane & 15, g = lane >> 4;
     Kept<KIND> K;
     float out[NOUT];
-    mlp_xyz_fwd<KIND, true, true>(pk, aux, px, py, pz, c, lane, out, &K);
+    mlp_xyz_fwd<KIND, true>(pk, aux, px, py, pz, c, lane, out, &K);
     (void)out;
 
     // output layer
@@ -1133,7 +1103,7 @@ NSR_DEV void mlp_xyz_bwd(const float *pk, const float *aux, const Own &O, float 
     const bool need_dB = F.params;
     if (F.rays || need_dB) {
         const Mat m0 = xyz_mat(CD, XW0), m3 = xyz_mat(CD, XW3E);
-        const int lo = (i16 & 3) * 128 + 16 * (i16 >> 2) + 4 * g;       // packed-stream position of W[.][16Tk+i16], see gemv_bwd
+        const int lo = (4 * g + 16 * (i16 >> 2)) * 4 + (i16 & 3);       // packed-stream position of W[.][16Tk+i16], see gemv_bwd
         float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
         for (int Tk = 0; Tk < kET; ++Tk) {
@@ -1142,8 +1112,8 @@ NSR_DEV void mlp_xyz_bwd(const float *pk, const float *aux, const Own &O, float 
             for (int To = 0; To < 2; ++To)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float a0 = pk[m0.pk + Tk * 512 + To * 64 + r + lo];
-                    const float a3 = pk[m3.pk + Tk * 512 + To * 64 + r + lo];
+                    const float a0 = pk[m0.pk + Tk * 512 + To * 256 + r * 4 + lo];
+                    const float a3 = pk[m3.pk + Tk * 512 + To * 256 + r * 4 + lo];
                     dE = mfma16(a0, dY0.t[To][r], dE);
                     dE2 = mfma16(a3, dY3.t[To][r], dE2);
                 }
@@ -1203,13 +1173,13 @@ struct NoxBwd {
             if ((4 - I + 3) % O.nw == O.wave) own_colsum(O, nox_b(I), kStA1);
             block_sync();
         }
-        if (I == 3) gemv_bwd<2, true>(dc.t, dY, wl + nox_mat(NW3C).pk, nox_mat(NW3C), i16, g);
+        if (I == 3) gemv_bwd<2>(dc.t, dY, wl + nox_mat(NW3C).pk, i16, g);
         if (I == 0) {
-            gemv_bwd<2, true>(dc.t, dY, wl + mh.pk, mh, i16, g);
+            gemv_bwd<2>(dc.t, dY, wl + mh.pk, i16, g);
         } else {
             Act<2> nd;
             act_zero(nd);
-            gemv_bwd<2, true>(nd.t, dY, wl + mh.pk, mh, i16, g);
+            gemv_bwd<2>(nd.t, dY, wl + mh.pk, i16, g);
             dh = nd;
         }
     }
@@ -1221,7 +1191,7 @@ NSR_DEV void mlp_nox_bwd(const float *pk, const float *aux, const Own &O, float 
     const int i16 = lane & 15, g = lane >> 4;
     Kept<0> K;
     float out[1];
-    mlp_nox_fwd<true, true>(pk, aux, c, lane, out, &K);
+    mlp_nox_fwd<true>(pk, aux, c, lane, out, &K);
     (void)out;
     Act<2> dh;
 #pragma unroll
