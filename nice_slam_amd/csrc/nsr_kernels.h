@@ -660,35 +660,30 @@ NSR_DEV Act<2> apply_mask(const Act<2> &d, unsigned m) {
     return o;
 }
 
-// sin / cos for Fourier arguments |x| up to a few thousand: two-constant Cody-Waite reduction by
-// pi/2 (exact products through fma) + minimax polynomials on [-pi/4, pi/4]; abs error ~1e-7, i.e.
-// the same class as libm sinf, branch-free so it schedules between MFMAs.
-NSR_DEV void sincos_core(float x, float &s, float &c, int &q) {
-    const float k = rintf(x * 0.63661977236758134f);
-    float r = fmaf(k, -1.57079637050628662109375f, x);
-    r = fmaf(k, 4.37113900018624283e-8f, r);
-    q = (int)k;
+// sin / cos for Fourier arguments |x| up to a few thousand: two-constant Cody-Waite reduction by pi (exact products
+// through fma) to r in [-pi/2, pi/2], one odd minimax polynomial of degree 9 there (3.3e-9 in exact arithmetic, ~1.5e-7
+// evaluated in fp32: the same class as libm sinf), sign from the parity of the quotient; branch-free, 13 VALU operations.
+NSR_DEV float sin_poly(float r, int k) {
     const float r2 = r * r;
-    float ps = fmaf(r2, 2.72436227533035e-06f, -1.984003756660968e-04f);
-    ps = fmaf(ps, r2, 8.333331905305386e-03f);
-    ps = fmaf(ps, r2, -1.666666716337204e-01f);
-    s = fmaf(ps * r2, r, r);
-    float pc = fmaf(r2, 2.4457105610053986e-05f, -1.3887537643313408e-03f);
-    pc = fmaf(pc, r2, 4.166664928197861e-02f);
-    pc = fmaf(pc, r2, -0.5f);
-    c = fmaf(pc, r2, 1.f);
+    float p = fmaf(r2, 2.59048850e-06f, -1.98008978e-04f);
+    p = fmaf(p, r2, 8.33289982e-03f);
+    p = fmaf(p, r2, -1.66666476e-01f);
+    const float s = fmaf(p * r2, r, r);
+    return (k & 1) ? -s : s;
 }
 NSR_DEV float sin_acc(float x) {
-    float s, c; int q;
-    sincos_core(x, s, c, q);
-    const float v = (q & 1) ? c : s;
-    return (q & 2) ? -v : v;
+    const float k = rintf(x * 0.318309886183790672f);
+    float r = fmaf(k, -3.14159274101257324f, x);
+    r = fmaf(k, 8.74227765734758577e-08f, r);
+    return sin_poly(r, (int)k);
 }
+// cos(x) = -(-1)^k sin(r) with x = (k + 1/2) pi + r
 NSR_DEV float cos_acc(float x) {
-    float s, c; int q;
-    sincos_core(x, s, c, q);
-    const float v = (q & 1) ? s : c;
-    return ((q + 1) & 2) ? -v : v;
+    const float k = rintf(fmaf(x, 0.318309886183790672f, -0.5f));
+    float r = fmaf(k, -3.14159274101257324f, x);
+    r = fmaf(k, 8.74227765734758577e-08f, r);
+    r = (r - 1.57079637050628662f) + 4.37113882867379289e-08f;
+    return sin_poly(r, (int)k + 1);
 }
 
 NSR_DEV void embed(Act<kET> &e, const float *aux, float px, float py, float pz, int g) {
