@@ -1220,7 +1220,10 @@ NSR_DEV void mlp_nox_bwd(const float *pk, const float *aux, const Own &O, float 
 // The per-block image of the parameter gradients lives in the global partial buffer (stays in L2; exclusive owner
 // per element, first ray group stores, later groups accumulate), summed over blocks by reduce_partials_kernel.
 // ------------------------------------------------------------------------------------------------
-template <int KIND>
+// PARAMS is the compile-time twin of "this decoder's dparams != NULL": the pass without parameter gradients (tracking,
+// decoders the optimiser does not step) needs neither the kept activations nor the staging code and compiles without
+// register spills
+template <int KIND, bool PARAMS>
 NSR_DEV void bwd_pass(const RenderParams &P) {
     constexpr int NPAR = param_total(KIND);
     char *lds = lds_base();
@@ -1242,7 +1245,7 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
     const DecDev &D = P.dec[KIND];
     BwdFlags F;
     F.grid = G.dfeat != nullptr;
-    F.params = D.dparams != nullptr;
+    F.params = PARAMS;
     F.rays = P.d_rays_o != nullptr;
     if (!F.grid && !F.params && !F.rays) return;
 
@@ -1370,12 +1373,16 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
 template <int STAGE>
 NSR_KERNEL NSR_BOUNDS(64 * NSR_BWD_TILES) void render_bwd_kernel(const RenderParams P) {
     if (STAGE == NSR_STAGE_COARSE) {
-        bwd_pass<NSR_COARSE>(P);
+        if (P.dec[NSR_COARSE].dparams) bwd_pass<NSR_COARSE, true>(P); else bwd_pass<NSR_COARSE, false>(P);
     } else {
         const int pass = bid_y();
-        if (pass == 0) bwd_pass<NSR_MIDDLE>(P);
-        else if (pass == 1) { if (STAGE >= NSR_STAGE_FINE) bwd_pass<NSR_FINE>(P); }
-        else { if (STAGE == NSR_STAGE_COLOR) bwd_pass<NSR_COLOR>(P); }
+        if (pass == 0) {
+            if (P.dec[NSR_MIDDLE].dparams) bwd_pass<NSR_MIDDLE, true>(P); else bwd_pass<NSR_MIDDLE, false>(P);
+        } else if (pass == 1) {
+            if (STAGE >= NSR_STAGE_FINE) { if (P.dec[NSR_FINE].dparams) bwd_pass<NSR_FINE, true>(P); else bwd_pass<NSR_FINE, false>(P); }
+        } else {
+            if (STAGE == NSR_STAGE_COLOR) { if (P.dec[NSR_COLOR].dparams) bwd_pass<NSR_COLOR, true>(P); else bwd_pass<NSR_COLOR, false>(P); }
+        }
     }
 }
 
