@@ -24,6 +24,7 @@ inline int round16(int bytes) { return (bytes + 15) & ~15; }
 // forward: up to 12 tiles (768 threads, 3 waves/SIMD, <=168 VGPRs).  backward: up to kBwdTiles tiles so that the
 // register-hungry backward gets 2 waves/SIMD with the full 256-VGPR budget instead of spilling.
 constexpr int kBwdTiles = NSR_BWD_TILES;
+constexpr int kBwdWaves = NSR_BWD_WAVES;
 int rays_per_block_t(int S, int max_tiles) {
     int rb = (max_tiles * nsr::kTile) / S;
     return rb < 1 ? 1 : rb;
@@ -193,8 +194,9 @@ int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream
         P.partials = b->workspace;
     }
     const int npts = P.rays_per_block * P.S;
-    const int lds = bwd_lds_bytes(P.stage, npts, P.tiles_per_block);
-    const dim3 grid(nblk, passes), block(64 * P.tiles_per_block);
+    const int waves = P.tiles_per_block < kBwdWaves ? P.tiles_per_block : kBwdWaves;
+    const int lds = bwd_lds_bytes(P.stage, npts, waves);
+    const dim3 grid(nblk, passes), block(64 * waves);
 #define NSR_BWD(ST)                                                                              \
     case ST:                                                                                     \
         if (int rc = launch_cfg(nsr::render_bwd_kernel<ST>, lds, "nsr_render_bwd")) return rc;    \

@@ -20,7 +20,10 @@
 #include "../../include/nsr.h"
 
 #ifndef NSR_BWD_TILES
-#define NSR_BWD_TILES 6     // waves per backward block (see nsr_api.cpp)
+#define NSR_BWD_TILES 6     // tiles per ray group of the backward kernel (see nsr_api.cpp)
+#endif
+#ifndef NSR_BWD_WAVES
+#define NSR_BWD_WAVES 6     // waves per backward block; a group's tiles are processed NSR_BWD_WAVES at a time
 #endif
 
 namespace nsr {
@@ -478,40 +481,38 @@ NSR_DEV void own_pair(const Own &O, const Mat m, int Tk, int a_off, int x_off, i
     }
     F4 b = F4{0.f, 0.f, 0.f, 0.f};
     if (XSRC == 2) b = ld4(aux + AUX_BM + (16 * Tk + i) * 4);
-    // software pipeline over the block's tiles: the LDS reads (and, for the embedding, the sines) of tile t+1 are
-    // issued before the 8 MFMAs of tile t
-    const float *S = O.stg;
-    f32x4 a0 = st_load_cm(S + a_off, 0, i, g), a1 = st_load_cm(S + a_off, 1, i, g), x;
-    if (XSRC == 2) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const F4 pp = ld4(S + kStP + (4 * g + q) * 4);
-            x[q] = sin_acc(fmaf(pp.z, b.z, fmaf(pp.y, b.y, pp.x * b.x)));
-        }
-    } else {
-        x = st_load_cm(S + x_off, x_sub, i, g);
-    }
-    for (int t = 0; t < O.nw; ++t) {
-        const float *Sn = O.stg + (t + 1 < O.nw ? t + 1 : t) * O.stride;
-        const f32x4 na0 = st_load_cm(Sn + a_off, 0, i, g), na1 = st_load_cm(Sn + a_off, 1, i, g);
-        f32x4 nx;
-        F4 pp[4];
+    // software pipeline over the block's tiles, two tiles per trip with ping-pong operand sets (no register rotation):
+    // the LDS reads (and, for the embedding, the sines) of the next tile are issued before the 8 MFMAs of this one
+    struct Ops { f32x4 a0, a1, x; };
+    auto fetch = [&](int t) {
+        const float *S = O.stg + (t < O.nw ? t : O.nw - 1) * O.stride;
+        Ops o;
+        o.a0 = st_load_cm(S + a_off, 0, i, g);
+        o.a1 = st_load_cm(S + a_off, 1, i, g);
         if (XSRC == 2) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pp[q] = ld4(Sn + kStP + (4 * g + q) * 4);
+            for (int q = 0; q < 4; ++q) {
+                const F4 pp = ld4(S + kStP + (4 * g + q) * 4);
+                o.x[q] = sin_acc(fmaf(pp.z, b.z, fmaf(pp.y, b.y, pp.x * b.x)));
+            }
         } else {
-            nx = st_load_cm(Sn + x_off, x_sub, i, g);
+            o.x = st_load_cm(S + x_off, x_sub, i, g);
         }
+        return o;
+    };
+    auto fmas = [&](const Ops &o) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            d0 = mfma16(a0[q], x[q], d0);
-            d1 = mfma16(a1[q], x[q], d1);
+            d0 = mfma16(o.a0[q], o.x[q], d0);
+            d1 = mfma16(o.a1[q], o.x[q], d1);
         }
-        if (XSRC == 2) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) nx[q] = sin_acc(fmaf(pp[q].z, b.z, fmaf(pp[q].y, b.y, pp[q].x * b.x)));
-        }
-        a0 = na0; a1 = na1; x = nx;
+    };
+    Ops A = fetch(0);
+    for (int t = 0; t < O.nw; t += 2) {
+        const Ops B = fetch(t + 1);
+        fmas(A);
+        A = fetch(t + 2);
+        if (t + 1 < O.nw) fmas(B);
     }
     if (live) {
 #pragma unroll
@@ -541,32 +542,34 @@ NSR_DEV void own_embed_pair(const Own &O, const Mat m0, const Mat m3, int Tk, in
         }
     }
     const F4 b = ld4(aux + AUX_BM + (16 * Tk + i) * 4);
-    const float *S = O.stg;
-    f32x4 p0 = st_load_cm(S + a0_off, 0, i, g), p1 = st_load_cm(S + a0_off, 1, i, g);
-    f32x4 q0 = st_load_cm(S + a3_off, 0, i, g), q1 = st_load_cm(S + a3_off, 1, i, g), x;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const F4 pp = ld4(S + kStP + (4 * g + q) * 4);
-        x[q] = sin_acc(fmaf(pp.z, b.z, fmaf(pp.y, b.y, pp.x * b.x)));
-    }
-    for (int t = 0; t < O.nw; ++t) {
-        const float *Sn = O.stg + (t + 1 < O.nw ? t + 1 : t) * O.stride;
-        const f32x4 np0 = st_load_cm(Sn + a0_off, 0, i, g), np1 = st_load_cm(Sn + a0_off, 1, i, g);
-        const f32x4 nq0 = st_load_cm(Sn + a3_off, 0, i, g), nq1 = st_load_cm(Sn + a3_off, 1, i, g);
-        F4 pp[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pp[q] = ld4(Sn + kStP + (4 * g + q) * 4);
+    struct Ops { f32x4 p0, p1, q0, q1, x; };
+    auto fetch = [&](int t) {
+        const float *S = O.stg + (t < O.nw ? t : O.nw - 1) * O.stride;
+        Ops o;
+        o.p0 = st_load_cm(S + a0_off, 0, i, g); o.p1 = st_load_cm(S + a0_off, 1, i, g);
+        o.q0 = st_load_cm(S + a3_off, 0, i, g); o.q1 = st_load_cm(S + a3_off, 1, i, g);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            d00 = mfma16(p0[q], x[q], d00);
-            d01 = mfma16(p1[q], x[q], d01);
-            d30 = mfma16(q0[q], x[q], d30);
-            d31 = mfma16(q1[q], x[q], d31);
+            const F4 pp = ld4(S + kStP + (4 * g + q) * 4);
+            o.x[q] = sin_acc(fmaf(pp.z, b.z, fmaf(pp.y, b.y, pp.x * b.x)));
         }
-        f32x4 nx;
+        return o;
+    };
+    auto fmas = [&](const Ops &o) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) nx[q] = sin_acc(fmaf(pp[q].z, b.z, fmaf(pp[q].y, b.y, pp[q].x * b.x)));
-        p0 = np0; p1 = np1; q0 = nq0; q1 = nq1; x = nx;
+        for (int q = 0; q < 4; ++q) {
+            d00 = mfma16(o.p0[q], o.x[q], d00);
+            d01 = mfma16(o.p1[q], o.x[q], d01);
+            d30 = mfma16(o.q0[q], o.x[q], d30);
+            d31 = mfma16(o.q1[q], o.x[q], d31);
+        }
+    };
+    Ops A = fetch(0);
+    for (int t = 0; t < O.nw; t += 2) {
+        const Ops B = fetch(t + 1);
+        fmas(A);
+        A = fetch(t + 2);
+        if (t + 1 < O.nw) fmas(B);
     }
     if (live) {
 #pragma unroll
@@ -651,6 +654,12 @@ NSR_DEV unsigned relu_mask(f32x4 (&acc)[2]) {
         }
     return m;
 }
+NSR_DEV void relu_plain(f32x4 (&acc)[2]) {
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[T][r] = fmaxf(acc[T][r], 0.f);
+}
 NSR_DEV Act<2> apply_mask(const Act<2> &d, unsigned m) {
     Act<2> o;
 #pragma unroll
@@ -663,27 +672,31 @@ NSR_DEV Act<2> apply_mask(const Act<2> &d, unsigned m) {
 // sin / cos for Fourier arguments |x| up to a few thousand: two-constant Cody-Waite reduction by pi (exact products
 // through fma) to r in [-pi/2, pi/2], one odd minimax polynomial of degree 9 there (3.3e-9 in exact arithmetic, ~1.5e-7
 // evaluated in fp32: the same class as libm sinf), sign from the parity of the quotient; branch-free, 13 VALU operations.
-NSR_DEV float sin_poly(float r, int k) {
+NSR_DEV float sin_poly(float r, unsigned sign) {
     const float r2 = r * r;
     float p = fmaf(r2, 2.59048850e-06f, -1.98008978e-04f);
     p = fmaf(p, r2, 8.33289982e-03f);
     p = fmaf(p, r2, -1.66666476e-01f);
     const float s = fmaf(p * r2, r, r);
-    return (k & 1) ? -s : s;
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s) ^ sign);
 }
+// quotient by the "1.5 * 2^23" trick: t = x/pi + 12582912 has round(x/pi) in its low mantissa bits (|x| < 1e7), so
+// its parity is bit 0 of the float and no float->int conversion / compare / select is needed for the sign
 NSR_DEV float sin_acc(float x) {
-    const float k = rintf(x * 0.318309886183790672f);
+    const float t = fmaf(x, 0.318309886183790672f, 12582912.f);
+    const float k = t - 12582912.f;
     float r = fmaf(k, -3.14159274101257324f, x);
     r = fmaf(k, 8.74227765734758577e-08f, r);
-    return sin_poly(r, (int)k);
+    return sin_poly(r, __builtin_bit_cast(unsigned, t) << 31);
 }
 // cos(x) = -(-1)^k sin(r) with x = (k + 1/2) pi + r
 NSR_DEV float cos_acc(float x) {
-    const float k = rintf(fmaf(x, 0.318309886183790672f, -0.5f));
+    const float t = fmaf(x, 0.318309886183790672f, -0.5f) + 12582912.f;     // (12582912 - 0.5 is not representable)
+    const float k = t - 12582912.f;
     float r = fmaf(k, -3.14159274101257324f, x);
     r = fmaf(k, 8.74227765734758577e-08f, r);
     r = (r - 1.57079637050628662f) + 4.37113882867379289e-08f;
-    return sin_poly(r, (int)k + 1);
+    return sin_poly(r, (__builtin_bit_cast(unsigned, t) << 31) ^ 0x80000000u);
 }
 
 NSR_DEV void embed(Act<kET> &e, const float *aux, float px, float py, float pz, int g) {
@@ -764,7 +777,8 @@ NSR_DEV void mlp_nox_fwd(const float *pk, const float *aux, const Act<2> &c, int
         } else {
             gemv_fwd<2>(acc, h, pk + nox_mat(i == 0 ? NW0 : (i == 1 ? NW1 : (i == 2 ? NW2 : NW4))).pk, lane);
         }
-        const unsigned m = relu_mask(acc);
+        unsigned m = 0;
+        if (KEEP) m = relu_mask(acc); else relu_plain(acc);
         h.t[0] = acc[0];
         h.t[1] = acc[1];
         if (KEEP) { kept->h[i] = h; kept->mask[i] = m; }
@@ -1257,7 +1271,8 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
 
     for (long long grp = bid_x(); grp < P.n_groups; grp += nblk_x()) {
         loop_fence();
-        const Own O{make_stream(img), stg, stg_floats(KIND), nwaves, wave, lane, grp == (long long)bid_x(), small};
+        const bool first_grp = grp == (long long)bid_x();
+        Own O{make_stream(img), stg, stg_floats(KIND), nwaves, wave, lane, first_grp, small};
         const long long ray0 = grp * P.rays_per_block;
         if (P.zvals) {            // sample depths saved by the forward pass: one coalesced load instead of re-deriving them
             for (int t = tid(); t < npts; t += nthreads())
@@ -1266,25 +1281,33 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
         } else {
             compute_z(P, ray0, ztmp, zbuf);
         }
-        // ---- tile set-up first: the feature gathers (L2 / Infinity-Cache latency) fly while the compositor runs
-        const int pidx = wave * kTile + (lane & 15);
+        // ---- tile set-up first: the feature gathers (L2 / Infinity-Cache latency) fly while the compositor runs.
+        // A ray group holds tiles_per_block tiles; the block's waves take them nwaves at a time (sub-rounds).
         const int g = lane >> 4;
-        const long long ray_t = ray0 + pidx / S;
-        const bool active = (pidx < npts) && (ray_t < P.n_rays);
-        const long long rr = active ? ray_t : 0;
-        const double zt = active ? zbuf[pidx] : 0.0;
-        const double px = (double)P.rays_o[rr * 3 + 0] + (double)P.rays_d[rr * 3 + 0] * zt;
-        const double py = (double)P.rays_o[rr * 3 + 1] + (double)P.rays_d[rr * 3 + 1] * zt;
-        const double pz = (double)P.rays_o[rr * 3 + 2] + (double)P.rays_d[rr * 3 + 2] * zt;
-        const bool inside = (px > P.blo[0]) && (px < P.bhi[0]) && (py > P.blo[1]) && (py < P.bhi[1]) &&
-                            (pz > P.blo[2]) && (pz < P.bhi[2]);
-        const Lvl L = make_level(G, px, py, pz);
-        const Act<2> c = gather_feat(G, L, g);
-        Act<2> cm;
-        if (KIND == NSR_FINE) {
-            const Lvl Lm = make_level(P.grid[NSR_MIDDLE], px, py, pz);
-            cm = gather_feat(P.grid[NSR_MIDDLE], Lm, g);
-        }
+        int pidx;
+        bool active, inside;
+        double px, py, pz;
+        Lvl L;
+        Act<2> c, cm;
+        auto tile_setup = [&](int sub) {
+            pidx = (sub * nwaves + wave) * kTile + (lane & 15);
+            const long long ray_t = ray0 + pidx / S;
+            active = (pidx < npts) && (ray_t < P.n_rays);
+            const long long rr = active ? ray_t : 0;
+            const double zt = active ? zbuf[pidx] : 0.0;
+            px = (double)P.rays_o[rr * 3 + 0] + (double)P.rays_d[rr * 3 + 0] * zt;
+            py = (double)P.rays_o[rr * 3 + 1] + (double)P.rays_d[rr * 3 + 1] * zt;
+            pz = (double)P.rays_o[rr * 3 + 2] + (double)P.rays_d[rr * 3 + 2] * zt;
+            inside = (px > P.blo[0]) && (px < P.bhi[0]) && (py > P.blo[1]) && (py < P.bhi[1]) &&
+                     (pz > P.blo[2]) && (pz < P.bhi[2]);
+            L = make_level(G, px, py, pz);
+            c = gather_feat(G, L, g);
+            if (KIND == NSR_FINE) {
+                const Lvl Lm = make_level(P.grid[NSR_MIDDLE], px, py, pz);
+                cm = gather_feat(P.grid[NSR_MIDDLE], Lm, g);
+            }
+        };
+        tile_setup(0);
         // ---- compositor backward: d raw per sample (common.py:231-244 differentiated)
         for (int r = wave; r < P.rays_per_block; r += nwaves) {
             const long long ray = ray0 + r;
@@ -1314,7 +1337,8 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
             if (act) draw[r * S + lane] = F4{c.w * gr, c.w * gg, c.w * gb, docc};
         }
         block_sync();
-        {   // ---- decoder backward for the tile of this wave
+        for (int sub = 0;;) {   // ---- decoder backward for the tile of this wave
+            O.first = first_grp && sub == 0;                       // layer images: stored by the block's first sub-round
             F4 dr = active ? draw[pidx] : F4{0.f, 0.f, 0.f, 0.f};
             if (!inside) dr.w = 0.f;                               // Renderer.py:57 cuts the occupancy gradient
             Act<2> dc;
@@ -1342,7 +1366,11 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
                 dpb[pidx * 3 + 1] = (double)duy * (2.0 * G.inv[1]) + (double)dpe[1];
                 dpb[pidx * 3 + 2] = (double)duz * (2.0 * G.inv[2]) + (double)dpe[2];
             }
+            if (++sub * nwaves >= P.tiles_per_block) break;
+            wave_fence();                                      // the scatter is done with this wave's staging region
+            tile_setup(sub);
         }
+        O.first = first_grp;                                       // output-layer image: touched once per group
         block_sync();
         if (F.params) {          // output-layer gradients of the whole block -> gradient image
             constexpr int NO = nout_of(KIND);
@@ -1371,7 +1399,7 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
 }
 
 template <int STAGE>
-NSR_KERNEL NSR_BOUNDS(64 * NSR_BWD_TILES) void render_bwd_kernel(const RenderParams P) {
+NSR_KERNEL NSR_BOUNDS(64 * NSR_BWD_WAVES) void render_bwd_kernel(const RenderParams P) {
     if (STAGE == NSR_STAGE_COARSE) {
         if (P.dec[NSR_COARSE].dparams) bwd_pass<NSR_COARSE, true>(P); else bwd_pass<NSR_COARSE, false>(P);
     } else {
