@@ -126,7 +126,7 @@ NSR_DEV void load_aux(float *aux, const float *__restrict__ flat) {
             const int n = idx - AUX_BO;
             if (n < nout_of(KIND)) v = flat[bo_off(KIND) + n];
         } else if (is_xyz(KIND)) {
-            const int ch = (idx - AUX_BM) >> 2, d = idx & 3;
+            const int rel = idx - AUX_BM, ch = (rel >> 4) * 4 + (rel & 3), d = (rel >> 2) & 3;   // [4-channel group][xyz.][4]
             if (ch < kE && d < 3) v = flat[B_off(KIND) + d * kE + ch];
         }
         aux[idx] = v;
@@ -408,7 +408,51 @@ NSR_DEV void load_packed(float *wl, const float *__restrict__ packed) {
 }
 
 NSR_DEV float red_g(float v) { v += shfl_xor(v, 16); v += shfl_xor(v, 32); return v; }
-NSR_DEV float sin_acc(float x);
+
+// sin / cos for Fourier arguments |x| up to a few thousand: two-constant Cody-Waite reduction by pi (exact products
+// through fma) to r in [-pi/2, pi/2], one odd minimax polynomial of degree 9 there (3.3e-9 in exact arithmetic, ~1.5e-7
+// evaluated in fp32: the same class as libm sinf), sign from the parity of the quotient; branch-free, 13 VALU operations.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+NSR_DEV f32x4 splat(float v) { f32x4 r = {v, v, v, v}; return r; }
+NSR_DEV f32x4 vfma(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+// Four arguments at a time: every step is a <4 x float> operation, i.e. two packed-fp32 instructions (v_pk_fma_f32 /
+// v_pk_mul_f32 / v_pk_add_f32), half the VALU issue slots of the scalar form.
+NSR_DEV f32x4 sin_poly4(f32x4 r, u32x4 sign) {
+    const f32x4 r2 = r * r;
+    f32x4 p = vfma(r2, splat(2.59048850e-06f), splat(-1.98008978e-04f));
+    p = vfma(p, r2, splat(8.33289982e-03f));
+    p = vfma(p, r2, splat(-1.66666476e-01f));
+    const f32x4 s = vfma(p * r2, r, r);
+    return __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, s) ^ sign);
+}
+// quotient by the "1.5 * 2^23" trick: t = x/pi + 12582912 has round(x/pi) in its low mantissa bits (|x| < 1e7), so
+// its parity is bit 0 of the float and no float->int conversion / compare / select is needed for the sign
+NSR_DEV f32x4 sin_acc4(f32x4 x) {
+    const f32x4 t = vfma(x, splat(0.318309886183790672f), splat(12582912.f));
+    const f32x4 k = t - splat(12582912.f);
+    f32x4 r = vfma(k, splat(-3.14159274101257324f), x);
+    r = vfma(k, splat(8.74227765734758577e-08f), r);
+    return sin_poly4(r, __builtin_bit_cast(u32x4, t) << 31);
+}
+// cos(x) = -(-1)^k sin(r) with x = (k + 1/2) pi + r
+NSR_DEV f32x4 cos_acc4(f32x4 x) {
+    const f32x4 t = vfma(x, splat(0.318309886183790672f), splat(-0.5f)) + splat(12582912.f);   // (12582912 - 0.5 is not representable)
+    const f32x4 k = t - splat(12582912.f);
+    f32x4 r = vfma(k, splat(-3.14159274101257324f), x);
+    r = vfma(k, splat(8.74227765734758577e-08f), r);
+    r = (r - splat(1.57079637050628662f)) + splat(4.37113882867379289e-08f);
+    return sin_poly4(r, (__builtin_bit_cast(u32x4, t) << 31) ^ 0x80000000u);
+}
+// Fourier matrix rows of four consecutive channels (group = channel / 4): Bx[4], By[4], Bz[4]
+struct B4 { f32x4 x, y, z; };
+NSR_DEV B4 load_b4(const float *aux, int group) {
+    const float *b = aux + AUX_BM + group * 16;
+    return B4{to_v(ld4(b)), to_v(ld4(b + 4)), to_v(ld4(b + 8))};
+}
+NSR_DEV F4 load_b1(const float *aux, int ch) {        // (Bx, By, Bz) of one channel
+    const float *b = aux + AUX_BM + (ch >> 2) * 16 + (ch & 3);
+    return F4{b[0], b[4], b[8], 0.f};
+}
 
 // ------------------------------------------------------------------------------------------------
 // Parameter gradients, owner-computes.
@@ -460,8 +504,7 @@ NSR_DEV void img_add(const Own &O, int lane_off, int const_off, float v) {
     stream_st(O.img, lane_off, const_off, v);
 }
 
-// img[W slice, k-tile Tk] += sum over the block's tiles of A^T X.   XSRC 0/1: X staged at x_off (sub-tile x_sub);
-// XSRC 2: X = Fourier embedding recomputed from the staged positions (decoder.py:26-30)
+// img[W slice, k-tile Tk] += sum over the block's tiles of A^T X,  X staged at x_off (sub-tile x_sub)
 template <int XSRC>
 NSR_DEV void own_pair(const Own &O, const Mat m, int Tk, int a_off, int x_off, int x_sub, const float *aux) {
     const int i = O.lane & 15, g = O.lane >> 4;
@@ -479,8 +522,7 @@ NSR_DEV void own_pair(const Own &O, const Mat m, int Tk, int a_off, int x_off, i
             d1[r] = stream_ld(O.img, lo, co + (16 + r) * m.stride);
         }
     }
-    F4 b = F4{0.f, 0.f, 0.f, 0.f};
-    if (XSRC == 2) b = ld4(aux + AUX_BM + (16 * Tk + i) * 4);
+    (void)aux;
     // software pipeline over the block's tiles, two tiles per trip with ping-pong operand sets (no register rotation):
     // the LDS reads (and, for the embedding, the sines) of the next tile are issued before the 8 MFMAs of this one
     struct Ops { f32x4 a0, a1, x; };
@@ -489,15 +531,7 @@ NSR_DEV void own_pair(const Own &O, const Mat m, int Tk, int a_off, int x_off, i
         Ops o;
         o.a0 = st_load_cm(S + a_off, 0, i, g);
         o.a1 = st_load_cm(S + a_off, 1, i, g);
-        if (XSRC == 2) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const F4 pp = ld4(S + kStP + (4 * g + q) * 4);
-                o.x[q] = sin_acc(fmaf(pp.z, b.z, fmaf(pp.y, b.y, pp.x * b.x)));
-            }
-        } else {
-            o.x = st_load_cm(S + x_off, x_sub, i, g);
-        }
+        o.x = st_load_cm(S + x_off, x_sub, i, g);
         return o;
     };
     auto fmas = [&](const Ops &o) {
@@ -541,18 +575,15 @@ NSR_DEV void own_embed_pair(const Own &O, const Mat m0, const Mat m3, int Tk, in
             d31[r] = stream_ld(O.img, lo3, co3 + (16 + r) * m3.stride);
         }
     }
-    const F4 b = ld4(aux + AUX_BM + (16 * Tk + i) * 4);
+    const F4 b = load_b1(aux, 16 * Tk + i);
     struct Ops { f32x4 p0, p1, q0, q1, x; };
     auto fetch = [&](int t) {
         const float *S = O.stg + (t < O.nw ? t : O.nw - 1) * O.stride;
         Ops o;
         o.p0 = st_load_cm(S + a0_off, 0, i, g); o.p1 = st_load_cm(S + a0_off, 1, i, g);
         o.q0 = st_load_cm(S + a3_off, 0, i, g); o.q1 = st_load_cm(S + a3_off, 1, i, g);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const F4 pp = ld4(S + kStP + (4 * g + q) * 4);
-            o.x[q] = sin_acc(fmaf(pp.z, b.z, fmaf(pp.y, b.y, pp.x * b.x)));
-        }
+        const f32x4 px = to_v(ld4(S + kStP + 4 * g)), py = to_v(ld4(S + kStP + 16 + 4 * g)), pz = to_v(ld4(S + kStP + 32 + 4 * g));
+        o.x = sin_acc4(vfma(pz, splat(b.z), vfma(py, splat(b.y), px * splat(b.x))));       // points 4g .. 4g+3
         return o;
     };
     auto fmas = [&](const Ops &o) {
@@ -627,12 +658,11 @@ NSR_DEV void own_dB(const Own &O, int Tk, int boff) {
     float sx = 0.f, sy = 0.f, sz = 0.f;
     for (int t = 0; t < O.nw; ++t) {
         const float *S = O.stg + t * O.stride;
+        const f32x4 px = to_v(ld4(S + kStP + 4 * pg)), py = to_v(ld4(S + kStP + 16 + 4 * pg)), pz = to_v(ld4(S + kStP + 32 + 4 * pg));
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int p = 4 * pg + q;
-            const float v = S[kStA0 + p * 96 + ch];
-            const F4 pp = ld4(S + kStP + p * 4);
-            sx = fmaf(v, pp.x, sx); sy = fmaf(v, pp.y, sy); sz = fmaf(v, pp.z, sz);
+            const float v = S[kStA0 + (4 * pg + q) * 96 + ch];
+            sx = fmaf(v, px[q], sx); sy = fmaf(v, py[q], sy); sz = fmaf(v, pz[q], sz);
         }
     }
     sx = red_g(sx); sy = red_g(sy); sz = red_g(sz);
@@ -658,7 +688,7 @@ NSR_DEV void relu_plain(f32x4 (&acc)[2]) {
 #pragma unroll
     for (int T = 0; T < 2; ++T)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[T][r] = fmaxf(acc[T][r], 0.f);
+        for (int r = 0; r < 4; ++r) acc[T][r] = relu1(acc[T][r]);
 }
 NSR_DEV Act<2> apply_mask(const Act<2> &d, unsigned m) {
     Act<2> o;
@@ -669,46 +699,14 @@ NSR_DEV Act<2> apply_mask(const Act<2> &d, unsigned m) {
     return o;
 }
 
-// sin / cos for Fourier arguments |x| up to a few thousand: two-constant Cody-Waite reduction by pi (exact products
-// through fma) to r in [-pi/2, pi/2], one odd minimax polynomial of degree 9 there (3.3e-9 in exact arithmetic, ~1.5e-7
-// evaluated in fp32: the same class as libm sinf), sign from the parity of the quotient; branch-free, 13 VALU operations.
-NSR_DEV float sin_poly(float r, unsigned sign) {
-    const float r2 = r * r;
-    float p = fmaf(r2, 2.59048850e-06f, -1.98008978e-04f);
-    p = fmaf(p, r2, 8.33289982e-03f);
-    p = fmaf(p, r2, -1.66666476e-01f);
-    const float s = fmaf(p * r2, r, r);
-    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s) ^ sign);
-}
-// quotient by the "1.5 * 2^23" trick: t = x/pi + 12582912 has round(x/pi) in its low mantissa bits (|x| < 1e7), so
-// its parity is bit 0 of the float and no float->int conversion / compare / select is needed for the sign
-NSR_DEV float sin_acc(float x) {
-    const float t = fmaf(x, 0.318309886183790672f, 12582912.f);
-    const float k = t - 12582912.f;
-    float r = fmaf(k, -3.14159274101257324f, x);
-    r = fmaf(k, 8.74227765734758577e-08f, r);
-    return sin_poly(r, __builtin_bit_cast(unsigned, t) << 31);
-}
-// cos(x) = -(-1)^k sin(r) with x = (k + 1/2) pi + r
-NSR_DEV float cos_acc(float x) {
-    const float t = fmaf(x, 0.318309886183790672f, -0.5f) + 12582912.f;     // (12582912 - 0.5 is not representable)
-    const float k = t - 12582912.f;
-    float r = fmaf(k, -3.14159274101257324f, x);
-    r = fmaf(k, 8.74227765734758577e-08f, r);
-    r = (r - 1.57079637050628662f) + 4.37113882867379289e-08f;
-    return sin_poly(r, (__builtin_bit_cast(unsigned, t) << 31) ^ 0x80000000u);
-}
-
 NSR_DEV void embed(Act<kET> &e, const float *aux, float px, float py, float pz, int g) {
 #pragma unroll
-    for (int T = 0; T < kET; ++T)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const F4 b = ld4(aux + AUX_BM + (16 * T + 4 * g + r) * 4);
-            const float arg = fmaf(pz, b.z, fmaf(py, b.y, px * b.x));     // decoder.py:29
-            e.t[T][r] = sin_acc(arg);                                       // decoder.py:30
-            if (r == 3) sched_fence();      // bound the ILP the scheduler extracts from 24 independent sines
-        }
+    for (int T = 0; T < kET; ++T) {
+        const B4 b = load_b4(aux, 4 * T + g);
+        const f32x4 arg = vfma(splat(pz), b.z, vfma(splat(py), b.y, splat(px) * b.x));     // decoder.py:29
+        e.t[T] = sin_acc4(arg);                                                            // decoder.py:30
+        sched_fence();                  // bound the ILP the scheduler extracts from 24 independent sines
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -743,7 +741,8 @@ NSR_DEV void mlp_xyz_fwd(const float *pk, const float *aux, float px, float py, 
         } else {
             gemv_fwd<2>(acc, h, pk + xyz_mat(CD, i == 1 ? XW1 : (i == 2 ? XW2 : XW4)).pk, lane);
         }
-        const unsigned m = relu_mask(acc);
+        unsigned m = 0;
+        if (KEEP) m = relu_mask(acc); else relu_plain(acc);
         acc[0] += to_v(ld4(aux + AUX_V + i * 32 + 4 * g));
         acc[1] += to_v(ld4(aux + AUX_V + i * 32 + 16 + 4 * g));
         gemv_fwd<NTC>(acc, c, pk + xyz_mat(CD, i == 0 ? XU0 : (i == 1 ? XU1 : (i == 2 ? XU2 : (i == 3 ? XU3 : XU4)))).pk, lane);
@@ -1080,7 +1079,7 @@ NSR_DEV void mlp_xyz_bwd(const float *pk, const float *aux, const Own &O, float 
     }
     if (F.params) {
         if (g == 0) {
-            st4(S + kStP + i16 * 4, F4{px, py, pz, 0.f});
+            S[kStP + i16] = px; S[kStP + 16 + i16] = py; S[kStP + 32 + i16] = pz;       // [xyz][16 points]
             st4(S + kStDO + i16 * 4, F4{d_out[0], NOUT > 1 ? d_out[NOUT > 1 ? 1 : 0] : 0.f, NOUT > 2 ? d_out[NOUT > 2 ? 2 : 0] : 0.f,
                                         NOUT > 3 ? d_out[NOUT > 3 ? 3 : 0] : 0.f});
         }
@@ -1128,13 +1127,11 @@ NSR_DEV void mlp_xyz_bwd(const float *pk, const float *aux, const Own &O, float 
                 }
             sched_fence();
             dE += dE2;
-            f32x4 darg;
+            const B4 b = load_b4(aux, 4 * Tk + g);
+            const f32x4 darg = dE * cos_acc4(vfma(splat(pz), b.z, vfma(splat(py), b.y, splat(px) * b.x)));
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const F4 b = ld4(aux + AUX_BM + (16 * Tk + 4 * g + r) * 4);
-                const float arg = fmaf(pz, b.z, fmaf(py, b.y, px * b.x));
-                darg[r] = dE[r] * cos_acc(arg);
-                ax = fmaf(darg[r], b.x, ax); ay = fmaf(darg[r], b.y, ay); az = fmaf(darg[r], b.z, az);
+                ax = fmaf(darg[r], b.x[r], ax); ay = fmaf(darg[r], b.y[r], ay); az = fmaf(darg[r], b.z[r], az);
             }
             if (need_dB) st4(S + kStA0 + i16 * 96 + 16 * Tk + 4 * g, to_F4(darg));     // [16][96] over A0|A1|X0
         }

@@ -120,7 +120,7 @@ constexpr int AUX_B = 0;       // b[5][32]   pts_linears biases
 constexpr int AUX_V = 160;     // v[5][32]   fc_c biases (xyz only)
 constexpr int AUX_WO = 320;    // wo[4][32]  output weights (rows >= nout are zero)
 constexpr int AUX_BO = 448;    // bo[4]
-constexpr int AUX_BM = 452;    // Bm[96][4]  Fourier matrix as (Bx,By,Bz,0) per channel (xyz only)
+constexpr int AUX_BM = 452;    // Bm[24][4][4]  Fourier matrix: per group of 4 channels Bx[4] | By[4] | Bz[4] | 0
 constexpr int AUX_FLOATS = 452 + 96 * 4;   // 836
 
 }  // namespace nsr
