@@ -95,7 +95,8 @@ typedef struct nsr_bwd_args {
     float *workspace;         /* nsr_bwd_workspace_floats() floats, contents undefined */
     int64_t workspace_floats;
     int32_t max_blocks;       /* persistent-grid cap used to size the workspace (0 = library default) */
-    int32_t pad_;
+    int32_t overwrite_dparams; /* 0: every nsr_decoder.dparams is ACCUMULATED into (autograd semantics, caller-zeroed for a
+                                 fresh gradient); 1: it is OVERWRITTEN (saves the caller the zero fill) */
     void *ev_start;           /* optional hipEvent_t pair recorded on `stream` right before / after the main   */
     void *ev_stop;            /* backward kernel (excludes the small partial-sum kernels); NULL = no timing      */
 } nsr_bwd_args;

@@ -44,7 +44,7 @@ class NsrBwdArgs(C.Structure):
     _fields_ = [("d_depth", C.c_void_p), ("d_var", C.c_void_p), ("d_rgb", C.c_void_p), ("depth", C.c_void_p),
                 ("d_rays_o", C.c_void_p), ("d_rays_d", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
-                ("max_blocks", C.c_int32), ("pad_", C.c_int32),
+                ("max_blocks", C.c_int32), ("overwrite_dparams", C.c_int32),
                 ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
 
 

@@ -17,6 +17,14 @@ def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+def _as_f32c(t: torch.Tensor, device=None) -> torch.Tensor:
+    """fp32, contiguous, on `device` -- without touching tensors that already are (each no-op `.to()` / `.contiguous()`
+    is microseconds of host time, and the mapping loop makes dozens of them per iteration)."""
+    if t.dtype is not torch.float32 or (device is not None and t.device != device):
+        t = t.to(device=device if device is not None else t.device, dtype=torch.float32)
+    return t if t.is_contiguous() else t.contiguous()
+
+
 def _require_cuda(t: torch.Tensor, what: str):
     if not t.is_cuda:
         raise _capi.NsrError(f"{what} must live on an AMD GPU (got {t.device}); nice_slam_amd has no CPU path")
@@ -89,7 +97,7 @@ class _GetSamplesFn(torch.autograd.Function):
         rays_d = torch.empty((n, 3), dtype=torch.float32, device=dev)
         s_depth = torch.empty((n,), dtype=torch.float32, device=dev)
         s_color = torch.empty((n, 3), dtype=torch.float32, device=dev)
-        c2w_c = c2w.detach().to(device=dev, dtype=torch.float32).contiguous()
+        c2w_c = _as_f32c(c2w.detach(), dev)
         lib.check(lib.nsr_get_samples(indices.data_ptr(), n, H0, H1, W0, W1, depth.shape[1], fx, fy, cx, cy,
                                       c2w_c.data_ptr(), c2w_c.stride(0), depth.data_ptr(), color.data_ptr(),
                                       rays_o.data_ptr(), rays_d.data_ptr(), s_depth.data_ptr(), s_color.data_ptr(),
@@ -119,17 +127,19 @@ def get_samples(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, c2w, depth, color, devi
     everything after the draw is one fused kernel."""
     if isinstance(c2w, np.ndarray):
         c2w = torch.from_numpy(c2w).to(device)
-    depth = depth.to(device=device)
-    color = color.to(device=device)
+    if not depth.is_cuda:
+        depth = depth.to(device=device)
+    if not color.is_cuda:
+        color = color.to(device=device)
     _require_cuda(depth, "get_samples: depth image")
-    indices = torch.randint((H1 - H0) * (W1 - W0), (n,), device=device)
+    indices = torch.randint((H1 - H0) * (W1 - W0), (n,), device=depth.device)
     return samples_from_indices(indices, H0, H1, W0, W1, fx, fy, cx, cy, c2w, depth, color)
 
 
 def samples_from_indices(indices, H0, H1, W0, W1, fx, fy, cx, cy, c2w, depth, color):
-    depth = depth.to(torch.float32).contiguous()
-    color = color.to(torch.float32).contiguous()
-    return _GetSamplesFn.apply(c2w, indices.contiguous(), depth, color, int(H0), int(H1), int(W0), int(W1),
+    depth = _as_f32c(depth)
+    color = _as_f32c(color, depth.device)
+    return _GetSamplesFn.apply(c2w, indices if indices.is_contiguous() else indices.contiguous(), depth, color, int(H0), int(H1), int(W0), int(W1),
                                float(fx), float(fy), float(cx), float(cy))
 
 

@@ -211,7 +211,7 @@ int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream
         const int first = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE;
         const int last = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : P.stage;
         nsr::ReduceParams R;
-        R.nblocks = nblk; R.stride = P.partial_stride;
+        R.nblocks = nblk; R.stride = P.partial_stride; R.overwrite = b->overwrite_dparams ? 1 : 0;
         int rows = 0, nmax = 0;
         for (int s = first; s <= last; ++s) {
             if (!P.dec[s].dparams) continue;

@@ -1422,6 +1422,7 @@ struct ReduceJob {
 struct ReduceParams {
     ReduceJob job[3];
     int nblocks, stride;
+    int overwrite;           // 1: dparams = sum (no caller-side zero fill needed), 0: dparams += sum
 };
 NSR_KERNEL void reduce_partials_kernel(const ReduceParams R) {
     const ReduceJob J = R.job[bid_y()];
@@ -1436,7 +1437,7 @@ NSR_KERNEL void reduce_partials_kernel(const ReduceParams R) {
     block_sync();
     if (slice == 0 && t < J.n) {
         for (int k = 1; k < nslice; ++k) s += red[k * 64 + lane];
-        J.dparams[t] += s;
+        J.dparams[t] = R.overwrite ? s : J.dparams[t] + s;
     }
 }
 

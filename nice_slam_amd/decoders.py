@@ -35,6 +35,7 @@ class _FlatDecoder(nn.Module):
         self._spec = param_spec(self.slot)
         self._flat = torch.zeros(sum(math.prod(s) for _, s in self._spec), dtype=torch.float32)
         self._grad_flat: Optional[torch.Tensor] = None
+        self._grad_views = None
         self._packed = None                                 # (key, tensor) cache of the MFMA operand stream
         self._build_modules()
         self.reset_parameters()
@@ -103,6 +104,7 @@ class _FlatDecoder(nn.Module):
                 p.data = f[off:off + p.numel()].view(p.shape)
             self._flat = f
             self._grad_flat = None
+            self._grad_views = None
             self._packed = None
         return self._flat
 
@@ -126,6 +128,42 @@ class _FlatDecoder(nn.Module):
     def wants_grad(self) -> bool:
         return any(p.requires_grad for p in self._views)
 
+    # -- parameter gradients ---------------------------------------------------------------------------
+    # The backward kernel reduces a decoder's gradient into one flat blob.  Exposing it as ~30 fresh `.grad` views per
+    # decoder per iteration (slice + view + assignment each) costs more host time than the kernel takes, so the blob is a
+    # persistent buffer with its per-Parameter views built once:
+    #   * every .grad is None (optimizer.zero_grad(set_to_none=True), the torch default): the kernel OVERWRITES the blob,
+    #     the cached views are assigned afterwards;
+    #   * every .grad already is its cached view (zero_grad(set_to_none=False), or deliberate accumulation): the kernel
+    #     ACCUMULATES into the blob -- autograd's semantics -- and nothing is assigned;
+    #   * anything else (foreign .grad tensors): the caller falls back to a temporary blob + publish_grads().
+    def grad_target(self):
+        """-> (flat gradient buffer, mode) with mode in {"overwrite", "accumulate"}, or (None, None) for the fallback."""
+        f = self.flat_params()
+        if self._grad_flat is None or self._grad_flat.device != f.device:
+            self._grad_flat = torch.zeros_like(f)
+            self._grad_views = [self._grad_flat[off:off + p.numel()].view(p.shape) for p, off in zip(self._views, self._offsets)]
+        n = n_none = n_ours = 0
+        for p, v in zip(self._views, self._grad_views):
+            if p.requires_grad:
+                n += 1
+                g = p.grad
+                if g is None:
+                    n_none += 1
+                elif g is v:
+                    n_ours += 1
+        if n_none == n:
+            return self._grad_flat, "overwrite"
+        if n_ours == n:
+            return self._grad_flat, "accumulate"
+        return None, None
+
+    def grad_done(self, mode: str):
+        if mode == "overwrite":
+            for p, v in zip(self._views, self._grad_views):
+                if p.requires_grad:
+                    p.grad = v
+
     def publish_grads(self, gflat: torch.Tensor):
         """Expose a freshly computed flat gradient as the ``.grad`` of every Parameter (views, no copies)."""
         for p, off in zip(self._views, self._offsets):
@@ -144,7 +182,7 @@ class _FlatDecoder(nn.Module):
         new.name, new.bound = self.name, (None if self.bound is None else self.bound.clone())
         new._spec = self._spec
         new._flat = self.flat_params().detach().clone()
-        new._grad_flat, new._packed = None, None
+        new._grad_flat, new._grad_views, new._packed = None, None, None
         new._build_modules()
         for a, b in zip(new._views, self._views):
             a.requires_grad_(b.requires_grad)

@@ -12,7 +12,7 @@ from typing import Dict, Optional
 import torch
 
 from . import _capi
-from .common import _require_cuda, _stream, get_rays, to_channels_last
+from .common import _as_f32c, _require_cuda, _stream, get_rays, to_channels_last
 from .layout import param_count, stage_slots
 
 _SLOT_IDX = {s: i for i, s in enumerate(_capi.SLOT_NAMES)}
@@ -89,6 +89,19 @@ def eval_points_raw(p: torch.Tensor, decoders, c: Dict[str, torch.Tensor], stage
     return out
 
 
+_GATES = {}
+
+
+def _gate(dev, want: bool) -> torch.Tensor:
+    """0-dim tensor whose only job is to tell _RenderFn (via needs_input_grad) whether a decoder wants parameter
+    gradients; one per (device, flag) for the life of the process instead of a fill kernel per decoder per call."""
+    key = (dev, want)
+    g = _GATES.get(key)
+    if g is None:
+        g = _GATES[key] = torch.zeros((), device=dev, requires_grad=want)
+    return g
+
+
 class _RenderFn(torch.autograd.Function):
     """inputs: rays_o, rays_d, then one grid per decoder of the stage, then one 0-dim 'gate' tensor per
     decoder (requires_grad iff that decoder's parameters do).  Parameter gradients are published straight
@@ -155,7 +168,22 @@ class _RenderFn(torch.autograd.Function):
         # the dense grid gradients, then the ray gradients, then the flat decoder-gradient blob
         need_ray = need_o or need_d
         n_grid = [grids[s].numel() if need else 0 for s, need in zip(slots, need_grid)]
-        n_par = [param_count(s) if need else 0 for s, need in zip(slots, need_par)]
+        # decoder gradients: straight into each decoder's persistent blob when possible (see _FlatDecoder.grad_target);
+        # the multi-GPU path and foreign .grad tensors use a temporary blob inside the fused buffer
+        direct = {}
+        if reduce_hook is None:
+            for s, need in zip(slots, need_par):
+                if need:
+                    tgt, mode = decoders.sub(s).grad_target()
+                    if tgt is not None:
+                        direct[s] = (tgt, mode)
+            modes = {m for _, m in direct.values()}
+            if len(modes) > 1:                                    # mixed: make everything "accumulate"
+                for s, (tgt, mode) in list(direct.items()):
+                    if mode == "overwrite":
+                        tgt.zero_()
+            b.overwrite_dparams = 1 if modes == {"overwrite"} else 0
+        n_par = [param_count(s) if (need and s not in direct) else 0 for s, need in zip(slots, need_par)]
         buf = torch.zeros((sum(n_grid) + (6 * n if need_ray else 0) + sum(n_par),), dtype=torch.float32, device=dev)
         off = 0
         d_grids = []
@@ -179,11 +207,14 @@ class _RenderFn(torch.autograd.Function):
         gflat = None
         offs = {}
         if any(need_par):
-            gflat = buf[off:off + sum(n_par)]
+            if sum(n_par):
+                gflat = buf[off:off + sum(n_par)]
             poff = 0
-            for s, cnt in zip(slots, n_par):
+            for s, cnt, need in zip(slots, n_par, need_par):
                 i = _SLOT_IDX[s]
-                if cnt:
+                if s in direct:
+                    a.dec[i].dparams = direct[s][0].data_ptr()
+                elif cnt:
                     offs[s] = poff
                     a.dec[i].dparams = gflat.data_ptr() + 4 * poff
                     poff += cnt
@@ -203,7 +234,10 @@ class _RenderFn(torch.autograd.Function):
             reduce_hook([g for g in d_grids if g is not None], gflat)
         for s, need in zip(slots, need_par):
             if need:
-                decoders.sub(s).publish_grads(gflat[offs[s]:offs[s] + param_count(s)])
+                if s in direct:
+                    decoders.sub(s).grad_done(direct[s][1])
+                else:
+                    decoders.sub(s).publish_grads(gflat[offs[s]:offs[s] + param_count(s)])
         ctx.keep = ctx.args = None
         return (None, d_o if need_o else None, d_d if need_d else None, *d_grids, *([None] * len(slots)))
 
@@ -274,10 +308,10 @@ class Renderer(object):
         if stage == "coarse":
             gt_depth = None
         slots = stage_slots(stage)
-        rays_o = rays_o.to(torch.float32).contiguous()
-        rays_d = rays_d.to(torch.float32).contiguous()
+        rays_o = _as_f32c(rays_o)
+        rays_d = _as_f32c(rays_d, dev)
         if gt_depth is not None:
-            gt_depth = gt_depth.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+            gt_depth = _as_f32c(gt_depth.detach().reshape(-1), dev)
         if rays_o.shape[0] == 0:                 # empty batch (e.g. every ray removed by the caller's AABB pre-filter)
             z = (rays_o.sum() + rays_d.sum()) * 0.0  # keeps the graph connected
             return (torch.zeros((0,), dtype=torch.float64, device=dev) + z, torch.zeros((0,), dtype=torch.float64, device=dev) + z,
@@ -287,7 +321,7 @@ class Renderer(object):
         for s in slots:
             want = torch.is_grad_enabled() and decoders.sub(s).wants_grad() and \
                 (self.decoder_grads is None or s in self.decoder_grads)
-            gates.append(torch.zeros((), device=dev, requires_grad=True) if want else torch.zeros((), device=dev))
+            gates.append(_gate(dev, want))
         meta = (self, decoders, stage, gt_depth, self._reduce_hook)
         return _RenderFn.apply(meta, rays_o, rays_d, *[grids[s] for s in slots], *gates)
 

@@ -128,7 +128,8 @@ class HostScene:
         out["_ctx"] = (a, keep, rays_o, rays_d, gt, S)
         return out
 
-    def backward(self, stage, fwd, d_depth, d_var, d_rgb, want_grid=True, want_params=True, want_rays=True, max_blocks=0):
+    def backward(self, stage, fwd, d_depth, d_var, d_rgb, want_grid=True, want_params=True, want_rays=True, max_blocks=0,
+                 overwrite_dparams=False):
         a, keep, rays_o, rays_d, gt, S = fwd["_ctx"]
         n = rays_o.shape[0]
         res = {}
@@ -140,7 +141,7 @@ class HostScene:
                 res["d_grid_" + s] = np.zeros_like(self.grids[s])
                 a.grid[i].dfeat = ptr(res["d_grid_" + s])
             if want_params:
-                res["d_flat_" + s] = np.zeros_like(self.flat[s])
+                res["d_flat_" + s] = np.full_like(self.flat[s], np.nan) if overwrite_dparams else np.zeros_like(self.flat[s])
                 a.dec[i].dparams = ptr(res["d_flat_" + s])
         b = _capi.NsrBwdArgs()
         dd = np.ascontiguousarray(d_depth, dtype=np.float64)
@@ -154,6 +155,7 @@ class HostScene:
         nws = self.lib.nsr_bwd_workspace_floats(_capi.STAGE_ID[stage], n, S, max_blocks)
         ws = np.full(max(nws, 1), np.nan, dtype=np.float32)
         b.workspace, b.workspace_floats, b.max_blocks = ptr(ws), nws, max_blocks
+        b.overwrite_dparams = 1 if overwrite_dparams else 0
         self.lib.check(self.lib.nsr_render_bwd(C.byref(a), C.byref(b), None), "bwd")
         for s in stage_slots(stage):       # back to reference layouts
             if want_grid:

@@ -72,6 +72,12 @@ def test_random_scene_against_oracle(emu, stage, n):
         if k in ("depth", "var", "rgb"):
             continue
         assert rel_err(res[k], v) < TOL, (stage, k)
+    # nsr_bwd_args.overwrite_dparams: same parameter gradients into a blob that was NOT zeroed (NaN-filled here)
+    res2 = sc.backward(stage, fwd, s["w"]["depth"].numpy(), s["w"]["var"].numpy(), s["w"]["rgb"].numpy(), max_blocks=2,
+                       overwrite_dparams=True)
+    for k, v in res.items():
+        if k.startswith("dparam/"):
+            assert np.array_equal(res2[k], v), (stage, k)
 
 
 def test_backward_flag_subsets(emu):

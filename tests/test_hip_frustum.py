@@ -93,11 +93,11 @@ def test_masked_exchange_single_rank_group():
         assert sh.last_exchange_floats == n_rows * 32 + n_par + grids["grid_middle"].numel()
         assert set(got) == set(ref)
         for k in ref:
-            assert torch.equal(got[k], ref[k]) or rel_err(got[k], ref[k]) < 1e-6, k   # atomics: summation order may differ
+            assert torch.equal(got[k], ref[k]) or rel_err(got[k], ref[k]) < 1e-5, k   # atomics: summation order may differ
         sh.set_voxel_masks(None)
         got = hip_render(sc, "fine", DEV, backward=True, product=(sh, dec, grids))
         ref = hip_render(sc, "fine", DEV, backward=True, product=product)
         for k in ref:
-            assert rel_err(got[k], ref[k]) < 1e-6, k
+            assert rel_err(got[k], ref[k]) < 1e-5, k          # two GPU runs: fp32 atomics add in a different order
     finally:
         dist.destroy_process_group()

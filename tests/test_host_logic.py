@@ -107,3 +107,38 @@ def test_renderer_rejects_imap_configuration():
     assert r2.N_samples == 32 and r2._ws == {}
     with pytest.raises(NotImplementedError):
         r.regulation(None, None, None, None, None, "cpu")
+
+
+def test_grad_target_state_machine():
+    """persistent gradient blob: overwrite when every .grad is None, accumulate when every .grad is the cached view,
+    fallback (None) for foreign .grad tensors; the views survive across calls, are rebuilt after .to()/deepcopy."""
+    import copy
+    dec = nsa.NICE(coarse=False)
+    sub = dec.color_decoder
+    flat, mode = sub.grad_target()
+    assert mode == "overwrite" and flat.numel() == param_count("color")
+    flat.copy_(torch.arange(flat.numel(), dtype=torch.float32))
+    sub.grad_done(mode)
+    off = 0
+    for p in sub.parameters():
+        assert p.grad.data_ptr() == flat.data_ptr() + 4 * off and torch.equal(p.grad.reshape(-1), flat[off:off + p.numel()])
+        off += p.numel()
+    views = [p.grad for p in sub.parameters()]
+    flat2, mode2 = sub.grad_target()
+    assert mode2 == "accumulate" and flat2 is flat
+    sub.grad_done(mode2)
+    assert all(a is b for a, b in zip(views, (p.grad for p in sub.parameters())))
+    for p in sub.parameters():                        # optimizer.zero_grad(set_to_none=True)
+        p.grad = None
+    assert sub.grad_target()[1] == "overwrite"
+    next(sub.parameters()).grad = torch.zeros_like(next(sub.parameters()))      # a foreign gradient tensor
+    assert sub.grad_target() == (None, None)
+    for p in sub.parameters():
+        p.grad = None
+    sub.output_linear.weight.requires_grad_(False)    # frozen parameters are ignored by the state test and get no .grad
+    flat3, mode3 = sub.grad_target()
+    sub.grad_done(mode3)
+    assert sub.output_linear.weight.grad is None and sub.output_linear.bias.grad is not None
+    cp = copy.deepcopy(sub)
+    f4, m4 = cp.grad_target()
+    assert m4 == "overwrite" and f4.data_ptr() != flat.data_ptr()
