@@ -165,7 +165,7 @@ def hip_render(sc, stage, device="cuda:0", backward=False, with_depth=True, rays
                 out["d_" + k] = v.grad
         for k, p in dec.named_parameters():
             if p.grad is not None:
-                out["dparam/" + k] = p.grad
+                out["dparam/" + k] = p.grad.clone()       # .grad is a view of the decoder's persistent gradient blob
     torch.cuda.synchronize()
     return out
 
