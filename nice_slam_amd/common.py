@@ -89,19 +89,23 @@ class _GetSamplesFn(torch.autograd.Function):
     """indices -> (rays_o, rays_d, depth, color); differentiable w.r.t. c2w (tracking / BA)."""
 
     @staticmethod
-    def forward(ctx, c2w, indices, depth, color, H0, H1, W0, W1, fx, fy, cx, cy):
+    def run(c2w, indices, depth, color, H0, H1, W0, W1, fx, fy, cx, cy):
         lib = _capi.get_lib()
         n = indices.shape[0]
         dev = depth.device
-        rays_o = torch.empty((n, 3), dtype=torch.float32, device=dev)
-        rays_d = torch.empty((n, 3), dtype=torch.float32, device=dev)
-        s_depth = torch.empty((n,), dtype=torch.float32, device=dev)
-        s_color = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        buf = torch.empty((10 * n,), dtype=torch.float32, device=dev)       # one allocation: o | d | depth | colour
+        rays_o, rays_d = buf[:3 * n].view(n, 3), buf[3 * n:6 * n].view(n, 3)
+        s_depth, s_color = buf[6 * n:7 * n], buf[7 * n:].view(n, 3)
         c2w_c = _as_f32c(c2w.detach(), dev)
         lib.check(lib.nsr_get_samples(indices.data_ptr(), n, H0, H1, W0, W1, depth.shape[1], fx, fy, cx, cy,
                                       c2w_c.data_ptr(), c2w_c.stride(0), depth.data_ptr(), color.data_ptr(),
                                       rays_o.data_ptr(), rays_d.data_ptr(), s_depth.data_ptr(), s_color.data_ptr(),
                                       _stream(dev)), "nsr_get_samples")
+        return rays_o, rays_d, s_depth, s_color
+
+    @staticmethod
+    def forward(ctx, c2w, indices, depth, color, H0, H1, W0, W1, fx, fy, cx, cy):
+        rays_o, rays_d, s_depth, s_color = _GetSamplesFn.run(c2w, indices, depth, color, H0, H1, W0, W1, fx, fy, cx, cy)
         ctx.geom = (H0, W0, W1 - W0, fx, fy, cx, cy, tuple(c2w.shape), c2w.dtype, c2w.device)
         ctx.save_for_backward(indices)
         ctx.mark_non_differentiable(s_depth, s_color)
@@ -139,8 +143,11 @@ def get_samples(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, c2w, depth, color, devi
 def samples_from_indices(indices, H0, H1, W0, W1, fx, fy, cx, cy, c2w, depth, color):
     depth = _as_f32c(depth)
     color = _as_f32c(color, depth.device)
-    return _GetSamplesFn.apply(c2w, indices if indices.is_contiguous() else indices.contiguous(), depth, color, int(H0), int(H1), int(W0), int(W1),
-                               float(fx), float(fy), float(cx), float(cy))
+    args = (c2w, indices if indices.is_contiguous() else indices.contiguous(), depth, color, int(H0), int(H1), int(W0), int(W1),
+            float(fx), float(fy), float(cx), float(cy))
+    if not (torch.is_grad_enabled() and isinstance(c2w, torch.Tensor) and c2w.requires_grad):
+        return _GetSamplesFn.run(*args)               # mapping without BA: nothing to differentiate, skip the autograd node
+    return _GetSamplesFn.apply(*args)
 
 
 def get_rays(H, W, fx, fy, cx, cy, c2w, device):
