@@ -1053,16 +1053,35 @@ struct XyzBwd {
 // dc: gradient w.r.t. the first 32 feature channels (the decoder's own grid).  dp: gradient w.r.t.
 // the fp32 world position through the embedding (already reduced over g).
 // With F.params every wave of the block must call this function (it contains block barriers).
+// Where this lane's d raw comes from: the compositor backward (a few waves of the block) fills `draw` in LDS while the
+// other waves already re-run the decoder forward; `sync` = this is the first use of `draw` in the ray group, so a block
+// barrier has to separate the two.
+struct DrawRef {
+    const F4 *draw;
+    int pidx;
+    bool active, inside, sync;
+};
+NSR_DEV F4 draw_fetch(const DrawRef &R) {
+    if (R.sync) block_sync();
+    F4 dr = R.active ? R.draw[R.pidx] : F4{0.f, 0.f, 0.f, 0.f};
+    if (!R.inside) dr.w = 0.f;                                 // Renderer.py:57 cuts the occupancy gradient
+    return dr;
+}
+
 template <int KIND>
 NSR_DEV void mlp_xyz_bwd(const float *pk, const float *aux, const Own &O, float *S,
                          float px, float py, float pz, const Act<cdim_of(KIND) / 16> &c,
-                         const float (&d_out)[nout_of(KIND)], BwdFlags F, int lane, Act<2> &dc, float (&dp)[3]) {
+                         const DrawRef &R, BwdFlags F, int lane, Act<2> &dc, float (&dp)[3]) {
     constexpr int CD = cdim_of(KIND), NOUT = nout_of(KIND), NTC = CD / 16;
     const int i16 = lane & 15, g = lane >> 4;
     Kept<KIND> K;
     float out[NOUT];
     mlp_xyz_fwd<KIND, true>(pk, aux, px, py, pz, c, lane, out, &K);
     (void)out;
+    const F4 dr = draw_fetch(R);
+    float d_out[NOUT];
+    if (NOUT == 1) { d_out[0] = dr.w; }
+    else { d_out[0] = dr.x; d_out[NOUT > 1 ? 1 : 0] = dr.y; d_out[NOUT > 2 ? 2 : 0] = dr.z; d_out[NOUT > 3 ? 3 : 0] = 0.f; }   // decoder.py:341 overwrites the 4th colour output
 
     // output layer
     Act<2> dh;
@@ -1193,12 +1212,13 @@ struct NoxBwd {
 
 // coarse decoder backward (MLP_no_xyz)
 NSR_DEV void mlp_nox_bwd(const float *pk, const float *aux, const Own &O, float *S,
-                         const Act<2> &c, float d_out, BwdFlags F, int lane, Act<2> &dc) {
+                         const Act<2> &c, const DrawRef &R, BwdFlags F, int lane, Act<2> &dc) {
     const int i16 = lane & 15, g = lane >> 4;
     Kept<0> K;
     float out[1];
     mlp_nox_fwd<true>(pk, aux, c, lane, out, &K);
     (void)out;
+    const float d_out = draw_fetch(R).w;
     Act<2> dh;
 #pragma unroll
     for (int T = 0; T < 2; ++T) {
@@ -1306,7 +1326,9 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
         };
         tile_setup(0);
         // ---- compositor backward: d raw per sample (common.py:231-244 differentiated)
-        for (int r = wave; r < P.rays_per_block; r += nwaves) {
+        // (rays go to waves 2, 3, ... first: with six waves on four SIMDs those two do not share their SIMD, and the
+        // other waves meanwhile start on the decoder forward re-run -- the barrier sits inside mlp_*_bwd, see DrawRef)
+        for (int r = nwaves >= 4 ? (wave + nwaves - 2) % nwaves : wave; r < P.rays_per_block; r += nwaves) {
             const long long ray = ray0 + r;
             if (ray >= P.n_rays) break;
             const bool act = lane < S;
@@ -1333,26 +1355,21 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
             const float docc = 10.f * (dalpha * ((1.f - c.alpha) * c.alpha));
             if (act) draw[r * S + lane] = F4{c.w * gr, c.w * gg, c.w * gb, docc};
         }
-        block_sync();
         for (int sub = 0;;) {   // ---- decoder backward for the tile of this wave
             O.first = first_grp && sub == 0;                       // layer images: stored by the block's first sub-round
-            F4 dr = active ? draw[pidx] : F4{0.f, 0.f, 0.f, 0.f};
-            if (!inside) dr.w = 0.f;                               // Renderer.py:57 cuts the occupancy gradient
+            const DrawRef R{draw, pidx, active, inside, sub == 0};
             Act<2> dc;
             float dpe[3] = {0.f, 0.f, 0.f};
             if (KIND == NSR_COARSE) {
-                mlp_nox_bwd(wl, aux, O, Sw, c, dr.w, F, lane, dc);
+                mlp_nox_bwd(wl, aux, O, Sw, c, R, F, lane, dc);
             } else if (KIND == NSR_MIDDLE) {
-                float d_out[1] = {dr.w};
-                mlp_xyz_bwd<NSR_MIDDLE>(wl, aux, O, Sw, (float)px, (float)py, (float)pz, c, d_out, F, lane, dc, dpe);
+                mlp_xyz_bwd<NSR_MIDDLE>(wl, aux, O, Sw, (float)px, (float)py, (float)pz, c, R, F, lane, dc, dpe);
             } else if (KIND == NSR_FINE) {
                 Act<4> cc;
                 cc.t[0] = c.t[0]; cc.t[1] = c.t[1]; cc.t[2] = cm.t[0]; cc.t[3] = cm.t[1];
-                float d_out[1] = {dr.w};
-                mlp_xyz_bwd<NSR_FINE>(wl, aux, O, Sw, (float)px, (float)py, (float)pz, cc, d_out, F, lane, dc, dpe);
+                mlp_xyz_bwd<NSR_FINE>(wl, aux, O, Sw, (float)px, (float)py, (float)pz, cc, R, F, lane, dc, dpe);
             } else {
-                float d_out[4] = {dr.x, dr.y, dr.z, 0.f};          // decoder.py:341 overwrites the 4th colour output
-                mlp_xyz_bwd<NSR_COLOR>(wl, aux, O, Sw, (float)px, (float)py, (float)pz, c, d_out, F, lane, dc, dpe);
+                mlp_xyz_bwd<NSR_COLOR>(wl, aux, O, Sw, (float)px, (float)py, (float)pz, c, R, F, lane, dc, dpe);
             }
             float dux = 0.f, duy = 0.f, duz = 0.f;
             if (F.rays) coord_grad(G, L, g, dc, dux, duy, duz);
