@@ -499,6 +499,13 @@ struct Own {
     bool first;          // first ray group of this block: store instead of accumulate (no zero-fill needed)
     float *small;        // per-wave LDS accumulators of the output layer: [wave][wo[4][32] | bo[4]]
 };
+// Owner of the t-th task of a phase (tasks listed heaviest first).  With six waves on four SIMDs (waves w and w+4 share
+// one) the first four tasks go to one wave per SIMD, starting with the two waves that have their SIMD to themselves.
+NSR_DEV bool mine(const Own &O, int t) {
+    const int r = t % O.nw;
+    const int w = O.nw == 6 ? ((0x541032 >> (4 * r)) & 0xF) : r;
+    return w == O.wave;
+}
 NSR_DEV void img_add(const Own &O, int lane_off, int const_off, float v) {
     if (!O.first) v += stream_ld(O.img, lane_off, const_off);
     stream_st(O.img, lane_off, const_off, v);
@@ -982,14 +989,6 @@ NSR_KERNEL NSR_BOUNDS(768) void eval_points_kernel(const RenderParams P) {
 // ------------------------------------------------------------------------------------------------
 struct BwdFlags { bool grid, params, rays; };
 
-// running index of the first (matrix, k-tile) pair of layer I in the owner round-robin (layers are visited 4..0)
-constexpr int xyz_pairs(int cd, int I) { return cd / 16 + (I > 0 ? 2 : 0) + (I == 0 ? kET : 0); }
-constexpr int xyz_pair_base(int cd, int I) {
-    int n = 0;
-    for (int j = 4; j > I; --j) n += xyz_pairs(cd, j);
-    return n;
-}
-
 // one layer of the xyz-decoder backward (i = 4..0), instantiated per layer so that every register
 // array index is a compile-time constant
 template <int KIND>
@@ -1022,22 +1021,22 @@ struct XyzBwd {
             if (I > 0) st_store(S + kStX0, K.h[I > 0 ? I - 1 : 0], i16, g);
             else st_store(S + kStX0, dY3, i16, g);                           // layer 0: the W0 / W3e task needs dY3 too
             block_sync();
-            int P = xyz_pair_base(CD, I);
-#pragma unroll
-            for (int Tk = 0; Tk < NTC; ++Tk, ++P)
-                if (P % O.nw == O.wave) own_pair<1>(O, mu, Tk, kStA0, kStC + (Tk >> 1) * 512, Tk & 1, aux);
-            if (I > 0) {
-#pragma unroll
-                for (int Tk = 0; Tk < 2; ++Tk, ++P)
-                    if (P % O.nw == O.wave) own_pair<0>(O, xyz_mat(CD, hid), Tk, kStA1, kStX0, Tk, aux);
-            }
+            int t = 0;                                   // tasks of this phase, heaviest first (see mine())
             if (I == 0) {
 #pragma unroll
-                for (int Tk = 0; Tk < kET; ++Tk, ++P)
-                    if (P % O.nw == O.wave) own_embed_pair(O, xyz_mat(CD, XW0), xyz_mat(CD, XW3E), Tk, kStA1, kStX0, aux);
+                for (int Tk = 0; Tk < kET; ++Tk, ++t)
+                    if (mine(O, t)) own_embed_pair(O, xyz_mat(CD, XW0), xyz_mat(CD, XW3E), Tk, kStA1, kStX0, aux);
             }
-            if ((2 * (4 - I)) % O.nw == O.wave) own_colsum(O, fcb_off(KIND, I), kStA0);
-            if ((2 * (4 - I) + 1) % O.nw == O.wave) own_colsum(O, bias_off(KIND, I), kStA1);
+            if (I > 0) {
+#pragma unroll
+                for (int Tk = 0; Tk < 2; ++Tk, ++t)
+                    if (mine(O, t)) own_pair<0>(O, xyz_mat(CD, hid), Tk, kStA1, kStX0, Tk, aux);
+            }
+#pragma unroll
+            for (int Tk = 0; Tk < NTC; ++Tk, ++t)
+                if (mine(O, t)) own_pair<1>(O, mu, Tk, kStA0, kStC + (Tk >> 1) * 512, Tk & 1, aux);
+            if (mine(O, t)) own_colsum(O, fcb_off(KIND, I), kStA0);
+            if (mine(O, t + 1)) own_colsum(O, bias_off(KIND, I), kStA1);
             block_sync();
         }
         if (I > 0) {
@@ -1160,7 +1159,7 @@ NSR_DEV void mlp_xyz_bwd(const float *pk, const float *aux, const Own &O, float 
         block_sync();
 #pragma unroll
         for (int Tk = 0; Tk < kET; ++Tk)
-            if (Tk % O.nw == O.wave) own_dB(O, Tk, B_off(KIND));
+            if (mine(O, Tk)) own_dB(O, Tk, B_off(KIND));
         block_sync();
     }
 }
@@ -1185,17 +1184,16 @@ struct NoxBwd {
             st_store(S + kStA1, dY, i16, g);
             st_store(S + kStX0, I == 0 ? c : K.h[I > 0 ? I - 1 : 0], i16, g);
             block_sync();
-            // pairs visited 4..0: L4 {0,1}  L3 {2,3 (c part), 4,5 (h part)}  L2 {6,7}  L1 {8,9}  L0 {10,11}
-            int P = I == 4 ? 0 : (I == 3 ? 2 : (I == 2 ? 6 : (I == 1 ? 8 : 10)));
+            int t = 0;
             if (I == 3) {
 #pragma unroll
-                for (int Tk = 0; Tk < 2; ++Tk, ++P)
-                    if (P % O.nw == O.wave) own_pair<1>(O, nox_mat(NW3C), Tk, kStA1, kStC, Tk, nullptr);
+                for (int Tk = 0; Tk < 2; ++Tk, ++t)
+                    if (mine(O, t)) own_pair<1>(O, nox_mat(NW3C), Tk, kStA1, kStC, Tk, nullptr);
             }
 #pragma unroll
-            for (int Tk = 0; Tk < 2; ++Tk, ++P)
-                if (P % O.nw == O.wave) own_pair<0>(O, mh, Tk, kStA1, kStX0, Tk, nullptr);
-            if ((4 - I + 3) % O.nw == O.wave) own_colsum(O, nox_b(I), kStA1);
+            for (int Tk = 0; Tk < 2; ++Tk, ++t)
+                if (mine(O, t)) own_pair<0>(O, mh, Tk, kStA1, kStX0, Tk, nullptr);
+            if (mine(O, t)) own_colsum(O, nox_b(I), kStA1);
             block_sync();
         }
         if (I == 3) gemv_bwd<2>(dc.t, dY, wl + nox_mat(NW3C).pk, i16, g);
