@@ -1382,17 +1382,7 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
             wave_fence();                                      // the scatter is done with this wave's staging region
             tile_setup(sub);
         }
-        O.first = first_grp;                                       // output-layer image: touched once per group
         block_sync();
-        if (F.params) {          // output-layer gradients of the whole block -> gradient image
-            constexpr int NO = nout_of(KIND);
-            const int t = tid();
-            if (t < NO * 32 || (t >= 128 && t < 128 + NO)) {
-                float v = 0.f;
-                for (int w = 0; w < nwaves; ++w) { v += small[w * 132 + t]; small[w * 132 + t] = 0.f; }
-                if (t < 128) img_add(O, t, wo_off(KIND), v); else img_add(O, t - 128, bo_off(KIND), v);
-            }
-        }
         if (F.rays) {
             for (int t = tid(); t < P.rays_per_block * 6; t += nthreads()) {
                 const int r = t / 6, q = t - r * 6, a = q % 3;
@@ -1407,6 +1397,16 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
             }
         }
         block_sync();
+    }
+    if (F.params) {              // output-layer gradients: the per-wave slots were accumulated over all ray groups of the block
+        constexpr int NO = nout_of(KIND);
+        const Stream st = make_stream(img);
+        const int t = tid();
+        if (t < NO * 32 || (t >= 128 && t < 128 + NO)) {
+            float v = 0.f;
+            for (int w = 0; w < nwaves; ++w) v += small[w * 132 + t];
+            if (t < 128) stream_st(st, t, wo_off(KIND), v); else stream_st(st, t - 128, bo_off(KIND), v);
+        }
     }
 }
 
