@@ -32,9 +32,26 @@ BWD_COLOR_FLOP_PER_RAY = (106140 - 51653) * 2 * 48
 FWD_FLOP_PER_RAY = {"middle": 15479 * 2 * 48, "fine": 36078 * 2 * 48, "color": 51653 * 2 * 48}
 
 
+def _stage_cycle(n=60):
+    """The 60 iterations of one optimize_map call (middle while it <= 0.4 n, fine while it <= 0.6 n, then colour:
+    src/Mapper.py:402-410 -> 25 / 12 / 23), interleaved evenly so that ANY window of K timed steps carries the same mix."""
+    counts = {"middle": 0, "fine": 0, "color": 0}
+    for it in range(n):
+        counts["middle" if it <= int(n * 0.4) else ("fine" if it <= int(n * 0.6) else "color")] += 1
+    done = {k: 0 for k in counts}
+    seq = []
+    for i in range(1, n + 1):                       # largest deficit first (weighted round-robin)
+        k = max(counts, key=lambda s: (counts[s] * i / n - done[s], counts[s]))
+        done[k] += 1
+        seq.append(k)
+    return seq
+
+
+_CYCLE = _stage_cycle()
+
+
 def stage_of(it, n=60):
-    it = it % n
-    return "middle" if it <= int(n * 0.4) else ("fine" if it <= int(n * 0.6) else "color")
+    return _CYCLE[it % n]
 
 
 class HipEvents:
@@ -100,6 +117,12 @@ def main():
     ap.add_argument("--dense-exchange", action="store_true",
                     help="multi-GPU: all-reduce the whole feature-grid gradients instead of the frustum-selected voxel rows")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line, the result JSON: anything a library prints there (RCCL's version banner, ...) is
+    # sent to stderr by pointing file descriptor 1 at it; the JSON goes to the saved original descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -172,7 +195,7 @@ def main():
 
     # Warm-up: eager iterations.  First untimed ones (code load, allocator, LDS attribute), then 5 per stage with HIP
     # events around the backward kernel -- these feed `roofline` / `kernel_ms`.
-    reps = (0, 30, 59) if args.stage is None else (0,)
+    reps = tuple(_CYCLE.index(k) for k in ("middle", "fine", "color")) if args.stage is None else (0,)
     for i in range(max(args.warmup, 2 * len(reps))):
         step(reps[i % len(reps)], False)
     torch.cuda.synchronize()
@@ -266,7 +289,8 @@ def main():
         res["kernel_ms"] = {f"render_bwd<{s}>": round(v[0], 4) for s, v in ksum.items()}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(sc)
-        print(json.dumps(res))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     if world > 1 or force_dist:
         dist.destroy_process_group()
 
