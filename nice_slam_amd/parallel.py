@@ -2,7 +2,7 @@
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Every rank holds the same
 ray batch, grids and decoders (replicated), renders a contiguous block of N/W rays and
-  * all-gathers the 28 B/ray outputs so the caller's loss code runs unchanged on the full batch,
+  * all-gathers the 28 B/ray outputs (one collective) so the caller's loss code runs unchanged on the full batch,
   * sums the feature-grid gradients and the flat decoder-parameter gradients: dense in-place all-reduces, or -- with
     the frame's frustum voxel masks set -- ONE all-reduce over the compacted rows of the selected voxels,
   * all-gathers the per-ray gradients (pose optimisation in BA).
@@ -38,17 +38,25 @@ class _ShardRows(torch.autograd.Function):
         return _all_gather_rows(g.contiguous(), ctx.sizes, ctx.group), None, None, None, None
 
 
-class _GatherRows(torch.autograd.Function):
-    """all-gather of row blocks; backward keeps this rank's block (every rank computes the same loss)."""
+class _GatherOutputs(torch.autograd.Function):
+    """(depth fp64, uncertainty fp64, colour fp32) of this rank's rays -> the same three for the whole batch, with ONE
+    all-gather: the 28 bytes of a ray travel as five fp64 columns (fp32 -> fp64 -> fp32 is exact).  Backward keeps this
+    rank's block of each gradient (every rank computes the same loss on the full batch)."""
 
     @staticmethod
-    def forward(ctx, x, lo, hi, sizes, group):
+    def forward(ctx, depth, unc, rgb, lo, hi, sizes, group):
         ctx.lo, ctx.hi = lo, hi
-        return _all_gather_rows(x.contiguous(), sizes, group)
+        packed = torch.cat([depth.reshape(-1, 1).to(torch.float64), unc.reshape(-1, 1).to(torch.float64),
+                            rgb.to(torch.float64)], 1)
+        full = _all_gather_rows(packed, sizes, group)
+        return (full[:, 0].to(depth.dtype).contiguous(), full[:, 1].to(unc.dtype).contiguous(),
+                full[:, 2:5].to(rgb.dtype).contiguous())
 
     @staticmethod
-    def backward(ctx, g):
-        return g[ctx.lo:ctx.hi].contiguous(), None, None, None, None
+    def backward(ctx, g_depth, g_unc, g_rgb):
+        lo, hi = ctx.lo, ctx.hi
+        cut = lambda g: None if g is None else g[lo:hi].contiguous()
+        return cut(g_depth), cut(g_unc), cut(g_rgb), None, None, None, None
 
 
 class _SumGrads(torch.autograd.Function):
@@ -205,4 +213,4 @@ class ShardedRenderer:
         finally:
             self.renderer._gt_max = None
             self.renderer._reduce_hook = None
-        return tuple(_GatherRows.apply(x, lo, hi, sizes, self.group) for x in (depth, unc, col))
+        return _GatherOutputs.apply(depth, unc, col, lo, hi, sizes, self.group)
