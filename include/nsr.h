@@ -5,6 +5,7 @@
  * native code).  Citations are relative to the reference tree:
  *
  *   nsr_get_samples      <- src/common.py:125-134  get_samples (after the torch.randint draw)
+ *   nsr_aabb_keep        <- src/Mapper.py:471-481, src/Tracker.py:95-104  bounding-box pre-filter (mask, no compaction)
  *   nsr_pack_params      <- (none) operand re-layout of src/conv_onet/models/decoder.py parameters
  *   nsr_render_fwd       <- src/utils/Renderer.py:63-198  Renderer.render_batch_ray  (forward)
  *                           incl. eval_points (:23-61), NICE.forward (decoder.py:312-342),
@@ -152,6 +153,16 @@ int64_t nsr_frustum_workspace_floats(int64_t n_voxels);
 int nsr_frustum_mask(const float *w2c, const float *cam_center, double fx, double fy, double cx, double cy,
                      int32_t H, int32_t W, const float *depth, const float *xs, const float *ys, const float *zs,
                      int32_t nx, int32_t ny, int32_t nz, float *workspace, uint8_t *voxel_mask, void *stream);
+
+/* --- SURVEY §8(f) rank 1 (third item): the callers' bounding-box pre-filter without compaction --------------------------
+ * Mapper.optimize_map (src/Mapper.py:471-481) and Tracker.optimize_cam_in_batch (src/Tracker.py:95-104) drop, before
+ * rendering, every ray whose depth lies beyond the scene bound:  t = min_axis max((lo-o)/d, (hi-o)/d)  (fp64),
+ * keep = t >= gt_depth, then index all four ray tensors with the boolean mask (a `nonzero` = a host sync per iteration).
+ * nsr_aabb_keep writes the same mask as bytes and, if kept_max != NULL (device float, caller-set to 0), the maximum
+ * gt_depth over the KEPT rays -- the batch-global scalar render_batch_ray needs -- so a caller can render the whole batch
+ * and weight its loss by the mask instead of compacting.  bound_lo / bound_hi: HOST arrays of 3 doubles. */
+int nsr_aabb_keep(const float *rays_o, const float *rays_d, const float *gt_depth, int64_t n,
+                  const double *bound_lo, const double *bound_hi, uint8_t *keep, float *kept_max, void *stream);
 
 #ifdef __cplusplus
 }

@@ -64,6 +64,8 @@ SYMBOLS = (
     ("nsr_get_samples", C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("nsr_aabb_keep", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                C.c_void_p, C.c_void_p, C.c_void_p]),
     ("nsr_frustum_workspace_floats", C.c_int64, [C.c_int64]),
     ("nsr_frustum_mask", C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_double, C.c_double, C.c_double, C.c_double,
                                    C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

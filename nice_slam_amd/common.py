@@ -150,6 +150,27 @@ def samples_from_indices(indices, H0, H1, W0, W1, fx, fy, cx, cy, c2w, depth, co
     return _GetSamplesFn.apply(*args)
 
 
+def aabb_keep(rays_o: torch.Tensor, rays_d: torch.Tensor, gt_depth: torch.Tensor, bound) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The callers' bounding-box pre-filter (src/Mapper.py:471-481, src/Tracker.py:95-104) as a mask instead of a
+    compaction:  keep = min_axis max((bound - o) / d) >= gt_depth  in fp64, one kernel, no host sync.
+    Returns ``(keep bool (N,), kept_max fp32 (1,))``; ``kept_max`` = max of ``gt_depth`` over the kept rays, to be passed as
+    ``render_batch_ray(..., gt_max=kept_max)``.  Rendering the full batch and multiplying each loss term by ``keep`` gives
+    the same loss and the same gradients as the reference's ``batch_rays_o[inside_mask]`` compaction."""
+    import ctypes as C
+    _require_cuda(rays_o, "aabb_keep: rays")
+    dev = rays_o.device
+    o, d, gd = _as_f32c(rays_o.detach()), _as_f32c(rays_d.detach(), dev), _as_f32c(gt_depth.detach().reshape(-1), dev)
+    n = o.shape[0]
+    keep = torch.empty((n,), dtype=torch.uint8, device=dev)
+    kmax = torch.zeros((1,), dtype=torch.float32, device=dev)
+    lo = (C.c_double * 3)(*[float(bound[a][0]) for a in range(3)])
+    hi = (C.c_double * 3)(*[float(bound[a][1]) for a in range(3)])
+    lib = _capi.get_lib()
+    lib.check(lib.nsr_aabb_keep(o.data_ptr(), d.data_ptr(), gd.data_ptr(), n, lo, hi, keep.data_ptr(), kmax.data_ptr(),
+                                _stream(dev)), "nsr_aabb_keep")
+    return keep.bool(), kmax
+
+
 def get_rays(H, W, fx, fy, cx, cy, c2w, device):
     """src/common.py:248-266: rays for a whole image (used by render_img, forward only)."""
     if isinstance(c2w, np.ndarray):

@@ -313,4 +313,18 @@ int nsr_frustum_mask(const float *w2c, const float *cam_center, double fx, doubl
     return finish("nsr_frustum_mask");
 }
 
+int nsr_aabb_keep(const float *rays_o, const float *rays_d, const float *gt_depth, int64_t n,
+                  const double *bound_lo, const double *bound_hi, uint8_t *keep, float *kept_max, void *stream) {
+    if (n < 0) return fail("nsr_aabb_keep: negative ray count");
+    if (n == 0) return 0;
+    if (!rays_o || !rays_d || !gt_depth || !bound_lo || !bound_hi || !keep) return fail("nsr_aabb_keep: null pointer");
+    nsr::AabbParams P;
+    P.rays_o = rays_o; P.rays_d = rays_d; P.gt_depth = gt_depth; P.n = n;
+    for (int a = 0; a < 3; ++a) { P.lo[a] = bound_lo[a]; P.hi[a] = bound_hi[a]; }
+    P.keep = keep; P.kept_max = kept_max;
+    const int tb = 256;
+    NSR_LAUNCH(nsr::aabb_keep_kernel, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, stream, P);
+    return finish("nsr_aabb_keep");
+}
+
 }  // extern "C"

@@ -56,6 +56,8 @@ NSR_DEV void block_sync() { __syncthreads(); }
 
 NSR_DEV void atomic_add_global(float *p, float v) { unsafeAtomicAdd(p, v); }
 NSR_DEV void atomic_add_lds(float *p, float v) { atomicAdd(p, v); }
+// max of non-negative floats (their bit patterns order like unsigned integers)
+NSR_DEV void atomic_max_pos(float *p, float v) { atomicMax(reinterpret_cast<unsigned *>(p), __builtin_bit_cast(unsigned, v)); }
 
 NSR_DEV char *lds_base() {
     extern __shared__ __attribute__((aligned(16))) char nsr_lds_[];

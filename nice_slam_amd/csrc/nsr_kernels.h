@@ -1527,6 +1527,37 @@ NSR_KERNEL void get_samples_kernel(const SampleParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// bounding-box pre-filter of the callers (Mapper.py:471-481, Tracker.py:95-104): keep a ray iff its exit distance from
+// the scene bound, t = min over axes of max((lo - o)/d, (hi - o)/d) in fp64, is >= its depth.  One thread per ray;
+// also the maximum depth over the KEPT rays (the batch-global scalar of render_batch_ray, Renderer.py:109,144) so that
+// neither the boolean-mask compaction nor its host sync is needed.
+// ------------------------------------------------------------------------------------------------
+struct AabbParams {
+    const float *rays_o, *rays_d, *gt_depth;
+    long long n;
+    double lo[3], hi[3];
+    unsigned char *keep;
+    float *kept_max;               // optional; caller-initialised (0): max of gt_depth over kept rays
+};
+
+NSR_KERNEL void aabb_keep_kernel(const AabbParams P) {
+    const long long r = (long long)bid_x() * nthreads() + tid();
+    if (r >= P.n) return;
+    double t = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double o = (double)P.rays_o[r * 3 + a], d = (double)P.rays_d[r * 3 + a];
+        const double t0 = (P.lo[a] - o) / d, t1 = (P.hi[a] - o) / d;
+        const double m = t0 > t1 ? t0 : t1;                       // torch.max(t, dim=2): NaN-free inputs assumed, like the callers
+        t = (a == 0 || m < t) ? m : t;
+    }
+    const float gd = P.gt_depth[r];
+    const bool k = t >= (double)gd;
+    P.keep[r] = k ? 1 : 0;
+    if (k && P.kept_max && gd > 0.f) atomic_max_pos(P.kept_max, gd);
+}
+
+// ------------------------------------------------------------------------------------------------
 // frustum feature selection (Mapper.get_mask_from_c2w, Mapper.py:93-164): one thread per voxel of a
 // [Z][Y][X] grid.  phase 0: project the voxel centre, bilinear depth lookup (cv2.remap INTER_LINEAR semantics: 1/32-pixel
 // fixed-point coordinates, zero border), store it, block maximum -> ws[n_vox + block].  phase 1: max over the block

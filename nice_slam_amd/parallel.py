@@ -187,7 +187,7 @@ class ShardedRenderer:
         self.last_exchange_floats = floats
         return out
 
-    def render_batch_ray(self, c, decoders, rays_d, rays_o, device, stage, gt_depth=None):
+    def render_batch_ray(self, c, decoders, rays_d, rays_o, device, stage, gt_depth=None, gt_max=None):
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         n = rays_o.shape[0]
         sizes = [shard_range(n, world, r)[1] - shard_range(n, world, r)[0] for r in range(world)]
@@ -205,7 +205,8 @@ class ShardedRenderer:
         self.renderer._gt_max = None
         if gt_depth is not None:
             gt_depth = gt_depth.reshape(-1)
-            self.renderer._gt_max = torch.max(gt_depth.detach().to(torch.float32)).reshape(1)    # batch-global, before slicing
+            self.renderer._gt_max = (gt_max.detach().to(torch.float32).reshape(1) if gt_max is not None else
+                                     torch.max(gt_depth.detach().to(torch.float32)).reshape(1))   # batch-global, before slicing
             gt_s = gt_depth[lo:hi]
         self.renderer._reduce_hook = self._reduce_flat
         try:

@@ -301,8 +301,11 @@ class Renderer(object):
         """Renderer.py:23-61 (forward only)."""
         return eval_points_raw(p, decoders, c, stage, self.bound)
 
-    def render_batch_ray(self, c, decoders, rays_d, rays_o, device, stage, gt_depth=None):
-        """Renderer.py:63-198: returns (depth fp64 (N,), uncertainty fp64 (N,), color fp32 (N,3))."""
+    def render_batch_ray(self, c, decoders, rays_d, rays_o, device, stage, gt_depth=None, gt_max=None):
+        """Renderer.py:63-198: returns (depth fp64 (N,), uncertainty fp64 (N,), color fp32 (N,3)).
+        ``gt_max`` (optional, not in the reference): a 1-element device tensor to use as the batch-global
+        ``max(gt_depth)`` of Renderer.py:109,144 instead of the maximum over ``gt_depth`` -- for callers that keep the
+        bounding-box-rejected rays in the batch and mask their loss (``nice_slam_amd.aabb_keep``)."""
         _require_cuda(rays_o, "render_batch_ray: rays")
         dev = rays_o.device
         if stage == "coarse":
@@ -323,6 +326,12 @@ class Renderer(object):
                 (self.decoder_grads is None or s in self.decoder_grads)
             gates.append(_gate(dev, want))
         meta = (self, decoders, stage, gt_depth, self._reduce_hook)
+        if gt_max is not None and self._gt_max is None:
+            self._gt_max = gt_max.detach().to(device=dev, dtype=torch.float32).reshape(1)
+            try:
+                return _RenderFn.apply(meta, rays_o, rays_d, *[grids[s] for s in slots], *gates)
+            finally:
+                self._gt_max = None
         return _RenderFn.apply(meta, rays_o, rays_d, *[grids[s] for s in slots], *gates)
 
     def render_img(self, c, decoders, c2w, device, stage, gt_depth=None):

@@ -227,3 +227,28 @@ def test_frustum_mask(emu, seed):
                                    ptr(xs), ptr(ys), ptr(zs), nx, ny, nz, ptr(ws), ptr(out), None))
     assert set(np.unique(out)) <= {0, 1}
     assert np.array_equal(out.astype(bool), ref.transpose(2, 1, 0))
+
+
+def test_aabb_keep_matches_reference_expression(emu):
+    """the callers' bounding-box pre-filter (Mapper.py:471-481) as a byte mask + kept-ray max depth"""
+    import ctypes as C
+    from emu_harness import ptr
+    g = torch.Generator().manual_seed(3)
+    n = 1000
+    bound = torch.tensor([[-2.0, 2.4], [-1.6, 1.9], [-2.2, 2.1]], dtype=torch.float64)
+    o = ((torch.rand((n, 3), generator=g) - 0.5) * 3.0).float()
+    d = torch.randn((n, 3), generator=g).float()
+    d[::7, 1] = 0.0                                            # axis-parallel components: +-inf slabs
+    depth = (torch.rand((n,), generator=g) * 4.0).float()
+    depth[::11] = 0.0
+    t = (bound.unsqueeze(0) - o.unsqueeze(-1)) / d.unsqueeze(-1)            # the reference's expression, fp64 by promotion
+    t, _ = torch.min(torch.max(t, dim=2)[0], dim=1)
+    ref = t >= depth
+    assert 0.2 < ref.float().mean() < 0.95
+    keep = np.full((n,), 7, dtype=np.uint8)
+    kmax = np.zeros((1,), dtype=np.float32)
+    lo, hi = (C.c_double * 3)(*bound[:, 0].tolist()), (C.c_double * 3)(*bound[:, 1].tolist())
+    on, dn, zn = o.numpy().copy(), d.numpy().copy(), depth.numpy().copy()
+    emu.check(emu.nsr_aabb_keep(ptr(on), ptr(dn), ptr(zn), n, lo, hi, ptr(keep), ptr(kmax), None))
+    assert np.array_equal(keep.astype(bool), ref.numpy())
+    assert kmax[0] == depth[ref].max().item()

@@ -199,3 +199,47 @@ def test_masked_grid_adam_replaces_masked_leaf_flow():
         assert torch.equal(b[~full[k].cpu()], sc["grids"][k][~full[k].cpu()]), k          # unmasked voxels untouched
         assert float((a - b).abs().mean()) < 2e-5 * float(a.abs().max()) + 1e-7, (k, float((a - b).abs().mean()))
         assert float((b - sc["grids"][k]).abs().max()) > 1e-4, k
+
+
+def test_aabb_mask_flow_equals_compaction():
+    """Mapper.py:471-489 two ways through the HIP renderer: the reference's boolean-mask compaction of the ray batch, and
+    the sync-free form (nice_slam_amd.aabb_keep: full batch, kept-ray max depth, loss weighted by the mask).  Same loss,
+    same grid / decoder gradients."""
+    import nice_slam_amd as nsa
+    sc = make_scene(seed=51, n_rays=400, small=True)
+    renderer, dec, grids_dev = build_product(sc, DEV)
+    o = sc["rays_o"].to(DEV) * 1.0
+    d = sc["rays_d"].to(DEV)
+    gd = sc["gt_depth"].to(DEV)                              # ~43 % of these rays end inside the bound
+    gc = sc["gt_color"].to(DEV)
+    bound = sc["bound"]
+
+    def run(masked):
+        c = {k: v.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) for k, v in grids_dev.items()}
+        for p in dec.parameters():
+            p.grad = None; p.requires_grad_(True)
+        if masked:
+            keep, kmax = nsa.aabb_keep(o, d, gd, bound)
+            depth, _, color = renderer.render_batch_ray(c, dec, d, o, DEV, "color", gt_depth=gd, gt_max=kmax)
+            w = keep & (gd > 0)
+            loss = (torch.abs(gd - depth) * w).sum() + 0.2 * (torch.abs(gc - color) * keep[:, None]).sum()
+        else:
+            t = (bound.unsqueeze(0).to(DEV) - o.unsqueeze(-1)) / d.unsqueeze(-1)
+            t, _ = torch.min(torch.max(t, dim=2)[0], dim=1)
+            keep = t >= gd
+            o2, d2, gd2, gc2 = o[keep], d[keep], gd[keep], gc[keep]
+            depth, _, color = renderer.render_batch_ray(c, dec, d2, o2, DEV, "color", gt_depth=gd2)
+            m = gd2 > 0
+            loss = torch.abs(gd2[m] - depth[m]).sum() + 0.2 * torch.abs(gc2 - color).sum()
+        loss.backward()
+        return (float(loss), keep.clone(), {k: v.grad.clone() for k, v in c.items() if v.grad is not None},
+                {k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None})
+
+    l0, k0, g0, p0 = run(False)
+    l1, k1, g1, p1 = run(True)
+    assert torch.equal(k0, k1) and 0.1 < k0.float().mean() < 0.95
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)
+    for k in g0:
+        assert rel_err(g1[k], g0[k]) < 1e-5, k
+    for k in p0:
+        assert rel_err(p1[k], p0[k]) < 2e-5, k
