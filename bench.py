@@ -18,7 +18,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -84,22 +83,77 @@ class HipEvents:
         return out
 
 
-def cpu_baseline(sc, reps=1):
-    """The CPU oracle (a torch restatement of the reference path, kind='port') on this box's host cores,
-    one forward+backward per stage on the same 1000-ray workload, stage-weighted like the GPU run."""
-    from scene_util import oracle_render
+# configs/Replica/room0.yaml + replica.yaml + nice_slam.yaml (BASELINE configs[1])
+REPLICA_ROOM0 = {
+    "scale": 1, "occupancy": True, "coarse": True,
+    "mapping": {"bound": [[-2.9, 8.9], [-3.2, 5.5], [-3.5, 3.3]]},
+    "grid_len": {"coarse": 2, "middle": 0.32, "fine": 0.16, "color": 0.16, "bound_divisible": 0.32},
+    "model": {"c_dim": 32, "coarse_bound_enlarge": 2},
+    "rendering": {"lindisp": False, "perturb": 0.0, "N_samples": 32, "N_surface": 16, "N_importance": 0},
+    "cam": {"H": 680, "W": 1200, "fx": 600.0, "fy": 600.0, "cx": 599.5, "cy": 339.5},
+}
+
+
+def build_scene(dev, seed=0):
+    """Synthetic workload of BASELINE configs[1], built with the product's own set-up code (no oracle involved): grids with
+    the reference's init statistics (NICE_SLAM.py:223-247), random-init decoders (no pretrained weights exist here), one
+    680x1200 RGB-D frame with depth U(1,4) m and 1 % zeros, a pose at the centre of the bound."""
+    import math
+    import types
+    import nice_slam_amd as nsa
+    from nice_slam_amd.common import set_decoder_bounds
+    cfg = REPLICA_ROOM0
+    torch.manual_seed(seed)
+    bound = nsa.load_bound(cfg)
+    cam = cfg["cam"]
+    slam = types.SimpleNamespace(nice=True, bound=bound, H=cam["H"], W=cam["W"], fx=cam["fx"], fy=cam["fy"], cx=cam["cx"], cy=cam["cy"])
+    renderer = nsa.Renderer(cfg, None, slam)
+    dec = nsa.NICE(coarse=True).to(dev)
+    set_decoder_bounds(dec, bound, cfg["model"]["coarse_bound_enlarge"])
+    grids = {k: v.to(dev) for k, v in nsa.grid_init(cfg, bound).items()}
+    g = torch.Generator().manual_seed(seed + 1)
+    depth = torch.rand((cam["H"], cam["W"]), generator=g) * 3.0 + 1.0
+    depth[torch.rand((cam["H"], cam["W"]), generator=g) < 0.01] = 0.0
+    color = torch.rand((cam["H"], cam["W"], 3), generator=g)
+    ang = 0.15
+    c2w = torch.eye(4)
+    c2w[:3, :3] = torch.tensor([[math.cos(ang), 0, math.sin(ang)], [0, 1, 0], [-math.sin(ang), 0, math.cos(ang)]])
+    c2w[:3, 3] = bound.mean(1).float()
+    return {"cfg": cfg, "bound": bound, "renderer": renderer, "dec": dec, "grids": grids, "c2w": c2w,
+            "depth_img": depth, "color_img": color, "intr": (cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])}
+
+
+def cpu_baseline(sc, n_rays, reps=1):
+    """The CPU oracle (a torch restatement of the reference path, kind='port') on this box's host cores, fed with the SAME
+    grids / decoder parameters / frame as the GPU run: one forward+backward per stage on an `n_rays` batch, stage-weighted
+    like the GPU run.  The only place of this file that touches oracle/."""
+    from oracle import nice_oracle as orc
     torch.set_num_threads(min(16, os.cpu_count() or 1))       # small-op torch CPU code scales poorly past ~16 threads
+    H, W, fx, fy, cx, cy = sc["intr"]
+    grids = {k: v.detach().cpu().contiguous() for k, v in sc["grids"].items()}                # NCDHW, standard strides
+    params = {k: v.detach().cpu().clone() for k, v in sc["dec"].state_dict().items()}
+    idx = torch.randint(H * W, (n_rays,), generator=torch.Generator().manual_seed(5))
+    rays_o, rays_d, gt_depth, gt_color = orc.pixel_rays(idx, 0, H, 0, W, fx, fy, cx, cy, sc["c2w"], sc["depth_img"], sc["color_img"])
+
+    def once(stage, n):
+        G = {k: v.clone().requires_grad_(True) for k, v in grids.items()}
+        P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        depth, _, col = orc.render_batch_ray(G, P, rays_d[:n], rays_o[:n], stage, gt_depth[:n], sc["bound"])
+        loss = (torch.abs(gt_depth[:n] - depth) * (gt_depth[:n] > 0)).sum()
+        if stage == "color":
+            loss = loss + 0.2 * torch.abs(gt_color[:n] - col).sum()
+        loss.backward()
+
     t = {}
     for stage in ("middle", "fine", "color"):
-        oracle_render(sc, stage, backward=True, rays=slice(0, 64))       # warm-up
+        once(stage, 64)                                        # warm-up
         t0 = time.perf_counter()
         for _ in range(reps):
-            oracle_render(sc, stage, backward=True)
+            once(stage, n_rays)
         t[stage] = (time.perf_counter() - t0) / reps
-    n = sc["rays_o"].shape[0]
     mix = (25 * t["middle"] + 12 * t["fine"] + 23 * t["color"]) / 60.0
-    return {"value": n / mix, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle fwd+bwd, {n} rays, 1 iter per stage (middle {t['middle']*1e3:.0f} ms, fine {t['fine']*1e3:.0f} ms, "
+    return {"value": n_rays / mix, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle fwd+bwd, {n_rays} rays, 1 iter per stage (middle {t['middle']*1e3:.0f} ms, fine {t['fine']*1e3:.0f} ms, "
                       f"color {t['color']*1e3:.0f} ms), weighted 25/12/23"}
 
 
@@ -135,13 +189,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from scene_util import make_scene, build_product
     import nice_slam_amd as nsa
     from nice_slam_amd.parallel import ShardedRenderer
 
     n_total = args.rays * world                                   # weak scaling: fixed rays per GPU
-    sc = make_scene(seed=0, n_rays=args.rays, scene="replica_room0", fine_scale=1.0, zero_frac=0.01, depth_range=(1.0, 4.0))
-    renderer, dec, grids = build_product(sc, dev)
+    sc = build_scene(dev)                                          # same seed -> identical scene on every rank
+    renderer, dec, grids = sc["renderer"], sc["dec"], sc["grids"]
     grids = {k: v.requires_grad_(True) for k, v in grids.items()}
     for n_, p in dec.named_parameters():                          # reference: every decoder parameter has requires_grad=True
         p.requires_grad_(True)
@@ -288,7 +341,7 @@ def main():
             res["config"]["grad_exchange_MB_last_iter"] = round(rend.last_exchange_floats * 4 / 1e6, 2)
         res["kernel_ms"] = {f"render_bwd<{s}>": round(v[0], 4) for s, v in ksum.items()}
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(sc)
+            res["cpu_baseline"] = cpu_baseline(sc, args.rays)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     if world > 1 or force_dist:

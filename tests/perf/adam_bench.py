@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""SURVEY §8(f) rank 1 measurement: the per-iteration grid update of Mapper.optimize_map on Replica room0 shapes.
+"""TEST INFRASTRUCTURE (measurement script; builds its inputs with tests/scene_util.py, i.e. with oracle helpers).
+SURVEY §8(f) rank 1 measurement: the per-iteration grid update of Mapper.optimize_map on Replica room0 shapes.
 (A) reference flow: val[mask] = val_grad (x2 per iteration) + torch.optim.Adam on the masked leaves
 (B) nice_slam_amd.MaskedGridAdam: one in-place kernel per grid.  Reports time per iteration and, for (B), achieved
 HBM GB/s against the algorithmic bytes (896 B per updated voxel + 1 B mask per voxel)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import nice_slam_amd as nsa

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Secondary baseline: the reference's op sequence -- restated by the oracle -- executed by stock
+"""TEST INFRASTRUCTURE (measurement script; builds its inputs with tests/scene_util.py, i.e. with oracle helpers).
+Secondary baseline: the reference's op sequence -- restated by the oracle -- executed by stock
 PyTorch-ROCm ATen kernels on the same MI355X (no nsr kernels involved).  Prints rays/s per stage and the mapping mix."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from scene_util import make_scene

@@ -1,7 +1,8 @@
-"""Host enqueue time of each part of the eager mapping iteration (no hipGraph): where a Python caller's time goes.
-    python tools/eager_sections.py  (on the GPU box)"""
+"""TEST INFRASTRUCTURE (measurement script; builds its inputs with tests/scene_util.py, i.e. with oracle helpers).
+Host enqueue time of each part of the eager mapping iteration (no hipGraph): where a Python caller's time goes.
+    python tests/perf/eager_sections.py  (on the GPU box)"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import nice_slam_amd as nsa

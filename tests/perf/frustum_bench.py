@@ -1,6 +1,7 @@
-"""Frustum feature selection at Replica room0 scale: nsr_frustum_mask on the GPU vs the numpy restatement of
+"""TEST INFRASTRUCTURE (measurement script; builds its inputs with tests/scene_util.py, i.e. with oracle helpers).
+Frustum feature selection at Replica room0 scale: nsr_frustum_mask on the GPU vs the numpy restatement of
 Mapper.get_mask_from_c2w on the host (what the reference runs once per grid per optimize_map call).
-Run on the GPU box:  python tools/frustum_bench.py > gpurun_out/frustum.txt"""
+Run on the GPU box:  python tests/perf/frustum_bench.py > gpurun_out/frustum.txt"""
 import json
 import os
 import sys
@@ -9,7 +10,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Forward-only, large-batch entry points of the path: Renderer.eval_points on a Mesher-sized
+"""TEST INFRASTRUCTURE (measurement script; builds its inputs with tests/scene_util.py, i.e. with oracle helpers).
+Forward-only, large-batch entry points of the path: Renderer.eval_points on a Mesher-sized
 point cloud (256^3 = 16.8 M points, src/utils/Mesher.py:382-433) and Renderer.render_img on a full 680x1200 frame
 (816 k rays, src/utils/Renderer.py:200-255).  Prints throughput and the fraction of the fp32 MFMA roofline."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from scene_util import make_scene, build_product

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Ablation timing of the backward kernel: which gradient outputs cost what (HIP events inside nsr_render_bwd)."""
+"""TEST INFRASTRUCTURE (measurement script; builds its inputs with tests/scene_util.py, i.e. with oracle helpers).
+Ablation timing of the backward kernel: which gradient outputs cost what (HIP events inside nsr_render_bwd)."""
 import os, sys, ctypes, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from scene_util import make_scene, build_product

@@ -1,11 +1,12 @@
-"""Per-phase cycle breakdown of the backward kernel from s_memtime stamps.
+"""TEST INFRASTRUCTURE (measurement script; builds its inputs with tests/scene_util.py, i.e. with oracle helpers).
+Per-phase cycle breakdown of the backward kernel from s_memtime stamps.
 
 Needs an INSTRUMENTED build of libnsr (not part of the product): a scratch copy of nice_slam_amd/csrc with a `long long *dbg`
 field in RenderParams (set from the environment variable NSR_DBG_PTR in nsr_render_bwd) and TS(O, slot) stamps at the
 phase boundaries of bwd_pass / mlp_xyz_bwd / XyzBwd::layer (slot map below); point NSR_LIB_PATH at it.
-    NSR_LIB_PATH=$PWD/nice_slam_amd/_ab/libnsr_ts.so python tools/ts_probe.py [n_rays]"""
+    NSR_LIB_PATH=$PWD/nice_slam_amd/_ab/libnsr_ts.so python tests/perf/ts_probe.py [n_rays]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch, numpy as np
 from scene_util import make_scene, build_product
