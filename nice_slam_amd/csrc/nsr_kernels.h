@@ -5,12 +5,12 @@
 // for k-tile T the lane owns channels 16T + 4g + r, r = 0..3, as one f32x4.  With that layout
 //   * the trilinear gather of a channels-last voxel (32 ch = 128 B) is two 16-B loads per corner per
 //     lane and lands directly in MFMA operand position -- no LDS transposition,
-//   * y = W x is a chain of v_mfma_f32_16x16x4_f32 with A = packed weights (one coalesced dword per
-//     lane per MFMA) and B = the register that already holds x, output again CL,
-//   * dx = W^T dy uses A = W read row-major (64-B runs) and B = dy registers,
-//   * dW = dy^T x contracts over the 16 points of the tile; both operands go through a 2.3 KB
-//     per-wave LDS transposition buffer, results are summed into a per-block LDS image of the flat
-//     parameter-gradient blob and flushed once per block.
+//   * y = W x is a chain of v_mfma_f32_16x16x4_f32 with A = packed weights staged in LDS (one 16-byte read per lane
+//     feeds four MFMAs) and B = the register that already holds x, output again CL,
+//   * dx = W^T dy reads the same packed stream through a transposed index, B = the dy registers,
+//   * dW = dy^T x contracts over points: each wave stages its tile's operands in LDS ("channel rows": one 16-byte read =
+//     the operand of four k-steps) and ONE owner wave per 16x16 weight-block pair contracts over all tiles of the block;
+//     results go to a per-block image of the flat gradient blob in global memory (L2), summed by reduce_partials_kernel.
 // References: Renderer.render_batch_ray (src/utils/Renderer.py:63-198), eval_points (:23-61),
 // NICE/MLP/MLP_no_xyz forward (src/conv_onet/models/decoder.py:168-203,254-274,312-342),
 // raw2outputs_nerf_color (src/common.py:204-245), ATen grid_sampler_3d (GridSampler.h).
@@ -465,7 +465,7 @@ NSR_DEV F4 load_b1(const float *aux, int ch) {        // (Bx, By, Bz) of one cha
 //      image of the flat gradient blob with a plain read-modify-write (exclusive owner => no atomics),
 //   4. block barrier.
 // Per-wave staging region (floats): P[16][4] | DO[16][4] | A0 | A1 | X0 | C[cdim/32]; a tile is 16 rows x 32
-// channels with the column XOR-swizzled by (row&1)<<4 so the transposed reads are bank-conflict free.
+// channels in the "channel rows" layout below (conflict-free scalar stores, one conflict-free 16-byte operand read).
 // ------------------------------------------------------------------------------------------------
 constexpr int kStP = 0, kStDO = 64, kStA0 = 128, kStA1 = 128 + 512, kStX0 = 128 + 1024, kStC = 128 + 1536;
 constexpr int stg_floats(int kind) { return 128 + 512 * (3 + cdim_of(kind) / 32); }
