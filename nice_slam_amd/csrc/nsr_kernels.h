@@ -461,10 +461,10 @@ NSR_DEV F4 load_b1(const float *aux, int ch) {        // (Bx, By, Bz) of one cha
 //   1. each wave stages the operands of its tile (dH, dY, layer input, features, point positions) in LDS,
 //   2. block barrier,
 //   3. each 16x16 block pair of the layer's dW has ONE owner wave, which contracts over the 16 points of
-//      EVERY tile of the block in one MFMA chain (K = 16 x tiles) and adds the result into the block's LDS
-//      image of the flat gradient blob with a plain read-modify-write (exclusive owner => no atomics),
+//      EVERY tile of the block in one MFMA chain (K = 16 x tiles) and adds the result into the block's image of
+//      the flat gradient blob (global memory, L2-resident; exclusive owner => plain loads / stores, no atomics),
 //   4. block barrier.
-// Per-wave staging region (floats): P[16][4] | DO[16][4] | A0 | A1 | X0 | C[cdim/32]; a tile is 16 rows x 32
+// Per-wave staging region (floats): P[3][16] | DO[16][4] | A0 | A1 | X0 | C[cdim/32]; a tile is 16 rows x 32
 // channels in the "channel rows" layout below (conflict-free scalar stores, one conflict-free 16-byte operand read).
 // ------------------------------------------------------------------------------------------------
 constexpr int kStP = 0, kStDO = 64, kStA0 = 128, kStA1 = 128 + 512, kStX0 = 128 + 1024, kStC = 128 + 1536;
@@ -512,8 +512,7 @@ NSR_DEV void img_add(const Own &O, int lane_off, int const_off, float v) {
 }
 
 // img[W slice, k-tile Tk] += sum over the block's tiles of A^T X,  X staged at x_off (sub-tile x_sub)
-template <int XSRC>
-NSR_DEV void own_pair(const Own &O, const Mat m, int Tk, int a_off, int x_off, int x_sub, const float *aux) {
+NSR_DEV void own_pair(const Own &O, const Mat m, int Tk, int a_off, int x_off, int x_sub) {
     const int i = O.lane & 15, g = O.lane >> 4;
     f32x4 d0 = f4zero(), d1 = f4zero();
     // the image values this task accumulates into (later ray groups of the block): requested now, consumed after the
@@ -529,7 +528,6 @@ NSR_DEV void own_pair(const Own &O, const Mat m, int Tk, int a_off, int x_off, i
             d1[r] = stream_ld(O.img, lo, co + (16 + r) * m.stride);
         }
     }
-    (void)aux;
     // software pipeline over the block's tiles, two tiles per trip with ping-pong operand sets (no register rotation):
     // the LDS reads (and, for the embedding, the sines) of the next tile are issued before the 8 MFMAs of this one
     struct Ops { f32x4 a0, a1, x; };
@@ -1030,11 +1028,11 @@ struct XyzBwd {
             if (I > 0) {
 #pragma unroll
                 for (int Tk = 0; Tk < 2; ++Tk, ++t)
-                    if (mine(O, t)) own_pair<0>(O, xyz_mat(CD, hid), Tk, kStA1, kStX0, Tk, aux);
+                    if (mine(O, t)) own_pair(O, xyz_mat(CD, hid), Tk, kStA1, kStX0, Tk);
             }
 #pragma unroll
             for (int Tk = 0; Tk < NTC; ++Tk, ++t)
-                if (mine(O, t)) own_pair<1>(O, mu, Tk, kStA0, kStC + (Tk >> 1) * 512, Tk & 1, aux);
+                if (mine(O, t)) own_pair(O, mu, Tk, kStA0, kStC + (Tk >> 1) * 512, Tk & 1);
             if (mine(O, t)) own_colsum(O, fcb_off(KIND, I), kStA0);
             if (mine(O, t + 1)) own_colsum(O, bias_off(KIND, I), kStA1);
             block_sync();
@@ -1188,11 +1186,11 @@ struct NoxBwd {
             if (I == 3) {
 #pragma unroll
                 for (int Tk = 0; Tk < 2; ++Tk, ++t)
-                    if (mine(O, t)) own_pair<1>(O, nox_mat(NW3C), Tk, kStA1, kStC, Tk, nullptr);
+                    if (mine(O, t)) own_pair(O, nox_mat(NW3C), Tk, kStA1, kStC, Tk);
             }
 #pragma unroll
             for (int Tk = 0; Tk < 2; ++Tk, ++t)
-                if (mine(O, t)) own_pair<0>(O, mh, Tk, kStA1, kStX0, Tk, nullptr);
+                if (mine(O, t)) own_pair(O, mh, Tk, kStA1, kStX0, Tk);
             if (mine(O, t)) own_colsum(O, nox_b(I), kStA1);
             block_sync();
         }
