@@ -24,9 +24,10 @@ NSR_DEV int tid() { return (int)threadIdx.x; }
 NSR_DEV int nthreads() { return (int)blockDim.x; }
 NSR_DEV int bid_x() { return (int)blockIdx.x; }
 NSR_DEV int f2i_rn(float x) { return __float2int_rn(x); }      // round half to even (cvRound)
-// max(x, 0); NaN -> 0.  (The compiler needs to see the operation: an inline-asm v_max_f32 right after an MFMA escapes its
-// hazard recogniser -- no wait states are inserted and stale accumulators are read.)
-NSR_DEV float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_huge_valf()); }
+// max(x, 0) as ONE instruction: on the bit pattern, v_max_i32(x, 0) (negative floats are negative integers).  fmaxf / fmed3
+// cost two (canonicalise + max), and an inline-asm v_max_f32 right after an MFMA escapes the compiler's hazard recogniser
+// (no wait states inserted, stale accumulators read).
+NSR_DEV float relu1(float x) { const int b = __builtin_bit_cast(int, x); return __builtin_bit_cast(float, b > 0 ? b : 0); }
 NSR_DEV int bid_y() { return (int)blockIdx.y; }
 NSR_DEV int nblk_x() { return (int)gridDim.x; }
 
