@@ -78,3 +78,19 @@ def test_product_fails_loudly_without_gpu():
         renderer.render_batch_ray(grids, dec, sc["rays_d"], sc["rays_o"], "cpu", "middle", gt_depth=sc["gt_depth"])
     with pytest.raises(NsrError):
         nsa.get_samples(0, 8, 0, 8, 4, 48, 64, 60., 60., 31.5, 23.5, sc["c2w"], sc["depth_img"], sc["color_img"], "cpu")
+
+
+def test_ctypes_struct_fields_follow_the_header():
+    """Field names and order of the mirrored structs, parsed from include/nsr.h."""
+    from nice_slam_amd import _capi
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "nsr.h")).read(), flags=re.S)
+    for cname, ctype in (("nsr_grid", _capi.NsrGrid), ("nsr_decoder", _capi.NsrDecoder),
+                         ("nsr_render_args", _capi.NsrRenderArgs), ("nsr_bwd_args", _capi.NsrBwdArgs)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), txt, re.S).group(1)
+        names = []
+        for stmt in body.split(";"):
+            for decl in stmt.split(","):
+                m = re.search(r"(\w+)\s*(?:\[[^\]]*\])?\s*$", decl.strip())
+                if m:
+                    names.append(m.group(1))
+        assert names == [f[0] for f in ctype._fields_], cname
