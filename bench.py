@@ -168,6 +168,8 @@ def main():
     ap.add_argument("--eager", action="store_true", help="do not capture the iteration in a hipGraph")
     ap.add_argument("--stepped-grads-only", action="store_true",
                     help="parameter gradients only for the decoder the reference's optimiser steps (colour); default: all, like the reference autograd")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="multi-GPU: weak = --rays per GPU (default), strong = --rays in total, split over the ranks")
     ap.add_argument("--dense-exchange", action="store_true",
                     help="multi-GPU: all-reduce the whole feature-grid gradients instead of the frustum-selected voxel rows")
     args = ap.parse_args()
@@ -192,7 +194,7 @@ def main():
     import nice_slam_amd as nsa
     from nice_slam_amd.parallel import ShardedRenderer
 
-    n_total = args.rays * world                                   # weak scaling: fixed rays per GPU
+    n_total = args.rays * world if args.scaling == "weak" else args.rays      # weak: fixed rays per GPU; strong: fixed batch
     sc = build_scene(dev)                                          # same seed -> identical scene on every rank
     renderer, dec, grids = sc["renderer"], sc["dec"], sc["grids"]
     grids = {k: v.requires_grad_(True) for k, v in grids.items()}
@@ -312,11 +314,11 @@ def main():
         res = {
             "metric": "rendered rays/sec (fwd+bwd) per mapping iter", "value": n_total * args.steps / dt, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (f64 sample placement / depth)",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32 (f64 sample placement / depth)",
             "data": "synthetic",
             "config": {"workload": "Replica room0 full config (BASELINE configs[1]): grids 21x28x37 / 43x56x74 x2, 32 ch fp32, "
                                    "random-init decoders, 680x1200 synthetic RGB-D, 5x200 pixels/iter, S=32+16",
-                       "rays_per_gpu": args.rays, "stage_mix": {s: stages.count(s) for s in sorted(set(stages))},
+                       "rays_per_gpu": n_total // world, "rays_per_iteration": n_total, "stage_mix": {s: stages.count(s) for s in sorted(set(stages))},
                        "timed_region": "get_samples x5 + render_batch_ray + mapping loss (sync-free form) + backward (all grid + all decoder grads, like the reference autograd), no optimiser",
                        "decoder_grads": "colour decoder only (what Mapper's optimiser steps)" if args.stepped_grads_only else "all decoders (reference autograd semantics)",
                        "launch": "hipGraph replay (one captured graph per stage)" if use_graph else "eager",
@@ -324,11 +326,11 @@ def main():
         }
         if "color" in ksum:
             ms, cnt = ksum["color"]
-            rays_launch = args.rays
+            rays_launch = n_total // world                      # rays per backward launch on this rank
             ach = rays_launch * BWD_COLOR_FLOP_PER_RAY / (ms * 1e-3)
             traffic, tsrc = None, None
             tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")      # from a separate rocprofv3 --pmc run (tools/pmc_summary.py)
-            if os.path.exists(tpath) and args.rays == RAYS_PER_GPU:
+            if os.path.exists(tpath) and rays_launch == RAYS_PER_GPU:
                 tj = json.load(open(tpath)).get("nsr::render_bwd_kernel<3>", {})
                 traffic, tsrc = tj.get("hbm_bytes_per_launch"), "profiles/r01_traffic.json: " + tj.get("note", "")
             res["roofline"] = {"bound": "mfma", "kernel": "render_bwd_kernel<color>", "achieved": ach / 1e12, "peak": FP32_PEAK / 1e12,
