@@ -183,13 +183,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("NSR_SINGLE_DEVICE") == "1":                # CI on a 1-GPU box: every rank on device 0 (with gloo, see below)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_dist = os.environ.get("NSR_FORCE_SHARDED") == "1"        # exercise the RCCL path with a single rank (CI on a 1-GPU box)
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("NSR_DIST_BACKEND", "nccl")       # "nccl" = RCCL; "gloo" only to exercise the multi-rank
+        if backend == "nccl":                                      # code path where RCCL cannot run (ranks sharing one GPU)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import nice_slam_amd as nsa
     from nice_slam_amd.parallel import ShardedRenderer
@@ -259,7 +265,8 @@ def main():
             step(st_i, True)
     torch.cuda.synchronize()
     # RCCL collectives are capturable too; NSR_DIST_GRAPH=0 forces the eager path for multi-rank runs
-    use_graph = not args.eager and ((world == 1 and not force_dist) or os.environ.get("NSR_DIST_GRAPH", "1") == "1")
+    use_graph = not args.eager and ((world == 1 and not force_dist) or os.environ.get("NSR_DIST_GRAPH", "1") == "1") \
+        and os.environ.get("NSR_DIST_BACKEND", "nccl") == "nccl"
     graphs = {}
     if use_graph:
         # The mapping iteration is launch-bound on the host (~25 small launches around three big kernels): capture one
