@@ -181,6 +181,9 @@ def main():
     os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import signal
+        signal.alarm(int(os.environ.get("NSR_BENCH_DEADLINE_S", "900")))   # a wedged collective must not hang the node: die loudly
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("NSR_SINGLE_DEVICE") == "1":                # CI on a 1-GPU box: every rank on device 0 (with gloo, see below)
