@@ -1,0 +1,41 @@
+"""hipGraph capture of a mapping / tracking iteration.
+
+The render path is two large kernels surrounded by a few dozen tiny ones (index draws, concatenations, the caller's loss
+and its backward, gradient plumbing); run eagerly from Python the iteration is bound by launch overhead (≈0.7 ms on
+MI355X for the Replica mapping iteration, whose kernels take 0.4 ms).  Everything this package launches is capturable:
+no host synchronisation, no data-dependent shapes, workspaces and gradient blobs at stable addresses.  ``CapturedStep``
+wraps the usual torch recipe (warm-up on a side stream, capture, replay):
+
+    step = nice_slam_amd.graphs.CapturedStep(one_iteration)     # one_iteration(): no arguments, static shapes,
+    for _ in range(n): step()                                   # reads its inputs from tensors it closes over
+
+What the closure must respect is torch's, not ours: no ``.item()`` / boolean-mask indexing inside (use
+``nice_slam_amd.aabb_keep`` instead of the compaction of Mapper.py:471-481), optimisers with ``capturable=True`` (or
+``MaskedGridAdam``, whose step scalars are host-side and therefore belong outside the captured region), and fresh inputs
+are written INTO the closed-over tensors (``t.copy_(new)``) before each replay.
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+import torch
+
+
+class CapturedStep:
+    def __init__(self, fn: Callable[[], object], warmup: int = 2, device=None):
+        self.fn = fn
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                      # warm-up off the capturing stream (allocator, lazy inits)
+            for _ in range(max(1, warmup)):
+                fn()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.result = fn()                              # static output tensors of the captured iteration
+
+    def __call__(self):
+        self.graph.replay()
+        return self.result

@@ -243,3 +243,50 @@ def test_aabb_mask_flow_equals_compaction():
         assert rel_err(g1[k], g0[k]) < 1e-5, k
     for k in p0:
         assert rel_err(p1[k], p0[k]) < 2e-5, k
+
+
+def test_captured_iteration_replays_like_eager():
+    """nice_slam_amd.graphs.CapturedStep: a mapping-style iteration (get_samples -> aabb_keep -> render -> masked loss ->
+    backward) captured once and replayed with new inputs written into its static tensors equals the eager iteration."""
+    import nice_slam_amd as nsa
+    sc = make_scene(seed=61, n_rays=8, small=True)
+    H, W, fx, fy, cx, cy = sc["intr"]
+    renderer, dec, grids_dev = build_product(sc, DEV)
+    c = {k: v.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) for k, v in grids_dev.items()}
+    for p in dec.parameters():
+        p.requires_grad_(True)
+    depth_img, color_img, c2w = sc["depth_img"].to(DEV), sc["color_img"].to(DEV), sc["c2w"].to(DEV)
+    g = torch.Generator().manual_seed(4)
+    idx_batches = [torch.randint(H * W, (256,), generator=g).to(DEV) for _ in range(3)]
+    idx = idx_batches[0].clone()                                   # the static input of the captured iteration
+
+    def iteration():
+        for t in c.values():
+            t.grad = None
+        for p in dec.parameters():
+            p.grad = None
+        o, d, gd, gc = nsa.common.samples_from_indices(idx, 0, H, 0, W, fx, fy, cx, cy, c2w, depth_img, color_img)
+        keep, kmax = nsa.aabb_keep(o, d, gd, sc["bound"])
+        depth, _, color = renderer.render_batch_ray(c, dec, d, o, DEV, "color", gt_depth=gd, gt_max=kmax)
+        loss = (torch.abs(gd - depth) * (keep & (gd > 0))).sum() + 0.2 * (torch.abs(gc - color) * keep[:, None]).sum()
+        loss.backward()
+        return loss
+
+    def snapshot(loss):
+        return (loss.detach().clone(), {k: v.grad.clone() for k, v in c.items() if v.grad is not None},
+                {k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None})
+
+    eager = []
+    for b in idx_batches:
+        idx.copy_(b)
+        eager.append(snapshot(iteration()))
+    step = nsa.graphs.CapturedStep(iteration)
+    for b, (l0, g0, p0) in zip(idx_batches, eager):
+        idx.copy_(b)
+        l1, g1, p1 = snapshot(step())
+        assert abs(float(l1) - float(l0)) <= 1e-6 * abs(float(l0))
+        assert set(g1) == set(g0) and set(p1) == set(p0)
+        for k in g0:
+            assert rel_err(g1[k], g0[k]) < 1e-5, k
+        for k in p0:
+            assert rel_err(p1[k], p0[k]) < 2e-5, k
