@@ -28,6 +28,9 @@ FP32_PEAK = 157.3e12           # MI355X dense fp32 MFMA peak (MI355X_MICROARCH.m
 # necessary backward FLOP per ray of the dominant kernel (color-stage backward): SURVEY §8(d)
 #   (106 140 - 51 653) MAC/pt * 2 FLOP * 48 pts  (dX chain + stepped dW + d-embedding; the forward is a separate launch)
 BWD_COLOR_FLOP_PER_RAY = (106140 - 51653) * 2 * 48
+# what the colour backward kernel EXECUTES on the MFMA pipe: forward re-run + dX + dW of all three decoders, like the
+# reference's autograd (SURVEY §8(d) "reference-equivalent" column: 154 959 MAC/pt)
+BWD_COLOR_EXEC_FLOP_PER_RAY = 154959 * 2 * 48
 FWD_FLOP_PER_RAY = {"middle": 15479 * 2 * 48, "fine": 36078 * 2 * 48, "color": 51653 * 2 * 48}
 
 
@@ -348,7 +351,11 @@ def main():
                                "avg_kernel_ms": ms, "launches": cnt,
                                "measured": "HIP events recorded inside nsr_render_bwd on the launch stream, eager iterations of this process"
                                            + (" (the timed region replays the captured graph of the same kernels)" if use_graph else ""),
-                               "algorithmic_flop_per_launch": rays_launch * BWD_COLOR_FLOP_PER_RAY}
+                               "algorithmic_flop_per_launch": rays_launch * BWD_COLOR_FLOP_PER_RAY,
+                               "executed_frac": (rays_launch * BWD_COLOR_EXEC_FLOP_PER_RAY / (ms * 1e-3)) / FP32_PEAK
+                               if not args.stepped_grads_only else None,
+                               "executed_note": "MFMA work the kernel actually issues (forward re-run + dX + dW for every decoder, "
+                                                "the reference autograd's semantics) over the same peak; `frac` counts only the necessary part"}
         if world > 1 or force_dist:
             res["config"]["grad_exchange_MB_last_iter"] = round(rend.last_exchange_floats * 4 / 1e6, 2)
         res["kernel_ms"] = {f"render_bwd<{s}>": round(v[0], 4) for s, v in ksum.items()}
