@@ -252,3 +252,40 @@ def test_aabb_keep_matches_reference_expression(emu):
     emu.check(emu.nsr_aabb_keep(ptr(on), ptr(dn), ptr(zn), n, lo, hi, ptr(keep), ptr(kmax), None))
     assert np.array_equal(keep.astype(bool), ref.numpy())
     assert kmax[0] == depth[ref].max().item()
+
+
+def test_degenerate_shapes(emu):
+    """feature grids with a single cell along every axis (tiny scenes: the coarse level often is 1 x 1 x 1 ... cells), and
+    one / two samples per ray"""
+    import scene_util as su
+    from emu_harness import HostScene
+    from oracle import nice_oracle as orc
+    su.SCENES["tiny_grids"] = ([[-0.7, 0.8], [-0.6, 0.7], [-0.5, 0.6]], dict(su.GRID_LEN, coarse=2.1, middle=0.9),
+                               (48, 64, 60.0, 60.0, 31.5, 23.5))
+    s = make_scene(seed=3, n_rays=7, scene="tiny_grids")
+    assert tuple(s["grids"]["grid_coarse"].shape[2:]) == (1, 1, 1) and tuple(s["grids"]["grid_middle"].shape[2:]) == (1, 1, 1)
+    sc = _host_scene(emu, s["grids"], s["params"], s["bound"].numpy())
+    for stage in ("coarse", "middle", "color"):
+        fwd = sc.forward(stage, s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy())
+        ref = oracle_render(s, stage, backward=True)
+        res = sc.backward(stage, fwd, s["w"]["depth"].numpy(), s["w"]["var"].numpy(), s["w"]["rgb"].numpy())
+        for k in ("depth", "var", "rgb"):
+            assert rel_err(fwd[k], ref[k]) < TOL, (stage, k)
+        for k, v in ref.items():
+            if k in res:
+                assert rel_err(res[k], v) < TOL, (stage, k)
+    s = make_scene(seed=4, n_rays=5, small=True)
+    for ns, nsurf in ((1, 0), (1, 1)):
+        hs = HostScene(emu, s["grids"], s["params"], s["bound"].numpy(), 2.0, n_samples=ns, n_surface=nsurf)
+        fwd = hs.forward("color", s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy())
+        grids = {k: v.clone().requires_grad_(True) for k, v in s["grids"].items()}
+        params = {k: v.clone().requires_grad_(True) for k, v in s["params"].items()}
+        depth, var, rgb = orc.render_batch_ray(grids, params, s["rays_d"], s["rays_o"], "color", s["gt_depth"], s["bound"],
+                                               n_samples=ns, n_surface=nsurf)
+        for k, v in (("depth", depth), ("var", var), ("rgb", rgb)):
+            assert rel_err(fwd[k], v.detach()) < TOL, (ns, nsurf, k)
+        w = s["w"]
+        ((depth * w["depth"]).sum() + (var * w["var"]).sum() + (rgb * w["rgb"]).sum()).backward()
+        res = hs.backward("color", fwd, w["depth"].numpy(), w["var"].numpy(), w["rgb"].numpy())
+        for k in ("grid_middle", "grid_fine", "grid_color"):
+            assert rel_err(res["d_" + k], grids[k].grad) < TOL, (ns, nsurf, k)
