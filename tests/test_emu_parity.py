@@ -289,3 +289,45 @@ def test_degenerate_shapes(emu):
         res = hs.backward("color", fwd, w["depth"].numpy(), w["var"].numpy(), w["rgb"].numpy())
         for k in ("grid_middle", "grid_fine", "grid_color"):
             assert rel_err(res["d_" + k], grids[k].grad) < TOL, (ns, nsurf, k)
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_randomised_configurations(emu, seed):
+    """random stage / sample counts / ray count / persistent-grid cap / missing depth, forward + full backward vs the oracle"""
+    from emu_harness import HostScene
+    from oracle import nice_oracle as orc
+    rng = np.random.RandomState(1000 + seed)
+    stage = ["coarse", "middle", "fine", "color"][rng.randint(4)]
+    ns = int(rng.randint(1, 41))
+    nsurf = int(rng.randint(0, min(24, 64 - ns) + 1))
+    n = int(rng.randint(1, 12))
+    with_depth = bool(rng.rand() < 0.8)
+    cap = int(rng.randint(1, 4))
+    s = make_scene(seed=300 + seed, n_rays=n, small=True)
+    if n > 2:
+        s["gt_depth"][1] = 0.0
+    gd = s["gt_depth"] if with_depth else None
+    hs = HostScene(emu, s["grids"], s["params"], s["bound"].numpy(), 2.0, n_samples=ns, n_surface=nsurf)
+    fwd = hs.forward(stage, s["rays_o"].numpy(), s["rays_d"].numpy(), None if gd is None else gd.numpy())
+    grids = {k: v.clone().requires_grad_(True) for k, v in s["grids"].items()}
+    params = {k: v.clone().requires_grad_(True) for k, v in s["params"].items()}
+    o = s["rays_o"].clone().requires_grad_(True); d = s["rays_d"].clone().requires_grad_(True)
+    depth, var, rgb = orc.render_batch_ray(grids, params, d, o, stage, gd, s["bound"], n_samples=ns, n_surface=nsurf)
+    cfg = (stage, ns, nsurf, n, with_depth, cap)
+    for k, v in (("depth", depth), ("var", var), ("rgb", rgb)):
+        assert rel_err(fwd[k], v.detach()) < TOL, (cfg, k)
+    w = s["w"]
+    ((depth * w["depth"]).sum() + (var * w["var"]).sum() + (rgb * w["rgb"]).sum()).backward()
+    res = hs.backward(stage, fwd, w["depth"].numpy(), w["var"].numpy(), w["rgb"].numpy(), max_blocks=cap,
+                      overwrite_dparams=bool(seed & 1))
+    assert rel_err(res["d_rays_o"], o.grad) < TOL and rel_err(res["d_rays_d"], d.grad) < TOL, cfg
+    for k, v in grids.items():
+        if v.grad is not None:
+            assert rel_err(res["d_" + k], v.grad) < TOL, (cfg, k)
+    blob = {}
+    for k, v in params.items():
+        if v.grad is not None and ("dparam/" + k) in res:
+            blob.setdefault(k.split(".")[0], []).append((res["dparam/" + k].ravel(), v.grad.numpy().ravel()))
+    for dec, parts in blob.items():        # whole-decoder blob in the max norm (bias gradients are cancellation-limited, DESIGN §1)
+        a = np.concatenate([p[0] for p in parts]); b = np.concatenate([p[1] for p in parts])
+        assert rel_err(a, b) < TOL, (cfg, dec)
