@@ -49,8 +49,20 @@ class OracleOps:
         idx = torch.randint((H1 - H0) * (W1 - W0), (n,))
         return orc.pixel_rays(idx, H0, H1, W0, W1, s.fx, s.fy, s.cx, s.cy, c2w, depth, color)
 
-    def render(self, stage, rays_d, rays_o, gt_depth):
+    def render(self, stage, rays_d, rays_o, gt_depth, gt_max=None):
+        if gt_max is not None:
+            # the oracle takes max(gt_depth) itself: clamp the rejected rays' depths to the kept rays' maximum (their
+            # outputs are masked out of every loss term, so only the batch-global scalar matters)
+            gt_depth = torch.minimum(gt_depth, gt_max.to(gt_depth.dtype).reshape(()))
         return orc.render_batch_ray(self.c, self.P, rays_d, rays_o, stage, gt_depth, self.bound)
+
+    def keep_mask(self, rays_o, rays_d, gt_depth):
+        with torch.no_grad():                       # Mapper.py:471-481 / Tracker.py:95-104, fp64 by promotion
+            t = (self.bound.unsqueeze(0) - rays_o.detach().unsqueeze(-1)) / rays_d.detach().unsqueeze(-1)
+            t, _ = torch.min(torch.max(t, dim=2)[0], dim=1)
+            keep = t >= gt_depth
+            kmax = torch.where(keep, gt_depth, torch.zeros_like(gt_depth)).max().reshape(1)
+        return keep, kmax
 
     def color_decoder_params(self):
         return [v for k, v in self.P.items() if k.startswith("color_decoder.")]

@@ -171,12 +171,18 @@ class ProductOps:
         self.c = {k: v.to(self.device).requires_grad_(True) for k, v in nsa.grid_init(cfg, self.bound).items()}
         self.selector = nsa.FrustumSelector(self.bound, seq.H, seq.W, seq.fx, seq.fy, seq.cx, seq.cy)
         self.bound_dev = self.bound.to(self.device)
+        self._params = list(self.decoders.parameters())
 
     def get_samples(self, H0, H1, W0, W1, n, c2w, depth, color):
         return self.nsa.get_samples(H0, H1, W0, W1, n, self.H, self.W, self.fx, self.fy, self.cx, self.cy, c2w, depth, color, self.device)
 
-    def render(self, stage, rays_d, rays_o, gt_depth):
-        return self.renderer.render_batch_ray(self.c, self.decoders, rays_d, rays_o, self.device, stage, gt_depth=gt_depth)
+    def render(self, stage, rays_d, rays_o, gt_depth, gt_max=None):
+        return self.renderer.render_batch_ray(self.c, self.decoders, rays_d, rays_o, self.device, stage, gt_depth=gt_depth,
+                                              gt_max=gt_max)
+
+    def keep_mask(self, rays_o, rays_d, gt_depth):
+        """bounding-box pre-filter as a mask (nsr_aabb_keep): (keep, max depth over the kept rays)"""
+        return self.nsa.aabb_keep(rays_o, rays_d, gt_depth, self.bound)
 
     def color_decoder_params(self):
         return list(self.decoders.color_decoder.parameters())
@@ -194,7 +200,7 @@ class ProductOps:
     def zero_grads(self):
         for g in self.c.values():
             g.grad = None
-        for p in self.decoders.parameters():
+        for p in self._params:                  # cached: Module.parameters() walks the module tree on every call
             p.grad = None
 
 
@@ -214,12 +220,10 @@ class MiniSLAM:
         self.counters = {"tracking_iters": 0, "mapping_iters": 0, "tracking_rays": 0, "mapping_rays": 0}
         self.timers = {"tracking_s": 0.0, "mapping_s": 0.0}
 
-    # -- shared: drop rays whose depth lies outside the bound (Tracker.py:95-104, Mapper.py:471-481)
-    def _inside(self, o, d, depth):
-        with torch.no_grad():
-            t = (self.ops.bound_dev.to(o.dtype)[None] - o.detach()[..., None]) / d.detach()[..., None]      # (N,3,2)
-            t = t.max(2)[0].min(1)[0]
-            return t >= depth
+    # The reference drops the rays whose depth lies outside the bound by boolean-mask compaction (Tracker.py:95-104,
+    # Mapper.py:471-481) and indexes its loss terms with further masks -- a host synchronisation each.  Here the batch
+    # keeps its size: ops.keep_mask() gives the same mask plus the kept rays' maximum depth (the batch-global scalar of
+    # the renderer), and every loss term is weighted by its mask.  Same loss, same gradients, no sync inside an iteration.
 
     # -- Tracker.optimize_cam_in_batch (Tracker.py:71-128)
     def _track_iter(self, cam, color, depth, opt):
@@ -228,25 +232,25 @@ class MiniSLAM:
         c2w = get_camera_from_tensor(cam)
         He, We = tc["ignore_edge_H"], tc["ignore_edge_W"]
         o, d, gd, gc = self.ops.get_samples(He, self.H - He, We, self.W - We, tc["pixels"], c2w, depth, color)
-        m = self._inside(o, d, gd)
-        o, d, gd, gc = o[m], d[m], gd[m], gc[m]
+        keep, kmax = self.ops.keep_mask(o, d, gd)
         self.ops.zero_grads()
-        dep, unc, col = self.ops.render("color", d, o, gd)
+        dep, unc, col = self.ops.render("color", d, o, gd, gt_max=kmax)
         unc = unc.detach()
-        if tc["handle_dynamic"]:
-            tmp = torch.abs(gd - dep) / torch.sqrt(unc + 1e-10)
-            mask = (tmp < 10 * tmp.median()) & (gd > 0)
+        tmp = torch.abs(gd - dep) / torch.sqrt(unc + 1e-10)
+        if tc["handle_dynamic"]:                       # median over the kept rays only, like the compacted batch
+            med = torch.nanmedian(torch.where(keep, tmp.detach(), torch.full_like(tmp, float("nan"))))
+            mask = (tmp < 10 * med) & (gd > 0) & keep
         else:
-            mask = gd > 0
-        loss = (torch.abs(gd - dep) / torch.sqrt(unc + 1e-10))[mask].sum()
+            mask = (gd > 0) & keep
+        loss = torch.where(mask, tmp, torch.zeros_like(tmp)).sum()
         if tc["use_color_in_tracking"]:
-            loss = loss + tc["w_color_loss"] * torch.abs(gc - col)[mask].sum()
+            loss = loss + tc["w_color_loss"] * torch.where(mask[:, None], torch.abs(gc - col), torch.zeros_like(col)).sum()
         loss.backward()
         opt.step()
         opt.zero_grad()
         self.counters["tracking_iters"] += 1
         self.counters["tracking_rays"] += int(o.shape[0])
-        return float(loss.item())
+        return loss.detach()
 
     # -- Tracker.run, one frame (Tracker.py:176-256)
     def track(self, idx, color, depth):
@@ -259,12 +263,14 @@ class MiniSLAM:
             init = pre
         cam = get_tensor_from_camera(init.detach()).to(self.device).requires_grad_(True)
         opt = torch.optim.Adam([cam], lr=tc["lr"])
-        best, best_loss = cam.clone().detach(), 1e10          # iters == 0: the motion-model prediction alone
-        for _ in range(tc["iters"]):
-            loss = self._track_iter(cam, color, depth, opt)
-            if loss < best_loss:
-                best_loss, best = loss, cam.clone().detach()
-        self.last_track_loss = best_loss
+        best, self.last_track_loss = cam.clone().detach(), float("nan")          # iters == 0: the motion-model prediction alone
+        if tc["iters"] > 0:                              # Tracker.py:236-246: keep the pose of the smallest loss (one sync per frame)
+            losses, cams = [], []
+            for _ in range(tc["iters"]):
+                losses.append(self._track_iter(cam, color, depth, opt))
+                cams.append(cam.clone().detach())
+            k = int(torch.argmin(torch.stack(losses)))
+            best, self.last_track_loss = cams[k], float(losses[k])
         return to44(get_camera_from_tensor(best)), init
 
     # -- Mapper.keyframe_selection_overlap (Mapper.py:166-228)
@@ -348,20 +354,19 @@ class MiniSLAM:
                 o, d, gd, gc = ops.get_samples(0, self.H, 0, self.W, pix, c2w, f_depth, f_color)
                 ro.append(o.float()); rd.append(d.float()); gds.append(gd.float()); gcs.append(gc.float())
             o, d, gd, gc = torch.cat(ro), torch.cat(rd), torch.cat(gds), torch.cat(gcs)
-            m = self._inside(o, d, gd)
-            o, d, gd, gc = o[m], d[m], gd[m], gc[m]
-            dep, _, col = ops.render(stage, d, o, gd)
-            dm = gd > 0
-            loss = torch.abs(gd[dm] - dep[dm]).sum()
+            keep, kmax = ops.keep_mask(o, d, gd)
+            dep, _, col = ops.render(stage, d, o, gd, gt_max=kmax)
+            dm = keep & (gd > 0)
+            loss = torch.where(dm, torch.abs(gd - dep), torch.zeros_like(dep)).sum()
             if stage == "color":
-                loss = loss + mc["w_color_loss"] * torch.abs(gc - col).sum()
+                loss = loss + mc["w_color_loss"] * torch.where(keep[:, None], torch.abs(gc - col), torch.zeros_like(col)).sum()
             loss.backward()
             opt.step()
             opt_grid.step({"grid_middle": st["middle_lr"] * lr_factor, "grid_fine": st["fine_lr"] * lr_factor,
                            "grid_color": st["color_lr"] * lr_factor})
             self.counters["mapping_iters"] += 1
             self.counters["mapping_rays"] += int(o.shape[0])
-        self.last_map_loss = float(loss.item())
+        self.last_map_loss = float(loss.item())                          # the only host read of the call
 
         if BA:                                                             # Mapper.py:527-541
             cam_id = 0
