@@ -190,6 +190,9 @@ class ShardedRenderer:
     def render_batch_ray(self, c, decoders, rays_d, rays_o, device, stage, gt_depth=None, gt_max=None):
         world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
         n = rays_o.shape[0]
+        if n < world:            # fewer rays than ranks: every rank renders the whole (tiny) batch itself -- identical results
+            return self.renderer.render_batch_ray(c, decoders, rays_d, rays_o, device, stage, gt_depth=gt_depth, **(
+                {"gt_max": gt_max} if gt_max is not None else {}))     # everywhere, no empty shard, no collective to mismatch
         sizes = [shard_range(n, world, r)[1] - shard_range(n, world, r)[0] for r in range(world)]
         lo, hi = shard_range(n, world, rank)
         if stage == "coarse":

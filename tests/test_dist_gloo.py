@@ -136,6 +136,39 @@ def test_two_rank_masked_gradient_exchange():
     assert rel_err(res[0][k][m], full[m]) > 1e-2
 
 
+def _tiny_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from scene_util import make_scene
+    from nice_slam_amd.parallel import ShardedRenderer
+    sc = make_scene(seed=5, n_rays=1, small=True)
+    grids = {k: v.clone().requires_grad_(True) for k, v in sc["grids"].items()}
+    rend = ShardedRenderer(OracleRenderer(sc))
+    depth, var, rgb = rend.render_batch_ray(grids, sc["params"], sc["rays_d"], sc["rays_o"], "cpu", "middle", gt_depth=sc["gt_depth"])
+    depth.sum().backward()
+    q.put((rank, float(depth[0]), float(grids["grid_middle"].grad.abs().sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fewer_rays_than_ranks_does_not_shard():
+    """1 ray on 2 ranks: no empty shard (whose missing backward would leave the other rank alone in a collective)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tiny_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1:] == res[1][1:] and res[0][2] > 0
+
+
 def test_shard_range_partition():
     from nice_slam_amd.parallel import shard_range
     for n in (0, 1, 7, 8, 1000, 100003):
