@@ -1546,8 +1546,8 @@ NSR_KERNEL void aabb_keep_kernel(const AabbParams P) {
     for (int a = 0; a < 3; ++a) {
         const double o = (double)P.rays_o[r * 3 + a], d = (double)P.rays_d[r * 3 + a];
         const double t0 = (P.lo[a] - o) / d, t1 = (P.hi[a] - o) / d;
-        const double m = t0 > t1 ? t0 : t1;                       // torch.max(t, dim=2): NaN-free inputs assumed, like the callers
-        t = (a == 0 || m < t) ? m : t;
+        const double m = tmax(t0, t1);                            // torch.max(t, dim=2) / torch.min(., dim=1): NaN-propagating, like ray_far_bb
+        t = (a == 0) ? m : tmin(t, m);
     }
     const float gd = P.gt_depth[r];
     const bool k = t >= (double)gd;

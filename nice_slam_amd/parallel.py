@@ -113,6 +113,7 @@ class ShardedRenderer:
         self.group = group
         self._rows = {}                 # grid key -> int64 indices of the selected voxels ([Z,Y,X] raster order)
         self._pending_flat = None       # decoder-gradient blob waiting to ride with the packed grid rows
+        self._pending_publish = None    # ... and the renderer's callback that publishes it as Parameter.grad afterwards
         self.last_exchange_floats = 0   # size of the most recent gradient exchange (diagnostics / bench)
 
     def __getattr__(self, name):
@@ -130,20 +131,30 @@ class ShardedRenderer:
     def _all_reduce(self, t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
-    def _reduce_flat(self, d_grids, gflat: Optional[torch.Tensor]):
+    def _reduce_flat(self, d_grids, gflat: Optional[torch.Tensor], publish=None) -> bool:
         """Renderer hook, called right after the backward kernel is enqueued, before the grid gradients are returned to
-        autograd (so before ``_SumGrads.backward`` of the same call)."""
+        autograd (so before ``_SumGrads.backward`` of the same call).  Returns True when the decoder-gradient blob was
+        parked to ride with the packed voxel rows: ``publish`` (which turns the blob into ``Parameter.grad``s) is then
+        called by ``_reduce_grid_grads`` / ``_flush_pending`` AFTER the exchange -- publishing earlier would let an
+        accumulation into already existing ``.grad`` tensors read rank-local values."""
         if gflat is None:
-            return
+            return False
         if d_grids and self._rows:
-            self._pending_flat = gflat          # rides with the packed voxel rows
-        else:
-            self._all_reduce(gflat)
+            self._flush_pending()
+            self._pending_flat, self._pending_publish = gflat, publish
+            return True
+        self._all_reduce(gflat)
+        return False
 
     def _flush_pending(self):
         if self._pending_flat is not None:
             self._all_reduce(self._pending_flat)
-            self._pending_flat = None
+            self._publish_pending()
+
+    def _publish_pending(self):
+        publish, self._pending_flat, self._pending_publish = self._pending_publish, None, None
+        if publish is not None:
+            publish()
 
     def _reduce_grid_grads(self, keys, gs):
         out, packed, floats = [], [], 0
@@ -162,7 +173,6 @@ class ShardedRenderer:
                     rows = self._rows[k] = rows.to(v.device)
                 packed.append((v, axis, rows))
         flat = self._pending_flat
-        self._pending_flat = None
         if packed:
             sizes = [rows.numel() * v.shape[1 - axis] for v, axis, rows in packed]
             total = sum(sizes) + (flat.numel() if flat is not None else 0)
@@ -184,6 +194,7 @@ class ShardedRenderer:
         elif flat is not None:
             self._all_reduce(flat)
             floats += flat.numel()
+        self._publish_pending()                 # the decoder blob is reduced now: expose it as Parameter.grad
         self.last_exchange_floats = floats
         return out
 

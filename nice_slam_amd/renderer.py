@@ -230,14 +230,21 @@ class _RenderFn(torch.autograd.Function):
         if renderer.profile_events is not None:           # bench.py: hipEvent pair around the main backward kernel
             b.ev_start, b.ev_stop = renderer.profile_events(stage)
         lib.check(lib.nsr_render_bwd(C.byref(a), C.byref(b), stream), "nsr_render_bwd")
-        if reduce_hook is not None:                       # multi-GPU: sum shard gradients (parallel.py)
-            reduce_hook([g for g in d_grids if g is not None], gflat)
-        for s, need in zip(slots, need_par):
-            if need:
-                if s in direct:
-                    decoders.sub(s).grad_done(direct[s][1])
-                else:
-                    decoders.sub(s).publish_grads(gflat[offs[s]:offs[s] + param_count(s)])
+        def publish():
+            for s, need in zip(slots, need_par):
+                if need:
+                    if s in direct:
+                        decoders.sub(s).grad_done(direct[s][1])
+                    else:
+                        decoders.sub(s).publish_grads(gflat[offs[s]:offs[s] + param_count(s)])
+
+        # multi-GPU (parallel.py): the hook sums the shard gradients.  It may DEFER the decoder blob (to let it ride in the
+        # same collective as the grid rows, which autograd hands over a moment later); the `.grad` tensors are then
+        # published by the hook after that exchange -- never before, or an accumulation into pre-existing `.grad`s would
+        # consume rank-local values
+        deferred = reduce_hook is not None and bool(reduce_hook([g for g in d_grids if g is not None], gflat, publish))
+        if not deferred:
+            publish()
         ctx.keep = ctx.args = None
         return (None, d_o if need_o else None, d_d if need_d else None, *d_grids, *([None] * len(slots)))
 

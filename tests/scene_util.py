@@ -93,16 +93,43 @@ def oracle_render(sc, stage, backward=False, with_depth=True, rays=None, lo=torc
     return out
 
 
-def parity_failures(got, sc, stage, tol=1e-4, backward=True, with_depth=True, rays=None, ref=None):
+def oracle_render_chunked(sc, stage, chunk=10000, lo=torch.float32):
+    """``oracle_render(..., backward=True)`` over a batch too large to hold the oracle's autograd graph at once (100k rays
+    = 4.8 M points): rays are independent once the batch-global ``max(gt_depth)`` (Renderer.py:109,144) is shared, so
+    every chunk gets the maximum-depth ray appended with zero loss weight; outputs are concatenated, the additive grid /
+    parameter gradients summed."""
+    n = sc["rays_o"].shape[0]
+    j = int(torch.argmax(sc["gt_depth"]))
+    out, acc = {}, {}
+    parts = {k: [] for k in ("depth", "var", "rgb", "d_rays_o", "d_rays_d")}
+    for lo_i in range(0, n, chunk):
+        sl = slice(lo_i, min(n, lo_i + chunk))
+        sub = dict(sc)
+        for k in ("rays_o", "rays_d", "gt_depth"):
+            sub[k] = torch.cat([sc[k][sl], sc[k][j:j + 1]])
+        sub["w"] = {k: torch.cat([v[sl], torch.zeros_like(v[:1])]) for k, v in sc["w"].items()}
+        r = oracle_render(sub, stage, backward=True, lo=lo)
+        for k in parts:
+            parts[k].append(r[k][:-1])
+        for k, v in r.items():
+            if k.startswith("d_grid") or k.startswith("dparam/"):
+                acc[k] = v.clone() if k not in acc else acc[k] + v
+    out.update({k: torch.cat(v) for k, v in parts.items()})
+    out.update(acc)
+    return out
+
+
+def parity_failures(got, sc, stage, tol=1e-4, backward=True, with_depth=True, rays=None, ref=None, truth_fn=None):
     """Keys of ``got`` that are NOT at parity with the reference path.
 
     Primary gate, every tensor: max|a-b| / max|b| <= tol against the fp32 oracle (BASELINE.json north_star).
     Secondary gate, parameter gradients only: a handful of them are heavily cancelling sums over all samples (the
     occupancy-bias gradient d bo = sum d occ and the fc_c.4 bias that is proportional to it): there the reference's OWN
-    fp32 result moves by 4e-4 .. 2e-3 between CPUs / against an fp64 evaluation, i.e. the per-tensor gate is below the
-    noise floor of the reference arithmetic.  Such a tensor passes iff (a) the decoder's whole flat gradient blob --
-    the unit the kernels produce -- is inside tol in the same max-norm, and (b) the tensor is within 1e-2 of the fp64
-    truth (no gross error).  Everything else must pass the primary gate."""
+    fp32 result sits 1-2e-3 away from an fp64 evaluation of the same graph, i.e. the per-tensor gate is below the noise
+    floor of the reference arithmetic.  Such a tensor passes iff (a) the decoder's whole flat gradient blob -- the unit
+    the kernels produce -- is inside tol in the same max-norm, and (b) its distance to the fp64 truth is at most TWICE
+    the distance of the fp32 oracle's own value of that tensor to the same truth (the product may not be noisier than
+    2x the reference itself).  Everything else must pass the primary gate."""
     ref = ref or oracle_render(sc, stage, backward=backward, with_depth=with_depth, rays=rays)
     bad = [k for k in ref if rel_err(got[k], ref[k]) >= tol]
     if not bad:
@@ -119,10 +146,12 @@ def parity_failures(got, sc, stage, tol=1e-4, backward=True, with_depth=True, ra
         blob_r = torch.cat([ref[q].reshape(-1).double() for q in keys])
         e_blob = rel_err(blob_g, blob_r)
         if truth is None:
-            truth = oracle_render(sc, stage, backward=backward, with_depth=with_depth, rays=rays, lo=torch.float64)
+            truth = truth_fn() if truth_fn is not None else \
+                oracle_render(sc, stage, backward=backward, with_depth=with_depth, rays=rays, lo=torch.float64)
         e_truth = rel_err(got[k], truth[k])
-        if e_blob >= tol or e_truth >= 1e-2:
-            out.append((k, rel_err(got[k], ref[k]), e_blob, e_truth))
+        e_ref = rel_err(ref[k], truth[k])                       # the reference's own fp32 noise on this tensor
+        if e_blob >= tol or e_truth > max(2.0 * e_ref, tol):
+            out.append((k, rel_err(got[k], ref[k]), e_blob, e_truth, e_ref))
     return out
 
 

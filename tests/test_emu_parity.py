@@ -239,6 +239,9 @@ def test_aabb_keep_matches_reference_expression(emu):
     o = ((torch.rand((n, 3), generator=g) - 0.5) * 3.0).float()
     d = torch.randn((n, 3), generator=g).float()
     d[::7, 1] = 0.0                                            # axis-parallel components: +-inf slabs
+    d[5::21, 0] = 0.0                                          # ... and starting ON the slab plane (-2.0 is exact in fp32): 0/0 = NaN;
+    o[5::21, 0] = -2.0                                         # torch.max / torch.min propagate it, `t >= depth` is False: ray dropped
+    assert torch.isnan((bound.unsqueeze(0) - o.double().unsqueeze(-1)) / d.double().unsqueeze(-1)).any()
     depth = (torch.rand((n,), generator=g) * 4.0).float()
     depth[::11] = 0.0
     t = (bound.unsqueeze(0) - o.unsqueeze(-1)) / d.unsqueeze(-1)            # the reference's expression, fp64 by promotion

@@ -30,70 +30,90 @@ def cam_to_c2w(cam):           # src/common.py:163-176
 
 
 def test_mapping_style_iterations():
+    """A staged mapping loop (masked leaves, ``val[mask] = val_grad``, Adam; Mapper.py:303-333,394-401,457-519) on the CPU
+    oracle defines the trajectory; the HIP path is evaluated TEACHER-FORCED on that trajectory (same state, same pixels at
+    every iteration), so its loss and every gradient the optimiser would consume are compared in MAX-norm (Adam would turn
+    1e-6 noise on near-zero gradient components into lr-sized parameter differences in a free-running comparison)."""
     import nice_slam_amd as nsa
     sc = make_scene(seed=31, n_rays=8, small=True)
     H, W, fx, fy, cx, cy = sc["intr"]
     renderer, dec, grids_dev = build_product(sc, DEV)
     g = torch.Generator().manual_seed(2)
     masks = {k: (torch.rand(v.shape[2:], generator=g) < 0.7)[None, None].expand_as(v).clone() for k, v in sc["grids"].items()}
+    keys = ("grid_middle", "grid_fine", "grid_color")
     n_pix, iters = 300, 6
     idx = [torch.randint(H * W, (n_pix,), generator=g) for _ in range(iters)]
     stages = ["middle", "middle", "fine", "fine", "color", "color"]
     lr = {"middle": {"grid_middle": 0.1}, "fine": {"grid_middle": 0.005, "grid_fine": 0.005},
           "color": {"grid_middle": 0.005, "grid_fine": 0.005, "grid_color": 0.005, "dec": 0.005}}
+    col_names = [k for k in sc["params"] if k.startswith("color_decoder.")]
 
-    def run(side):
-        dev = DEV if side == "hip" else "cpu"
-        if side == "hip":
-            c = {k: v.detach().clone(memory_format=torch.preserve_format) for k, v in grids_dev.items()}
-            for p in dec.parameters():
-                p.requires_grad_(True); p.grad = None
-            dec_params = list(dec.color_decoder.parameters())
-        else:
-            c = {k: v.clone() for k, v in sc["grids"].items()}
-            P = {k: v.clone().requires_grad_(True) for k, v in sc["params"].items()}
-            dec_params = [v for k, v in P.items() if k.startswith("color_decoder.")]
-        leaves = {k: c[k][masks[k].to(dev)].clone().requires_grad_(True) for k in ("grid_middle", "grid_fine", "grid_color")}
-        groups = [{"params": dec_params, "lr": 0.0}] + [{"params": [leaves[k]], "lr": 0.0} for k in ("grid_middle", "grid_fine", "grid_color")]
-        opt = torch.optim.Adam(groups)
-        c2w, depth_img, color_img = sc["c2w"].to(dev), sc["depth_img"].to(dev), sc["color_img"].to(dev)
-        losses = []
-        for it in range(iters):
-            stage = stages[it]
-            for k in leaves:                                   # Mapper.py:394-401
-                val = c[k]
-                val[masks[k].to(dev)] = leaves[k]
-                c[k] = val
-            opt.param_groups[0]["lr"] = lr[stage].get("dec", 0.0)
-            for gi, k in enumerate(("grid_middle", "grid_fine", "grid_color")):
-                opt.param_groups[gi + 1]["lr"] = lr[stage].get(k, 0.0)
-            opt.zero_grad()
-            if side == "hip":
-                o, d, gd, gc = nsa.common.samples_from_indices(idx[it].to(dev), 0, H, 0, W, fx, fy, cx, cy, c2w, depth_img, color_img)
-                depth, unc, col = renderer.render_batch_ray(c, dec, d, o, dev, stage, gt_depth=gd)
-            else:
-                o, d, gd, gc = orc.pixel_rays(idx[it], 0, H, 0, W, fx, fy, cx, cy, c2w, depth_img, color_img)
-                depth, unc, col = orc.render_batch_ray(c, P, d, o, stage, gd, sc["bound"])
-            m = gd > 0
-            loss = torch.abs(gd[m] - depth[m]).sum()            # Mapper.py:487-493
-            if stage == "color":
-                loss = loss + 0.2 * torch.abs(gc - col).sum()
-            loss.backward()
-            opt.step()
-            opt.zero_grad()
-            for k in leaves:                                   # Mapper.py:511-519
-                val = c[k].detach()
-                val[masks[k].to(dev)] = leaves[k].clone().detach()
-                c[k] = val
-            losses.append(float(loss))
-        return losses, {k: v.detach().cpu() for k, v in leaves.items()}
+    # ---- reference trajectory on the CPU oracle
+    c = {k: v.clone() for k, v in sc["grids"].items()}
+    P = {k: v.clone().requires_grad_(True) for k, v in sc["params"].items()}
+    leaves = {k: c[k][masks[k]].clone().requires_grad_(True) for k in keys}
+    opt = torch.optim.Adam([{"params": [P[k] for k in col_names], "lr": 0.0}] + [{"params": [leaves[k]], "lr": 0.0} for k in keys])
+    traj = []
+    for it in range(iters):
+        stage = stages[it]
+        state = {k: v.detach().clone() for k, v in leaves.items()}
+        state.update({k: P[k].detach().clone() for k in col_names})
+        for k in keys:                                         # Mapper.py:394-401
+            val = c[k]; val[masks[k]] = leaves[k]; c[k] = val
+        opt.param_groups[0]["lr"] = lr[stage].get("dec", 0.0)
+        for gi, k in enumerate(keys):
+            opt.param_groups[gi + 1]["lr"] = lr[stage].get(k, 0.0)
+        opt.zero_grad()
+        o, d, gd, gc = orc.pixel_rays(idx[it], 0, H, 0, W, fx, fy, cx, cy, sc["c2w"], sc["depth_img"], sc["color_img"])
+        depth, unc, col = orc.render_batch_ray(c, P, d, o, stage, gd, sc["bound"])
+        m = gd > 0
+        loss = torch.abs(gd[m] - depth[m]).sum()                # Mapper.py:487-493
+        if stage == "color":
+            loss = loss + 0.2 * torch.abs(gc - col).sum()
+        loss.backward()
+        grads = {k: v.grad.detach().clone() for k, v in leaves.items() if v.grad is not None}
+        if stage == "color":
+            grads["color_blob"] = torch.cat([P[k].grad.reshape(-1) for k in col_names])
+        traj.append((state, float(loss.detach()), grads))
+        opt.step()
+        for k in keys:                                         # Mapper.py:511-519
+            val = c[k].detach(); val[masks[k]] = leaves[k].clone().detach(); c[k] = val
+    assert float((traj[-1][0]["grid_middle"] - traj[0][0]["grid_middle"]).abs().max()) > 0.05       # the trajectory moves
 
-    l_hip, leaves_hip = run("hip")
-    l_ref, leaves_ref = run("cpu")
-    assert np.allclose(l_hip, l_ref, rtol=2e-4), (l_hip, l_ref)
-    for k in leaves_ref:                                        # Adam turns tiny gradient noise into lr-sized steps: compare loosely
-        d = (leaves_hip[k] - leaves_ref[k]).abs()
-        assert float(d.mean()) < 1e-4, (k, float(d.mean()))
+    # ---- the HIP path on the same trajectory
+    cd = {k: v.detach().clone(memory_format=torch.preserve_format) for k, v in grids_dev.items()}
+    for p in dec.parameters():
+        p.requires_grad_(True)
+    col_params = dict(dec.color_decoder.named_parameters())
+    c2w, depth_img, color_img = sc["c2w"].to(DEV), sc["depth_img"].to(DEV), sc["color_img"].to(DEV)
+    mdev = {k: masks[k].to(DEV) for k in keys}
+    n_cmp = 0
+    for it in range(iters):
+        stage = stages[it]
+        state, ref_loss, ref_grads = traj[it]
+        lv = {k: state[k].to(DEV).requires_grad_(True) for k in keys}
+        with torch.no_grad():
+            for k in col_names:
+                col_params[k[len("color_decoder."):]].copy_(state[k])
+        for p in dec.parameters():
+            p.grad = None
+        for k in keys:
+            val = cd[k]; val[mdev[k]] = lv[k]; cd[k] = val
+        o, d, gd, gc = nsa.common.samples_from_indices(idx[it].to(DEV), 0, H, 0, W, fx, fy, cx, cy, c2w, depth_img, color_img)
+        depth, unc, col = renderer.render_batch_ray(cd, dec, d, o, DEV, stage, gt_depth=gd)
+        m = gd > 0
+        loss = torch.abs(gd[m] - depth[m]).sum()
+        if stage == "color":
+            loss = loss + 0.2 * torch.abs(gc - col).sum()
+        loss.backward()
+        assert abs(float(loss) - ref_loss) < 1e-5 * abs(ref_loss), (it, float(loss), ref_loss)
+        for k, gr in ref_grads.items():
+            got = torch.cat([col_params[n[len("color_decoder."):]].grad.reshape(-1) for n in col_names]) if k == "color_blob" else lv[k].grad
+            assert rel_err(got, gr) < 1e-4, (it, stage, k, rel_err(got, gr))
+            n_cmp += 1
+        for k in keys:
+            val = cd[k].detach(); val[mdev[k]] = lv[k].detach().clone(); cd[k] = val
+    assert n_cmp == 2 * 1 + 2 * 2 + 2 * 4
 
 
 def test_tracking_style_pose_gradient():
@@ -170,21 +190,13 @@ def test_masked_grid_adam_replaces_masked_leaf_flow():
         loss = (torch.abs(gd - depth) * (gd > 0)).sum()
         return loss + 0.2 * torch.abs(gc - col).sum() if stage == "color" else loss
 
+    # Both flows are stepped with the SAME gradient tensor (rendered once per iteration from flow B's grids, which stay
+    # equal to flow A's), so the comparison isolates the optimiser arithmetic and can be held in max-norm.
     # (A) reference flow: masked 1-D leaves + torch Adam + index_put write-back (Mapper.py:303-333,394-401,504,511-519)
     cA = {k: v.detach().clone(memory_format=torch.preserve_format) for k, v in grids_dev.items()}
     full = {k: vmasks[k][None, None].expand_as(cA[k]).to(DEV) for k in keys}
     leaves = {k: cA[k][full[k]].clone().requires_grad_(True) for k in keys}
     opt = torch.optim.Adam([{"params": [leaves[k]], "lr": 0.0} for k in keys])
-    for stage in stages:
-        for k in keys:
-            val = cA[k]; val[full[k]] = leaves[k]; cA[k] = val
-        for gi, k in enumerate(keys):
-            opt.param_groups[gi]["lr"] = lr[stage].get(k, 0.0)
-        opt.zero_grad()
-        loss_of(cA, stage).backward()
-        opt.step()
-        for k in keys:
-            val = cA[k].detach(); val[full[k]] = leaves[k].detach().clone(); cA[k] = val
     # (B) fused: dense grids are the parameters
     cB = {k: v.detach().clone(memory_format=torch.preserve_format).requires_grad_(k in keys) for k, v in grids_dev.items()}
     fused = nsa.MaskedGridAdam({k: cB[k] for k in keys}, {k: vmasks[k] for k in keys})
@@ -192,12 +204,21 @@ def test_masked_grid_adam_replaces_masked_leaf_flow():
         for k in keys:
             cB[k].grad = None
         loss_of(cB, stage).backward()
+        grads = {k: cB[k].grad for k in keys if cB[k].grad is not None}
+        for k in keys:
+            val = cA[k]; val[full[k]] = leaves[k].detach(); cA[k] = val      # Mapper.py:394-401
+        for gi, k in enumerate(keys):
+            opt.param_groups[gi]["lr"] = lr[stage].get(k, 0.0)
+            leaves[k].grad = grads[k][full[k]].clone() if k in grads else None
+        opt.step()
+        for k in keys:
+            val = cA[k].detach(); val[full[k]] = leaves[k].detach().clone(); cA[k] = val     # Mapper.py:511-519
         with torch.no_grad():
             fused.step({k: lr[stage].get(k, 0.0) for k in keys})
     for k in keys:
         a, b = cA[k].detach().cpu(), cB[k].detach().cpu()
         assert torch.equal(b[~full[k].cpu()], sc["grids"][k][~full[k].cpu()]), k          # unmasked voxels untouched
-        assert float((a - b).abs().mean()) < 2e-5 * float(a.abs().max()) + 1e-7, (k, float((a - b).abs().mean()))
+        assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()), (k, float((a - b).abs().max()), float(a.abs().max()))
         assert float((b - sc["grids"][k]).abs().max()) > 1e-4, k
 
 

@@ -80,23 +80,72 @@ def test_replica_room0_config(stage):
     _compare(hip_render(sc, stage, backward=True), oracle_render(sc, stage, backward=True), "room0/" + stage, sc, stage)
 
 
-def test_scannet_config_color():
-    """BASELINE configs[2]: ScanNet scene0000 shapes, 5000 rays (oracle ~10 s)."""
+@pytest.mark.parametrize("stage", ("middle", "fine", "color"))
+def test_scannet_config(stage):
+    """BASELINE configs[2]: ScanNet scene0000 shapes (47x85x81 fine/colour), 5000 rays = its mapping batch, every stage."""
     sc = make_scene(seed=22, n_rays=5000, scene="scannet_0000", fine_scale=1.0)
-    _compare(hip_render(sc, "color", backward=True), oracle_render(sc, "color", backward=True), "scannet/color", sc, "color")
+    _compare(hip_render(sc, stage, backward=True), oracle_render(sc, stage, backward=True), "scannet/" + stage, sc, stage)
 
 
-def test_apartment_config_fine():
-    """BASELINE configs[3]: Apartment grid shapes (81x53x107 fine/colour, 125 MB of grids), 5000 rays."""
+@pytest.mark.parametrize("stage", ("middle", "fine", "color"))
+def test_apartment_config(stage):
+    """BASELINE configs[3]: Apartment grid shapes (81x53x107 fine/colour, 125 MB of grids), 5000 rays, every stage."""
     sc = make_scene(seed=24, n_rays=5000, scene="apartment", fine_scale=1.0)
-    _compare(hip_render(sc, "fine", backward=True), oracle_render(sc, "fine", backward=True), "apartment/fine", sc, "fine")
+    _compare(hip_render(sc, stage, backward=True), oracle_render(sc, stage, backward=True), "apartment/" + stage, sc, stage)
 
 
 def test_synthetic_stress_shapes_color():
-    """BASELINE configs[4] geometry: bound +-5.12 m, 1024x1024 pinhole; parity at 2000 rays (the 100k-ray size is
-    covered by the property test below)."""
+    """BASELINE configs[4] geometry: bound +-5.12 m, 1024x1024 pinhole; a quick 2000-ray case (the full 100k rays follow)."""
     sc = make_scene(seed=25, n_rays=2000, scene="synthetic", fine_scale=1.0)
     _compare(hip_render(sc, "color", backward=True), oracle_render(sc, "color", backward=True), "synthetic/color", sc, "color")
+
+
+def test_synthetic_stress_full_size_vs_oracle():
+    """BASELINE configs[4] at its full size: 100 000 rays (4.8 M sample points), 64^3 fine / colour grids, colour stage,
+    forward + every gradient against the oracle (evaluated in 10k-ray chunks that share the batch-global max depth)."""
+    from scene_util import oracle_render_chunked
+    sc = make_scene(seed=26, n_rays=100_000, scene="synthetic", fine_scale=1.0)
+    got = hip_render(sc, "color", backward=True)
+    ref = oracle_render_chunked(sc, "color")
+    assert set(ref) <= set(got)
+    bad = parity_failures(got, sc, "color", tol=TOL, ref=ref, truth_fn=lambda: oracle_render_chunked(sc, "color", lo=torch.float64))
+    assert not bad, bad
+
+
+def test_replica_tracking_config():
+    """BASELINE configs[1], tracking side (configs/Replica/replica.yaml: 200 pixels from the image minus a 100-pixel
+    border, colour stage, gradient w.r.t. the rays only -- src/Tracker.py:91-127): outputs and ray gradients against the
+    oracle, and no grid / decoder gradient is produced."""
+    import nice_slam_amd as nsa
+    from oracle import nice_oracle as orc
+    sc = make_scene(seed=27, n_rays=8, scene="replica_room0", fine_scale=1.0)
+    H, W, fx, fy, cx, cy = sc["intr"]
+    g = torch.Generator().manual_seed(8)
+    idx = torch.randint((H - 200) * (W - 200), (200,), generator=g)
+    dev = "cuda:0"
+    renderer, dec, grids = build_product(sc, dev)
+    for p in dec.parameters():
+        p.requires_grad_(False)
+    c2w = sc["c2w"][:3].clone().to(dev).requires_grad_(True)
+    o, d, gd, gc = nsa.common.samples_from_indices(idx.to(dev), 100, H - 100, 100, W - 100, fx, fy, cx, cy, c2w,
+                                                   sc["depth_img"].to(dev), sc["color_img"].to(dev))
+    depth, unc, col = renderer.render_batch_ray(grids, dec, d, o, dev, "color", gt_depth=gd)
+
+    def loss_fn(depth, unc, col, gd, gc):                       # Tracker.py:110-123
+        unc = unc.detach()
+        tmp = torch.abs(gd - depth) / torch.sqrt(unc + 1e-10)
+        mask = (tmp < 10 * tmp.median()) & (gd > 0)
+        return (torch.abs(gd - depth) / torch.sqrt(unc + 1e-10))[mask].sum() + 0.5 * torch.abs(gc - col)[mask].sum()
+
+    loss_fn(depth, unc, col, gd, gc).backward()
+    c2 = sc["c2w"][:3].clone().requires_grad_(True)
+    o2, d2, gd2, gc2 = orc.pixel_rays(idx, 100, H - 100, 100, W - 100, fx, fy, cx, cy, c2, sc["depth_img"], sc["color_img"])
+    assert torch.equal(o.detach().cpu(), o2.detach()) and torch.equal(d.detach().cpu(), d2.detach())
+    depth2, unc2, col2 = orc.render_batch_ray(sc["grids"], sc["params"], d2, o2, "color", gd2, sc["bound"])
+    loss_fn(depth2, unc2, col2, gd2, gc2).backward()
+    for a, b, nm in ((depth, depth2, "depth"), (unc, unc2, "var"), (col, col2, "rgb"), (c2w.grad, c2.grad, "d_c2w")):
+        assert rel_err(a, b) < TOL, (nm, rel_err(a, b))
+    assert all(p.grad is None for p in dec.parameters()) and all(v.grad is None for v in grids.values())
 
 
 def test_edge_cases():
