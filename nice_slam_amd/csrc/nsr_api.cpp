@@ -1,5 +1,6 @@
 // nsr_api.cpp -- the C ABI of libnsr.so (see include/nsr.h).  Compiled as HIP for gfx950.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -21,16 +22,19 @@ constexpr int kLdsLimit = 160 * 1024;
 
 inline int round16(int bytes) { return (bytes + 15) & ~15; }
 
-// forward: up to 12 tiles (768 threads, 3 waves/SIMD, <=168 VGPRs).  backward: up to kBwdTiles tiles so that the
-// register-hungry backward gets 2 waves/SIMD with the full 256-VGPR budget instead of spilling.
+// forward: up to 12 tiles (768 threads, 3 waves/SIMD, <=168 VGPRs).  backward: 4 waves (one per SIMD, the full 512-entry
+// register file each, nsr_bwd.h) that take the kBwdTiles tiles of a ray group in turns.
 constexpr int kBwdTiles = NSR_BWD_TILES;
-constexpr int kBwdWaves = NSR_BWD_WAVES;
+constexpr int kBwdWaves = nsr::kBwdWaves;
 int rays_per_block_t(int S, int max_tiles) {
     int rb = (max_tiles * nsr::kTile) / S;
     return rb < 1 ? 1 : rb;
 }
 int rays_per_block(int S) { return rays_per_block_t(S, kMaxTiles); }
-int rays_per_block_bwd(int S) { return rays_per_block_t(S, kBwdTiles); }
+int rays_per_block_bwd(int S) {                // at most 16 rays per group: the group's rays are staged in LDS (few samples per
+    const int rb = rays_per_block_t(S, kBwdTiles);   // ray only occur in tests; render configurations have 32 or 48)
+    return rb > 16 ? 16 : rb;
+}
 
 int stage_passes(int stage) { return stage == NSR_STAGE_COARSE ? 1 : 3; }
 
@@ -83,6 +87,7 @@ int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays,
         for (int i = 0; i < 3; ++i) {
             if (!(g.hi[i] > g.lo[i])) return fail("nsr: empty normalisation box");
             G.lo[i] = g.lo[i];
+            G.ext[i] = g.hi[i] - g.lo[i];
             G.inv[i] = 1.0 / (g.hi[i] - g.lo[i]);
         }
         const nsr_decoder &d = a->dec[s];
@@ -116,11 +121,22 @@ int fwd_lds_bytes(int stage, int npts) {
     return round16(3 * nsr::AUX_FLOATS * 4) + npts * (8 + 8 + 16) + wl * 4;
 }
 
-int bwd_lds_bytes(int stage, int npts, int tiles) {
-    const int npk = stage == NSR_STAGE_COARSE ? nsr::packed_total(0) : nsr::packed_total(2);   // largest packed stream of the stage
-    const int head = (nsr::AUX_FLOATS + npk + 3) & ~3;
-    const int stg = stage == NSR_STAGE_COARSE ? nsr::stg_floats(0) : nsr::stg_floats(2);     // largest staging region of the stage
-    return round16(head * 4 + npts * (8 + 8 + 16 + 24) + tiles * 132 * 4) + tiles * stg * 4;
+int bwd_lds_bytes(int stage, int npts, int rays, int waves) {
+    // every decoder pass of the launch lays LDS out for ITS decoder (nsr_bwd.h: bwd_pass): the launch needs the largest
+    const int first = stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE;
+    const int last = stage == NSR_STAGE_COARSE ? NSR_COARSE : stage;
+    int need = 0;
+    for (int kind = first; kind <= last; ++kind) {
+        const int head = (nsr::AUX_FLOATS + nsr::packed_total(kind) + 3) & ~3;
+        const int bytes = round16(head * 4 + npts * (8 + 8 + 16 + 24) + rays * 24) + waves * nsr::bwd_stg_floats(kind) * 4;
+        need = bytes > need ? bytes : need;
+    }
+    return need;
+}
+
+// per-wave accumulator slabs of the fine pass (nsr_bwd.h), behind the per-block gradient images
+long long slab_floats(int stage, long long blocks) {
+    return stage >= NSR_STAGE_FINE ? blocks * kBwdWaves * nsr::kSlabFloats : 0;
 }
 
 }  // namespace
@@ -131,20 +147,21 @@ int nsr_version(void) { return NSR_VERSION; }
 const char *nsr_last_error(void) { return g_err.c_str(); }
 
 int64_t nsr_param_count(int slot) { return (slot < 0 || slot > 3) ? -1 : nsr::param_total(slot); }
-int64_t nsr_packed_count(int slot) { return (slot < 0 || slot > 3) ? -1 : nsr::packed_total(slot); }
+int64_t nsr_packed_count(int slot) { return (slot < 0 || slot > 3) ? -1 : nsr::packed_buf_total(slot); }
 
 int64_t nsr_bwd_workspace_floats(int stage, int64_t n_rays, int n_samples_total, int max_blocks) {
     if (stage < 0 || stage > 3 || n_samples_total < 1 || n_samples_total > NSR_MAX_SAMPLES) return -1;
     const int rb = rays_per_block_bwd(n_samples_total);
     const long long groups = (n_rays + rb - 1) / rb;
-    const long long blocks = bwd_blocks(groups, max_blocks);
-    return (int64_t)stage_passes(stage) * (blocks > 0 ? blocks : 1) * max_param_count(stage);
+    long long blocks = bwd_blocks(groups, max_blocks);
+    if (blocks < 1) blocks = 1;
+    return (int64_t)stage_passes(stage) * blocks * max_param_count(stage) + slab_floats(stage, blocks);
 }
 
 int nsr_pack_params(int slot, const float *params, float *packed, void *stream) {
     if (slot < 0 || slot > 3) return fail("nsr_pack_params: slot out of range");
     if (!params || !packed) return fail("nsr_pack_params: null pointer");
-    const int n = nsr::packed_total(slot), tb = 256, nb = (n + tb - 1) / tb;
+    const int n = nsr::packed_buf_total(slot), tb = 256, nb = (n + tb - 1) / tb;
     switch (slot) {
         case 0: NSR_LAUNCH(nsr::pack_kernel<0>, dim3(nb), dim3(tb), 0, stream, params, packed); break;
         case 1: NSR_LAUNCH(nsr::pack_kernel<1>, dim3(nb), dim3(tb), 0, stream, params, packed); break;
@@ -183,19 +200,24 @@ int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream
     if (P.n_rays == 0) return 0;
     P.d_depth = b->d_depth; P.d_var = b->d_var; P.d_rgb = b->d_rgb; P.g_depth = b->depth;
     P.d_rays_o = b->d_rays_o; P.d_rays_d = b->d_rays_d;
+#ifdef NSR_TS
+    if (const char *e = getenv("NSR_DBG_PTR")) P.dbg = reinterpret_cast<long long *>(strtoull(e, nullptr, 16));
+#endif
     const int passes = stage_passes(P.stage);
     const int nblk = bwd_blocks(P.n_groups, b->max_blocks);
     bool any_params = false;
     for (int s = 0; s < 4; ++s) any_params |= P.dec[s].dparams != nullptr;
     P.partial_stride = max_param_count(P.stage);
     if (any_params) {
-        const long long need = (long long)passes * nblk * P.partial_stride;
+        const long long images = (long long)passes * nblk * P.partial_stride;
+        const long long need = images + slab_floats(P.stage, nblk);
         if (!b->workspace || b->workspace_floats < need) return fail("nsr_render_bwd: workspace too small");
         P.partials = b->workspace;
+        P.slabs = b->workspace + images;
     }
     const int npts = P.rays_per_block * P.S;
-    const int waves = P.tiles_per_block < kBwdWaves ? P.tiles_per_block : kBwdWaves;
-    const int lds = bwd_lds_bytes(P.stage, npts, waves);
+    const int waves = kBwdWaves;
+    const int lds = bwd_lds_bytes(P.stage, npts, P.rays_per_block, waves);
     const dim3 grid(nblk, passes), block(64 * waves);
 #define NSR_BWD(ST)                                                                              \
     case ST:                                                                                     \

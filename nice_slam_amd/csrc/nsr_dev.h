@@ -47,6 +47,8 @@ NSR_DEV void wave_fence() {
 }
 // keep the instruction scheduler from hoisting the next operand stream above this point
 NSR_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// keep a loaded value (and thereby its load) alive up to this point without doing anything with it
+NSR_DEV void keep_alive(float v) { asm volatile("" ::"v"(v)); }
 // compiler-only memory clobber: stops loop-invariant code motion of loads across loop iterations
 NSR_DEV void loop_fence() { asm volatile("" ::: "memory"); }
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter
@@ -54,6 +56,18 @@ NSR_DEV void loop_fence() { asm volatile("" ::: "memory"); }
 // atomics of the wave (grid scatter, gradient-image stores: microseconds each).  No barrier in these kernels hands
 // global data from one wave to another, so only lgkmcnt is drained (cdna_hip_programming.md, "pipelining across barriers").
 NSR_DEV void block_sync() { __syncthreads(); }
+
+// Profiling stamps (tests/perf/ts_probe.py): compiled in only with -DNSR_TS (tools/build_ts.sh); the product build has none.
+struct Dbg {
+    long long *p;        // this wave's slot array, or NULL
+    NSR_DEV void stamp(int slot) const {
+#ifdef NSR_TS
+        if (p && (threadIdx.x & 63) == 0) p[slot] = (long long)__builtin_amdgcn_s_memtime();
+#else
+        (void)slot;
+#endif
+    }
+};
 
 NSR_DEV void atomic_add_global(float *p, float v) { unsafeAtomicAdd(p, v); }
 NSR_DEV void atomic_add_lds(float *p, float v) { atomicAdd(p, v); }

@@ -8,9 +8,10 @@
 //   * y = W x is a chain of v_mfma_f32_16x16x4_f32 with A = packed weights staged in LDS (one 16-byte read per lane
 //     feeds four MFMAs) and B = the register that already holds x, output again CL,
 //   * dx = W^T dy reads the same packed stream through a transposed index, B = the dy registers,
-//   * dW = dy^T x contracts over points: each wave stages its tile's operands in LDS ("channel rows": one 16-byte read =
-//     the operand of four k-steps) and ONE owner wave per 16x16 weight-block pair contracts over all tiles of the block;
-//     results go to a per-block image of the flat gradient blob in global memory (L2), summed by reduce_partials_kernel.
+//   * dW = dy^T x contracts over points: each wave re-lays its tile's operands out through a private LDS staging tile
+//     ("channel rows": one 16-byte read = the operand of four k-steps) and accumulates EVERY 16x16 block of the decoder's
+//     dW in its own registers for the whole kernel (nsr_bwd.h); one image of the flat gradient blob per block goes to
+//     global memory at the end, summed over blocks by reduce_partials_kernel.
 // References: Renderer.render_batch_ray (src/utils/Renderer.py:63-198), eval_points (:23-61),
 // NICE/MLP/MLP_no_xyz forward (src/conv_onet/models/decoder.py:168-203,254-274,312-342),
 // raw2outputs_nerf_color (src/common.py:204-245), ATen grid_sampler_3d (GridSampler.h).
@@ -18,13 +19,6 @@
 #include "nsr_dev.h"
 #include "nsr_layout.h"
 #include "../../include/nsr.h"
-
-#ifndef NSR_BWD_TILES
-#define NSR_BWD_TILES 6     // tiles per ray group of the backward kernel (see nsr_api.cpp)
-#endif
-#ifndef NSR_BWD_WAVES
-#define NSR_BWD_WAVES 6     // waves per backward block; a group's tiles are processed NSR_BWD_WAVES at a time
-#endif
 
 namespace nsr {
 
@@ -51,7 +45,8 @@ struct GridDev {
     float *dfeat;
     int Z, Y, X;
     double lo[3];
-    double inv[3];      // 1 / (hi - lo)
+    double ext[3];      // hi - lo (the divisor of normalize_3d_coordinate, common.py:281-283)
+    double inv[3];      // 1 / (hi - lo): only scales the coordinate GRADIENT (d p = d u * (n-1)/2 * 2/(hi-lo))
 };
 
 struct DecDev {
@@ -80,6 +75,8 @@ struct RenderParams {
     float *d_rays_o, *d_rays_d;
     float *partials;          // [3 passes][gridDim.x][max param count]
     int partial_stride;       // floats between two blocks' partial images
+    float *slabs;             // fine pass: per-wave global accumulator slabs [gridDim.x][waves][kSlabFloats] (nsr_bwd.h)
+    long long *dbg;           // profiling stamps (NSR_TS builds only), else NULL
     // eval_points only
     const double *points;
     long long n_points;
@@ -87,13 +84,38 @@ struct RenderParams {
 };
 
 // ------------------------------------------------------------------------------------------------
-// parameter packing: flat blob -> MFMA operand stream, four k-steps per lane contiguous (one 16-byte read each)
-//   packed[m.pk + ((T*2 + Tp)*64 + lane)*4 + r] = W[16*Tp + (lane&15)][kbeg + 16T + 4(lane>>4) + r]
+// parameter packing: flat blob -> [aux table | MFMA operand stream]  (what the render kernels copy into LDS, verbatim)
+//   aux table (AUX_FLOATS): biases, fc_c biases, output layer, Fourier matrix in the order the kernels read them
+//   stream, four k-steps per lane contiguous (one 16-byte read each):
+//   stream[m.pk + ((T*2 + Tp)*64 + lane)*4 + r] = W[16*Tp + (lane&15)][kbeg + 16T + 4(lane>>4) + r]
 // ------------------------------------------------------------------------------------------------
 template <int KIND>
+NSR_DEV float aux_value(const float *__restrict__ flat, int idx) {
+    float v = 0.f;
+    if (idx < AUX_V) {
+        const int i = idx >> 5, o = idx & 31;
+        v = flat[bias_off(KIND, i) + o];
+    } else if (idx < AUX_WO) {
+        if (is_xyz(KIND)) { const int i = (idx - AUX_V) >> 5, o = idx & 31; v = flat[fcb_off(KIND, i) + o]; }
+    } else if (idx < AUX_BO) {
+        const int n = (idx - AUX_WO) >> 5, k = idx & 31;
+        if (n < nout_of(KIND)) v = flat[wo_off(KIND) + n * 32 + k];
+    } else if (idx < AUX_BM) {
+        const int n = idx - AUX_BO;
+        if (n < nout_of(KIND)) v = flat[bo_off(KIND) + n];
+    } else if (is_xyz(KIND)) {
+        const int rel = idx - AUX_BM, ch = (rel >> 4) * 4 + (rel & 3), d = (rel >> 2) & 3;   // [4-channel group][xyz.][4]
+        if (ch < kE && d < 3) v = flat[B_off(KIND) + d * kE + ch];
+    }
+    return v;
+}
+
+template <int KIND>
 NSR_KERNEL void pack_kernel(const float *__restrict__ flat, float *__restrict__ packed) {
-    const int idx = bid_x() * nthreads() + tid();
-    if (idx >= packed_total(KIND)) return;
+    const int gidx = bid_x() * nthreads() + tid();
+    if (gidx >= packed_buf_total(KIND)) return;
+    if (gidx < AUX_FLOATS) { packed[gidx] = aux_value<KIND>(flat, gidx); return; }
+    const int idx = gidx - AUX_FLOATS;
     float v = 0.f;
 #pragma unroll
     for (int id = 0; id < nmat_of(KIND); ++id) {
@@ -106,32 +128,23 @@ NSR_KERNEL void pack_kernel(const float *__restrict__ flat, float *__restrict__ 
             if (k < m.kcols) v = flat[m.off + o * m.stride + m.kbeg + k];
         }
     }
-    packed[idx] = v;
+    packed[gidx] = v;
 }
 
-// stage the small per-decoder tables into LDS (all threads of the block)
-template <int KIND>
-NSR_DEV void load_aux(float *aux, const float *__restrict__ flat) {
-    for (int idx = tid(); idx < AUX_FLOATS; idx += nthreads()) {
-        float v = 0.f;
-        if (idx < AUX_V) {
-            const int i = idx >> 5, o = idx & 31;
-            v = flat[bias_off(KIND, i) + o];
-        } else if (idx < AUX_WO) {
-            if (is_xyz(KIND)) { const int i = (idx - AUX_V) >> 5, o = idx & 31; v = flat[fcb_off(KIND, i) + o]; }
-        } else if (idx < AUX_BO) {
-            const int n = (idx - AUX_WO) >> 5, k = idx & 31;
-            if (n < nout_of(KIND)) v = flat[wo_off(KIND) + n * 32 + k];
-        } else if (idx < AUX_BM) {
-            const int n = idx - AUX_BO;
-            if (n < nout_of(KIND)) v = flat[bo_off(KIND) + n];
-        } else if (is_xyz(KIND)) {
-            const int rel = idx - AUX_BM, ch = (rel >> 4) * 4 + (rel & 3), d = (rel >> 2) & 3;   // [4-channel group][xyz.][4]
-            if (ch < kE && d < 3) v = flat[B_off(KIND) + d * kE + ch];
-        }
-        aux[idx] = v;
+// cooperative global -> LDS copy of NF4 16-byte words; four loads in flight per thread before the first store
+template <int NF4>
+NSR_DEV void copy_f4(float *dst, const float *__restrict__ src) {
+    const int nt = nthreads();
+    int t = tid();
+    for (; t + 3 * nt < NF4; t += 4 * nt) {
+        const F4 a = ld4(src + 4 * t), b = ld4(src + 4 * (t + nt)), c = ld4(src + 4 * (t + 2 * nt)), d = ld4(src + 4 * (t + 3 * nt));
+        st4(dst + 4 * t, a); st4(dst + 4 * (t + nt), b); st4(dst + 4 * (t + 2 * nt), c); st4(dst + 4 * (t + 3 * nt), d);
     }
+    for (; t < NF4; t += nt) st4(dst + 4 * t, ld4(src + 4 * t));
 }
+// stage the small per-decoder tables into LDS (all threads of the block); `packed` = the decoder's packed buffer
+template <int KIND>
+NSR_DEV void load_aux(float *aux, const float *__restrict__ packed) { copy_f4<AUX_FLOATS / 4>(aux, packed); }
 
 // ------------------------------------------------------------------------------------------------
 // sample placement along the rays of one block  (Renderer.py:88-170)
@@ -215,8 +228,15 @@ struct Lvl {
     float mx, my, mz;   // d u / d g_normalised, 0 when the coordinate was clipped
 };
 
-NSR_DEV void axis_setup(double p, double lo, double inv, int n, int &i0, float &w0, float &w1, float &mult) {
-    const double gn = ((p - lo) * inv) * 2.0 - 1.0;      // fp64 normalisation, then one rounding
+// a / b for a divisor whose correctly rounded reciprocal `rb` is known: one residual correction gives the correctly
+// rounded quotient (Markstein), i.e. the value of the IEEE division the reference performs, for 3 instead of ~35 operations
+NSR_DEV double div_by(double a, double b, double rb) {
+    const double q = a * rb;
+    return fma(fma(-q, b, a), rb, q);
+}
+
+NSR_DEV void axis_setup(double p, double lo, double ext, double inv, int n, int &i0, float &w0, float &w1, float &mult) {
+    const double gn = div_by(p - lo, ext, inv) * 2.0 - 1.0;      // the reference's fp64 operations in its order, then one rounding
     const float gf = (float)gn;
     const float nm1 = (float)(n - 1);
     float u = ((gf + 1.f) / 2.f) * nm1;
@@ -234,9 +254,9 @@ NSR_DEV void axis_setup(double p, double lo, double inv, int n, int &i0, float &
 NSR_DEV Lvl make_level(const GridDev &G, double px, double py, double pz) {
     Lvl L;
     int x0, y0, z0;
-    axis_setup(px, G.lo[0], G.inv[0], G.X, x0, L.gx, L.fx, L.mx);
-    axis_setup(py, G.lo[1], G.inv[1], G.Y, y0, L.gy, L.fy, L.my);
-    axis_setup(pz, G.lo[2], G.inv[2], G.Z, z0, L.gz, L.fz, L.mz);
+    axis_setup(px, G.lo[0], G.ext[0], G.inv[0], G.X, x0, L.gx, L.fx, L.mx);
+    axis_setup(py, G.lo[1], G.ext[1], G.inv[1], G.Y, y0, L.gy, L.fy, L.my);
+    axis_setup(pz, G.lo[2], G.ext[2], G.inv[2], G.Z, z0, L.gz, L.fz, L.mz);
     L.vox = (z0 * G.Y + y0) * G.X + x0;
     L.sx = G.X > 1 ? 1 : 0;
     L.sy = G.Y > 1 ? G.X : 0;
@@ -262,6 +282,32 @@ NSR_DEV Act<2> gather_feat(const GridDev &G, const Lvl &L, int g) {
         const float w = corner_w(L, k);
         const float *src = G.feat + (long long)corner_vox(L, k) * kC + 4 * g;
         const F4 a = ld4(src), b = ld4(src + 16);
+        c.t[0][0] = fmaf(a.x, w, c.t[0][0]); c.t[0][1] = fmaf(a.y, w, c.t[0][1]);
+        c.t[0][2] = fmaf(a.z, w, c.t[0][2]); c.t[0][3] = fmaf(a.w, w, c.t[0][3]);
+        c.t[1][0] = fmaf(b.x, w, c.t[1][0]); c.t[1][1] = fmaf(b.y, w, c.t[1][1]);
+        c.t[1][2] = fmaf(b.z, w, c.t[1][2]); c.t[1][3] = fmaf(b.w, w, c.t[1][3]);
+    }
+    return c;
+}
+
+// the same in two halves, so that the 16 loads can be issued long before their values are needed
+struct GatherRaw { F4 a[8], b[8]; };
+NSR_DEV void gather_issue(GatherRaw &R, const GridDev &G, const Lvl &L, int g) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float *src = G.feat + (long long)corner_vox(L, k) * kC + 4 * g;
+        R.a[k] = ld4(src);
+        R.b[k] = ld4(src + 16);
+    }
+}
+NSR_DEV Act<2> gather_finish(const GatherRaw &R, const Lvl &L) {
+    Act<2> c;
+    c.t[0] = f4zero();
+    c.t[1] = f4zero();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float w = corner_w(L, k);
+        const F4 a = R.a[k], b = R.b[k];
         c.t[0][0] = fmaf(a.x, w, c.t[0][0]); c.t[0][1] = fmaf(a.y, w, c.t[0][1]);
         c.t[0][2] = fmaf(a.z, w, c.t[0][2]); c.t[0][3] = fmaf(a.w, w, c.t[0][3]);
         c.t[1][0] = fmaf(b.x, w, c.t[1][0]); c.t[1][1] = fmaf(b.y, w, c.t[1][1]);
@@ -403,9 +449,7 @@ NSR_DEV void gemv_bwd(f32x4 (&dx)[NTK], const Act<2> &dy, const float *w, int i,
 
 // cooperative copy of a decoder's packed operand stream into LDS (caller provides the barriers)
 template <int KIND>
-NSR_DEV void load_packed(float *wl, const float *__restrict__ packed) {
-    for (int t = tid(); t < packed_total(KIND) / 4; t += nthreads()) st4(wl + 4 * t, ld4(packed + 4 * t));
-}
+NSR_DEV void load_packed(float *wl, const float *__restrict__ packed) { copy_f4<packed_total(KIND) / 4>(wl, packed + AUX_FLOATS); }
 
 NSR_DEV float red_g(float v) { v += shfl_xor(v, 16); v += shfl_xor(v, 32); return v; }
 
@@ -455,16 +499,11 @@ NSR_DEV F4 load_b1(const float *aux, int ch) {        // (Bx, By, Bz) of one cha
 }
 
 // ------------------------------------------------------------------------------------------------
-// Parameter gradients, owner-computes.
-// Measured (tools/lds_atomic_probe.hip): ds_add_f32 costs ~195 cycles per wave instruction per CU, so the
-// per-tile dW blocks are NOT summed with LDS atomics.  Instead every layer is a lock-step phase of the block:
-//   1. each wave stages the operands of its tile (dH, dY, layer input, features, point positions) in LDS,
-//   2. block barrier,
-//   3. each 16x16 block pair of the layer's dW has ONE owner wave, which contracts over the 16 points of
-//      EVERY tile of the block in one MFMA chain (K = 16 x tiles) and adds the result into the block's image of
-//      the flat gradient blob (global memory, L2-resident; exclusive owner => plain loads / stores, no atomics),
-//   4. block barrier.
-// Per-wave staging region (floats): P[3][16] | DO[16][4] | A0 | A1 | X0 | C[cdim/32]; a tile is 16 rows x 32
+// Parameter gradients (see nsr_bwd.h): dW = dy^T x contracts over the points of a tile, so both operands are needed in
+// "lane = channel" form.  Each wave re-lays its tile out through a private LDS staging region.
+// Measured (tools/lds_atomic_probe.hip): ds_add_f32 costs ~195 cycles per wave instruction per CU, so gradients are
+// never summed with LDS atomics.
+// Per-wave staging region (floats): P[3][16] | DO[4][16] | A0 | A1 | X0 | C[cdim/32]; a tile is 16 rows x 32
 // channels in the "channel rows" layout below (conflict-free scalar stores, one conflict-free 16-byte operand read).
 // ------------------------------------------------------------------------------------------------
 constexpr int kStP = 0, kStDO = 64, kStA0 = 128, kStA1 = 128 + 512, kStX0 = 128 + 1024, kStC = 128 + 1536;
@@ -490,194 +529,6 @@ NSR_DEV f32x4 st_load_cm(const float *T, int Tt, int i, int g) {
 }
 // points 4*grp .. 4*grp+3 of one channel
 NSR_DEV F4 st_row4(const float *T, int ch, int grp) { return ld4(T + st_row(ch) * 16 + ((grp ^ (ch & 3)) << 2)); }
-
-struct Own {
-    Stream img;          // this block's image of the flat parameter-gradient blob (global partial buffer, L2 resident);
-                         // addressed through a buffer descriptor: 32-bit offsets, no 64-bit address registers
-    const float *stg;    // staging regions of all waves
-    int stride, nw, wave, lane;
-    bool first;          // first ray group of this block: store instead of accumulate (no zero-fill needed)
-    float *small;        // per-wave LDS accumulators of the output layer: [wave][wo[4][32] | bo[4]]
-};
-// Owner of the t-th task of a phase (tasks listed heaviest first).  With six waves on four SIMDs (waves w and w+4 share
-// one) the first four tasks go to one wave per SIMD, starting with the two waves that have their SIMD to themselves.
-NSR_DEV bool mine(const Own &O, int t) {
-    const int r = t % O.nw;
-    const int w = O.nw == 6 ? ((0x541032 >> (4 * r)) & 0xF) : r;
-    return w == O.wave;
-}
-NSR_DEV void img_add(const Own &O, int lane_off, int const_off, float v) {
-    if (!O.first) v += stream_ld(O.img, lane_off, const_off);
-    stream_st(O.img, lane_off, const_off, v);
-}
-
-// img[W slice, k-tile Tk] += sum over the block's tiles of A^T X,  X staged at x_off (sub-tile x_sub)
-NSR_DEV void own_pair(const Own &O, const Mat m, int Tk, int a_off, int x_off, int x_sub) {
-    const int i = O.lane & 15, g = O.lane >> 4;
-    f32x4 d0 = f4zero(), d1 = f4zero();
-    // the image values this task accumulates into (later ray groups of the block): requested now, consumed after the
-    // MFMA chain, so the L2 round trip hides behind it
-    const int k = 16 * Tk + i;
-    const bool live = k < m.kcols;
-    const int lo = 4 * g * m.stride + i;
-    const int co = m.off + m.kbeg + 16 * Tk;
-    if (!O.first && live) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            d0[r] = stream_ld(O.img, lo, co + r * m.stride);
-            d1[r] = stream_ld(O.img, lo, co + (16 + r) * m.stride);
-        }
-    }
-    // software pipeline over the block's tiles, two tiles per trip with ping-pong operand sets (no register rotation):
-    // the LDS reads (and, for the embedding, the sines) of the next tile are issued before the 8 MFMAs of this one
-    struct Ops { f32x4 a0, a1, x; };
-    auto fetch = [&](int t) {
-        const float *S = O.stg + (t < O.nw ? t : O.nw - 1) * O.stride;
-        Ops o;
-        o.a0 = st_load_cm(S + a_off, 0, i, g);
-        o.a1 = st_load_cm(S + a_off, 1, i, g);
-        o.x = st_load_cm(S + x_off, x_sub, i, g);
-        return o;
-    };
-    auto fmas = [&](const Ops &o) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            d0 = mfma16(o.a0[q], o.x[q], d0);
-            d1 = mfma16(o.a1[q], o.x[q], d1);
-        }
-    };
-    Ops A = fetch(0);
-    for (int t = 0; t < O.nw; t += 2) {
-        const Ops B = fetch(t + 1);
-        fmas(A);
-        A = fetch(t + 2);
-        if (t + 1 < O.nw) fmas(B);
-    }
-    if (live) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            stream_st(O.img, lo, co + r * m.stride, d0[r]);
-            stream_st(O.img, lo, co + (16 + r) * m.stride, d1[r]);
-        }
-    }
-}
-// The two weight blocks that read the Fourier embedding, W0 (layer 0) and W3e (embedding columns of layer 3), in one
-// task: the 16 embedding channels of k-tile Tk are recomputed ONCE per tile (decoder.py:26-30) and contracted with
-// dY0 (staged at a0_off) and dY3 (staged at a3_off):   img[W0 / W3e slice, k-tile Tk] += sum over tiles of dY^T E
-NSR_DEV void own_embed_pair(const Own &O, const Mat m0, const Mat m3, int Tk, int a0_off, int a3_off, const float *aux) {
-    const int i = O.lane & 15, g = O.lane >> 4;
-    f32x4 d00 = f4zero(), d01 = f4zero(), d30 = f4zero(), d31 = f4zero();
-    const int k = 16 * Tk + i;
-    const bool live = k < m0.kcols;
-    const int lo0 = 4 * g * m0.stride + i, lo3 = 4 * g * m3.stride + i;
-    const int co0 = m0.off + m0.kbeg + 16 * Tk, co3 = m3.off + m3.kbeg + 16 * Tk;
-    if (!O.first && live) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            d00[r] = stream_ld(O.img, lo0, co0 + r * m0.stride);
-            d01[r] = stream_ld(O.img, lo0, co0 + (16 + r) * m0.stride);
-            d30[r] = stream_ld(O.img, lo3, co3 + r * m3.stride);
-            d31[r] = stream_ld(O.img, lo3, co3 + (16 + r) * m3.stride);
-        }
-    }
-    const F4 b = load_b1(aux, 16 * Tk + i);
-    struct Ops { f32x4 p0, p1, q0, q1, x; };
-    auto fetch = [&](int t) {
-        const float *S = O.stg + (t < O.nw ? t : O.nw - 1) * O.stride;
-        Ops o;
-        o.p0 = st_load_cm(S + a0_off, 0, i, g); o.p1 = st_load_cm(S + a0_off, 1, i, g);
-        o.q0 = st_load_cm(S + a3_off, 0, i, g); o.q1 = st_load_cm(S + a3_off, 1, i, g);
-        const f32x4 px = to_v(ld4(S + kStP + 4 * g)), py = to_v(ld4(S + kStP + 16 + 4 * g)), pz = to_v(ld4(S + kStP + 32 + 4 * g));
-        o.x = sin_acc4(vfma(pz, splat(b.z), vfma(py, splat(b.y), px * splat(b.x))));       // points 4g .. 4g+3
-        return o;
-    };
-    auto fmas = [&](const Ops &o) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            d00 = mfma16(o.p0[q], o.x[q], d00);
-            d01 = mfma16(o.p1[q], o.x[q], d01);
-            d30 = mfma16(o.q0[q], o.x[q], d30);
-            d31 = mfma16(o.q1[q], o.x[q], d31);
-        }
-    };
-    Ops A = fetch(0);
-    for (int t = 0; t < O.nw; t += 2) {
-        const Ops B = fetch(t + 1);
-        fmas(A);
-        A = fetch(t + 2);
-        if (t + 1 < O.nw) fmas(B);
-    }
-    if (live) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            stream_st(O.img, lo0, co0 + r * m0.stride, d00[r]);
-            stream_st(O.img, lo0, co0 + (16 + r) * m0.stride, d01[r]);
-            stream_st(O.img, lo3, co3 + r * m3.stride, d30[r]);
-            stream_st(O.img, lo3, co3 + (16 + r) * m3.stride, d31[r]);
-        }
-    }
-}
-// img[off + ch] += sum over tiles and points of A[p][ch]    (bias gradients)
-NSR_DEV void own_colsum(const Own &O, int off, int a_off) {
-    const int ch = O.lane & 31, half = O.lane >> 5;
-    float s = 0.f;
-    for (int t = 0; t < O.nw; ++t) {
-        const float *T = O.stg + t * O.stride + a_off;
-        const F4 u = st_row4(T, ch, 2 * half), v = st_row4(T, ch, 2 * half + 1);      // points 8*half .. 8*half+7
-        s += u.x; s += u.y; s += u.z; s += u.w; s += v.x; s += v.y; s += v.z; s += v.w;
-    }
-    s += shfl_xor(s, 32);
-    if (half == 0) img_add(O, ch, off, s);
-}
-// output layer, wave-local (no block barrier, no atomics): slot[n*32 + ch] += sum_p d_out[p][n] * h4[p][ch],
-// slot[128 + n] += sum_p d_out[p][n] over the 16 points of THIS wave's tile (DO and X0 = h4 staged in its own region);
-// `slot` is this wave's private 132-float accumulator; the block sums the slots into the gradient image once per
-// ray group (bwd_pass).
-template <int NOUT>
-NSR_DEV void out_layer_local(const Own &O, const float *S) {
-    const int ch = O.lane & 31, half = O.lane >> 5;
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
-    const F4 h0 = st_row4(S + kStX0, ch, 2 * half), h1 = st_row4(S + kStX0, ch, 2 * half + 1);
-    const float hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int p = half * 8 + q;
-        const F4 d = ld4(S + kStDO + p * 4);
-        const float h = hv[q];
-        s[0] = fmaf(d.x, h, s[0]); sb[0] += d.x;
-        if (NOUT > 1) { s[1] = fmaf(d.y, h, s[1]); s[2] = fmaf(d.z, h, s[2]); s[3] = fmaf(d.w, h, s[3]); sb[1] += d.y; sb[2] += d.z; sb[3] += d.w; }
-    }
-#pragma unroll
-    for (int n = 0; n < NOUT; ++n) {
-        const float v = s[n] + shfl_xor(s[n], 32);
-        const float bsum = sb[n] + shfl_xor(sb[n], 32);
-        float *slot = O.small + O.wave * 132;
-        if (half == 0) slot[n * 32 + ch] += v;
-        if (O.lane == 0) slot[128 + n] += bsum;
-    }
-}
-// Fourier matrix: img[B + d*93 + ch] += sum darg[p][ch] * p[p][d]  for the 16 channels of k-tile Tk
-// (darg of the whole tile staged as [16][96] starting at kStA0)
-NSR_DEV void own_dB(const Own &O, int Tk, int boff) {
-    const int j = O.lane & 15, pg = O.lane >> 4, ch = 16 * Tk + j;
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (int t = 0; t < O.nw; ++t) {
-        const float *S = O.stg + t * O.stride;
-        const f32x4 px = to_v(ld4(S + kStP + 4 * pg)), py = to_v(ld4(S + kStP + 16 + 4 * pg)), pz = to_v(ld4(S + kStP + 32 + 4 * pg));
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float v = S[kStA0 + (4 * pg + q) * 96 + ch];
-            sx = fmaf(v, px[q], sx); sy = fmaf(v, py[q], sy); sz = fmaf(v, pz[q], sz);
-        }
-    }
-    sx = red_g(sx); sy = red_g(sy); sz = red_g(sz);
-    if (pg == 0 && ch < kE) {
-        img_add(O, j, boff + 16 * Tk, sx);
-        img_add(O, j, boff + kE + 16 * Tk, sy);
-        img_add(O, j, boff + 2 * kE + 16 * Tk, sz);
-    }
-}
-
 
 NSR_DEV unsigned relu_mask(f32x4 (&acc)[2]) {
     unsigned m = 0;
@@ -798,11 +649,11 @@ NSR_DEV void mlp_nox_fwd(const float *pk, const float *aux, const Act<2> &c, int
 template <int STAGE>
 NSR_DEV void load_stage_aux(const RenderParams &P, float *aux) {
     if (STAGE == NSR_STAGE_COARSE) {
-        load_aux<NSR_COARSE>(aux, P.dec[NSR_COARSE].params);
+        load_aux<NSR_COARSE>(aux, P.dec[NSR_COARSE].packed);
     } else {
-        load_aux<NSR_MIDDLE>(aux, P.dec[NSR_MIDDLE].params);
-        if (STAGE >= NSR_STAGE_FINE) load_aux<NSR_FINE>(aux + AUX_FLOATS, P.dec[NSR_FINE].params);
-        if (STAGE == NSR_STAGE_COLOR) load_aux<NSR_COLOR>(aux + 2 * AUX_FLOATS, P.dec[NSR_COLOR].params);
+        load_aux<NSR_MIDDLE>(aux, P.dec[NSR_MIDDLE].packed);
+        if (STAGE >= NSR_STAGE_FINE) load_aux<NSR_FINE>(aux + AUX_FLOATS, P.dec[NSR_FINE].packed);
+        if (STAGE == NSR_STAGE_COLOR) load_aux<NSR_COLOR>(aux + 2 * AUX_FLOATS, P.dec[NSR_COLOR].packed);
     }
 }
 
@@ -982,447 +833,7 @@ NSR_KERNEL NSR_BOUNDS(768) void eval_points_kernel(const RenderParams P) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// backward of one decoder for one tile
-// ------------------------------------------------------------------------------------------------
-struct BwdFlags { bool grid, params, rays; };
-
-// one layer of the xyz-decoder backward (i = 4..0), instantiated per layer so that every register
-// array index is a compile-time constant
-template <int KIND>
-struct XyzBwd {
-    static constexpr int CD = cdim_of(KIND), NTC = CD / 16;
-    const float *wl;     // packed operand stream of this decoder, staged in LDS
-    const float *aux;
-    Own O;
-    float *S;            // this wave's staging region
-    const Kept<KIND> &K;
-    BwdFlags F;
-    int lane;
-    Act<2> &dc;
-    Act<2> &dh;
-    Act<2> dY3, dY0;
-
-    template <int I>
-    NSR_DEV void layer() {
-        const int i16 = lane & 15, g = lane >> 4;
-        constexpr int uid = I == 0 ? XU0 : (I == 1 ? XU1 : (I == 2 ? XU2 : (I == 3 ? XU3 : XU4)));
-        constexpr int hid = I == 1 ? XW1 : (I == 2 ? XW2 : (I == 3 ? XW3H : XW4));
-        const Mat mu = xyz_mat(CD, uid);
-        if (F.params) st_store(S + kStA0, dh, i16, g);                      // dH_i: gradient of (U_i c + v_i) is dh itself
-        if (F.grid || F.rays) gemv_bwd<2>(dc.t, dh, wl + mu.pk, i16, g);      // first 32 feature columns only
-        const Act<2> dY = apply_mask(dh, K.mask[I]);
-        if (I == 3) dY3 = dY;
-        if (I == 0) dY0 = dY;
-        if (F.params) {
-            st_store(S + kStA1, dY, i16, g);
-            if (I > 0) st_store(S + kStX0, K.h[I > 0 ? I - 1 : 0], i16, g);
-            else st_store(S + kStX0, dY3, i16, g);                           // layer 0: the W0 / W3e task needs dY3 too
-            block_sync();
-            int t = 0;                                   // tasks of this phase, heaviest first (see mine())
-            if (I == 0) {
-#pragma unroll
-                for (int Tk = 0; Tk < kET; ++Tk, ++t)
-                    if (mine(O, t)) own_embed_pair(O, xyz_mat(CD, XW0), xyz_mat(CD, XW3E), Tk, kStA1, kStX0, aux);
-            }
-            if (I > 0) {
-#pragma unroll
-                for (int Tk = 0; Tk < 2; ++Tk, ++t)
-                    if (mine(O, t)) own_pair(O, xyz_mat(CD, hid), Tk, kStA1, kStX0, Tk);
-            }
-#pragma unroll
-            for (int Tk = 0; Tk < NTC; ++Tk, ++t)
-                if (mine(O, t)) own_pair(O, mu, Tk, kStA0, kStC + (Tk >> 1) * 512, Tk & 1);
-            if (mine(O, t)) own_colsum(O, fcb_off(KIND, I), kStA0);
-            if (mine(O, t + 1)) own_colsum(O, bias_off(KIND, I), kStA1);
-            block_sync();
-        }
-        if (I > 0) {
-            Act<2> nd;
-            act_zero(nd);
-            gemv_bwd<2>(nd.t, dY, wl + xyz_mat(CD, hid).pk, i16, g);
-            dh = nd;
-        }
-    }
-};
-
-// xyz decoder.  c: features (CL).  d_out: gradient of the decoder outputs of this lane's point.
-// dc: gradient w.r.t. the first 32 feature channels (the decoder's own grid).  dp: gradient w.r.t.
-// the fp32 world position through the embedding (already reduced over g).
-// With F.params every wave of the block must call this function (it contains block barriers).
-// Where this lane's d raw comes from: the compositor backward (a few waves of the block) fills `draw` in LDS while the
-// other waves already re-run the decoder forward; `sync` = this is the first use of `draw` in the ray group, so a block
-// barrier has to separate the two.
-struct DrawRef {
-    const F4 *draw;
-    int pidx;
-    bool active, inside, sync;
-};
-NSR_DEV F4 draw_fetch(const DrawRef &R) {
-    if (R.sync) block_sync();
-    F4 dr = R.active ? R.draw[R.pidx] : F4{0.f, 0.f, 0.f, 0.f};
-    if (!R.inside) dr.w = 0.f;                                 // Renderer.py:57 cuts the occupancy gradient
-    return dr;
-}
-
-template <int KIND>
-NSR_DEV void mlp_xyz_bwd(const float *pk, const float *aux, const Own &O, float *S,
-                         float px, float py, float pz, const Act<cdim_of(KIND) / 16> &c,
-                         const DrawRef &R, BwdFlags F, int lane, Act<2> &dc, float (&dp)[3]) {
-    constexpr int CD = cdim_of(KIND), NOUT = nout_of(KIND), NTC = CD / 16;
-    const int i16 = lane & 15, g = lane >> 4;
-    Kept<KIND> K;
-    float out[NOUT];
-    mlp_xyz_fwd<KIND, true>(pk, aux, px, py, pz, c, lane, out, &K);
-    (void)out;
-    const F4 dr = draw_fetch(R);
-    float d_out[NOUT];
-    if (NOUT == 1) { d_out[0] = dr.w; }
-    else { d_out[0] = dr.x; d_out[NOUT > 1 ? 1 : 0] = dr.y; d_out[NOUT > 2 ? 2 : 0] = dr.z; d_out[NOUT > 3 ? 3 : 0] = 0.f; }   // decoder.py:341 overwrites the 4th colour output
-
-    // output layer
-    Act<2> dh;
-#pragma unroll
-    for (int T = 0; T < 2; ++T) {
-        f32x4 v = f4zero();
-#pragma unroll
-        for (int n = 0; n < NOUT; ++n) {
-            const F4 w = ld4(aux + AUX_WO + n * 32 + 16 * T + 4 * g);
-            v[0] = fmaf(w.x, d_out[n], v[0]); v[1] = fmaf(w.y, d_out[n], v[1]);
-            v[2] = fmaf(w.z, d_out[n], v[2]); v[3] = fmaf(w.w, d_out[n], v[3]);
-        }
-        dh.t[T] = v;
-    }
-    if (F.params) {
-        if (g == 0) {
-            S[kStP + i16] = px; S[kStP + 16 + i16] = py; S[kStP + 32 + i16] = pz;       // [xyz][16 points]
-            st4(S + kStDO + i16 * 4, F4{d_out[0], NOUT > 1 ? d_out[NOUT > 1 ? 1 : 0] : 0.f, NOUT > 2 ? d_out[NOUT > 2 ? 2 : 0] : 0.f,
-                                        NOUT > 3 ? d_out[NOUT > 3 ? 3 : 0] : 0.f});
-        }
-#pragma unroll
-        for (int q = 0; q < NTC / 2; ++q) {
-            Act<2> cq;
-            cq.t[0] = c.t[2 * q]; cq.t[1] = c.t[2 * q + 1];
-            st_store(S + kStC + q * 512, cq, i16, g);
-        }
-        st_store(S + kStX0, K.h[4], i16, g);
-        wave_fence();
-        out_layer_local<NOUT>(O, S);
-        wave_fence();
-    }
-
-    act_zero(dc);
-    XyzBwd<KIND> X{pk, aux, O, S, K, F, lane, dc, dh};
-    act_zero(X.dY3);
-    act_zero(X.dY0);
-    X.template layer<4>();
-    X.template layer<3>();
-    X.template layer<2>();
-    X.template layer<1>();
-    X.template layer<0>();
-    const Act<2> dY3 = X.dY3, dY0 = X.dY0;
-
-    // ---- embedding: dE = W0^T dY0 + W3e^T dY3 ; d arg = dE * cos(arg)
-    dp[0] = dp[1] = dp[2] = 0.f;
-    const bool need_dB = F.params;
-    if (F.rays || need_dB) {
-        const Mat m0 = xyz_mat(CD, XW0), m3 = xyz_mat(CD, XW3E);
-        const int lo = (4 * g + 16 * (i16 >> 2)) * 4 + (i16 & 3);       // packed-stream position of W[.][16Tk+i16], see gemv_bwd
-        float ax = 0.f, ay = 0.f, az = 0.f;
-#pragma unroll
-        for (int Tk = 0; Tk < kET; ++Tk) {
-            f32x4 dE = f4zero(), dE2 = f4zero();
-#pragma unroll
-            for (int To = 0; To < 2; ++To)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float a0 = pk[m0.pk + Tk * 512 + To * 256 + r * 4 + lo];
-                    const float a3 = pk[m3.pk + Tk * 512 + To * 256 + r * 4 + lo];
-                    dE = mfma16(a0, dY0.t[To][r], dE);
-                    dE2 = mfma16(a3, dY3.t[To][r], dE2);
-                }
-            sched_fence();
-            dE += dE2;
-            const B4 b = load_b4(aux, 4 * Tk + g);
-            const f32x4 darg = dE * cos_acc4(vfma(splat(pz), b.z, vfma(splat(py), b.y, splat(px) * b.x)));
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                ax = fmaf(darg[r], b.x[r], ax); ay = fmaf(darg[r], b.y[r], ay); az = fmaf(darg[r], b.z[r], az);
-            }
-            if (need_dB) st4(S + kStA0 + i16 * 96 + 16 * Tk + 4 * g, to_F4(darg));     // [16][96] over A0|A1|X0
-        }
-        dp[0] = red_g(ax); dp[1] = red_g(ay); dp[2] = red_g(az);
-    }
-    if (need_dB) {
-        block_sync();
-#pragma unroll
-        for (int Tk = 0; Tk < kET; ++Tk)
-            if (mine(O, Tk)) own_dB(O, Tk, B_off(KIND));
-        block_sync();
-    }
-}
-
-struct NoxBwd {
-    const float *wl;     // packed operand stream of the coarse decoder, staged in LDS
-    Own O;
-    float *S;
-    const Act<2> &c;
-    const Kept<0> &K;
-    BwdFlags F;
-    int lane;
-    Act<2> &dc;
-    Act<2> &dh;
-
-    template <int I>
-    NSR_DEV void layer() {
-        const int i16 = lane & 15, g = lane >> 4;
-        const Act<2> dY = apply_mask(dh, K.mask[I]);
-        const Mat mh = nox_mat(I == 0 ? NW0 : (I == 1 ? NW1 : (I == 2 ? NW2 : (I == 3 ? NW3H : NW4))));
-        if (F.params) {
-            st_store(S + kStA1, dY, i16, g);
-            st_store(S + kStX0, I == 0 ? c : K.h[I > 0 ? I - 1 : 0], i16, g);
-            block_sync();
-            int t = 0;
-            if (I == 3) {
-#pragma unroll
-                for (int Tk = 0; Tk < 2; ++Tk, ++t)
-                    if (mine(O, t)) own_pair(O, nox_mat(NW3C), Tk, kStA1, kStC, Tk);
-            }
-#pragma unroll
-            for (int Tk = 0; Tk < 2; ++Tk, ++t)
-                if (mine(O, t)) own_pair(O, mh, Tk, kStA1, kStX0, Tk);
-            if (mine(O, t)) own_colsum(O, nox_b(I), kStA1);
-            block_sync();
-        }
-        if (I == 3) gemv_bwd<2>(dc.t, dY, wl + nox_mat(NW3C).pk, i16, g);
-        if (I == 0) {
-            gemv_bwd<2>(dc.t, dY, wl + mh.pk, i16, g);
-        } else {
-            Act<2> nd;
-            act_zero(nd);
-            gemv_bwd<2>(nd.t, dY, wl + mh.pk, i16, g);
-            dh = nd;
-        }
-    }
-};
-
-// coarse decoder backward (MLP_no_xyz)
-NSR_DEV void mlp_nox_bwd(const float *pk, const float *aux, const Own &O, float *S,
-                         const Act<2> &c, const DrawRef &R, BwdFlags F, int lane, Act<2> &dc) {
-    const int i16 = lane & 15, g = lane >> 4;
-    Kept<0> K;
-    float out[1];
-    mlp_nox_fwd<true>(pk, aux, c, lane, out, &K);
-    (void)out;
-    const float d_out = draw_fetch(R).w;
-    Act<2> dh;
-#pragma unroll
-    for (int T = 0; T < 2; ++T) {
-        const F4 w = ld4(aux + AUX_WO + 16 * T + 4 * g);
-        f32x4 v = {w.x * d_out, w.y * d_out, w.z * d_out, w.w * d_out};
-        dh.t[T] = v;
-    }
-    if (F.params) {
-        if (g == 0) st4(S + kStDO + i16 * 4, F4{d_out, 0.f, 0.f, 0.f});
-        st_store(S + kStC, c, i16, g);
-        st_store(S + kStX0, K.h[4], i16, g);
-        wave_fence();
-        out_layer_local<1>(O, S);
-        wave_fence();
-    }
-    act_zero(dc);
-    NoxBwd X{pk, O, S, c, K, F, lane, dc, dh};
-    X.layer<4>();
-    X.layer<3>();
-    X.layer<2>();
-    X.layer<1>();
-    X.layer<0>();
-}
-
-// ------------------------------------------------------------------------------------------------
-// backward kernel.  grid = (blocks, passes); pass p handles one decoder:
-//   coarse stage: p0 = coarse.   otherwise: p0 = middle, p1 = fine, p2 = color.
-// LDS: aux[AUX] | packed weights of the decoder | ztmp f64[npts] | zbuf f64[npts] | draw F4[npts] | dpb f64[npts*3]
-//      | per-wave staging regions (stg_floats(KIND) each)
-// The per-block image of the parameter gradients lives in the global partial buffer (stays in L2; exclusive owner
-// per element, first ray group stores, later groups accumulate), summed over blocks by reduce_partials_kernel.
-// ------------------------------------------------------------------------------------------------
-// PARAMS is the compile-time twin of "this decoder's dparams != NULL": the pass without parameter gradients (tracking,
-// decoders the optimiser does not step) needs neither the kept activations nor the staging code and compiles without
-// register spills
-template <int KIND, bool PARAMS>
-NSR_DEV void bwd_pass(const RenderParams &P) {
-    constexpr int NPAR = param_total(KIND);
-    char *lds = lds_base();
-    const int npts = P.rays_per_block * P.S, S = P.S;
-    const int lane = tid() & 63, wave = tid() >> 6, nwaves = nthreads() >> 6;
-    float *aux = reinterpret_cast<float *>(lds);
-    float *wl = aux + AUX_FLOATS;                          // this decoder's packed operand stream
-    constexpr int head = (AUX_FLOATS + packed_total(KIND) + 3) & ~3;
-    double *ztmp = reinterpret_cast<double *>(aux + head);
-    double *zbuf = ztmp + npts;
-    F4 *draw = reinterpret_cast<F4 *>(zbuf + npts);
-    double *dpb = reinterpret_cast<double *>(draw + npts);
-    float *small = reinterpret_cast<float *>(dpb + 3 * npts);              // [waves][132] floats (wo[4][32] | bo[4])
-    const int stg_off = (head * 4 + npts * (8 + 8 + 16 + 24) + nwaves * 132 * 4 + 15) & ~15;
-    float *stg = reinterpret_cast<float *>(lds + stg_off);
-    float *Sw = stg + wave * stg_floats(KIND);             // this wave's staging region (also Tx / tab of the scatter)
-
-    const GridDev &G = P.grid[KIND];
-    const DecDev &D = P.dec[KIND];
-    BwdFlags F;
-    F.grid = G.dfeat != nullptr;
-    F.params = PARAMS;
-    F.rays = P.d_rays_o != nullptr;
-    if (!F.grid && !F.params && !F.rays) return;
-
-    load_aux<KIND>(aux, D.params);
-    load_packed<KIND>(wl, D.packed);                       // visible after the first barrier inside compute_z
-    for (int t = tid(); t < 132 * nwaves; t += nthreads()) small[t] = 0.f;
-    float *img = F.params ? P.partials + ((long long)bid_y() * nblk_x() + bid_x()) * P.partial_stride : nullptr;
-    (void)NPAR;
-
-    for (long long grp = bid_x(); grp < P.n_groups; grp += nblk_x()) {
-        loop_fence();
-        const bool first_grp = grp == (long long)bid_x();
-        Own O{make_stream(img), stg, stg_floats(KIND), nwaves, wave, lane, first_grp, small};
-        const long long ray0 = grp * P.rays_per_block;
-        if (P.zvals) {            // sample depths saved by the forward pass: one coalesced load instead of re-deriving them
-            for (int t = tid(); t < npts; t += nthreads())
-                zbuf[t] = (ray0 + t / S < P.n_rays) ? P.zvals[ray0 * S + t] : 0.0;
-            block_sync();
-        } else {
-            compute_z(P, ray0, ztmp, zbuf);
-        }
-        // ---- tile set-up first: the feature gathers (L2 / Infinity-Cache latency) fly while the compositor runs.
-        // A ray group holds tiles_per_block tiles; the block's waves take them nwaves at a time (sub-rounds).
-        const int g = lane >> 4;
-        int pidx;
-        bool active, inside;
-        double px, py, pz;
-        Lvl L;
-        Act<2> c, cm;
-        auto tile_setup = [&](int sub) {
-            pidx = (sub * nwaves + wave) * kTile + (lane & 15);
-            const long long ray_t = ray0 + pidx / S;
-            active = (pidx < npts) && (ray_t < P.n_rays);
-            const long long rr = active ? ray_t : 0;
-            const double zt = active ? zbuf[pidx] : 0.0;
-            px = (double)P.rays_o[rr * 3 + 0] + (double)P.rays_d[rr * 3 + 0] * zt;
-            py = (double)P.rays_o[rr * 3 + 1] + (double)P.rays_d[rr * 3 + 1] * zt;
-            pz = (double)P.rays_o[rr * 3 + 2] + (double)P.rays_d[rr * 3 + 2] * zt;
-            inside = (px > P.blo[0]) && (px < P.bhi[0]) && (py > P.blo[1]) && (py < P.bhi[1]) &&
-                     (pz > P.blo[2]) && (pz < P.bhi[2]);
-            L = make_level(G, px, py, pz);
-            c = gather_feat(G, L, g);
-            if (KIND == NSR_FINE) {
-                const Lvl Lm = make_level(P.grid[NSR_MIDDLE], px, py, pz);
-                cm = gather_feat(P.grid[NSR_MIDDLE], Lm, g);
-            }
-        };
-        tile_setup(0);
-        // ---- compositor backward: d raw per sample (common.py:231-244 differentiated)
-        // (rays go to waves 2, 3, ... first: with six waves on four SIMDs those two do not share their SIMD, and the
-        // other waves meanwhile start on the decoder forward re-run -- the barrier sits inside mlp_*_bwd, see DrawRef)
-        for (int r = nwaves >= 4 ? (wave + nwaves - 2) % nwaves : wave; r < P.rays_per_block; r += nwaves) {
-            const long long ray = ray0 + r;
-            if (ray >= P.n_rays) break;
-            const bool act = lane < S;
-            const F4 rw = act ? ld4(P.raw + (ray * S + lane) * 4) : F4{0.f, 0.f, 0.f, 0.f};
-            const double z = act ? zbuf[r * S + lane] : 0.0;
-            const Comp c = comp_weights(rw.w, act, lane);
-            const double gD = P.d_depth ? P.d_depth[ray] : 0.0;
-            const double gV = P.d_var ? P.d_var[ray] : 0.0;
-            float gr = 0.f, gg = 0.f, gb = 0.f;
-            if (P.d_rgb) { gr = P.d_rgb[ray * 3 + 0]; gg = P.d_rgb[ray * 3 + 1]; gb = P.d_rgb[ray * 3 + 2]; }
-            const double dz = z - P.g_depth[ray];
-            const double s1 = wave_sum_d((double)c.w * dz);
-            const float Gz = (float)(gD * z + gV * (dz * dz - 2.0 * s1 * z));
-            const float Gw = Gz + fmaf(gb, rw.z, fmaf(gg, rw.y, gr * rw.x));
-            float v = act ? Gw * c.w : 0.f;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const float o = shfl_down(v, d);
-                if (lane + d < 64) v += o;
-            }
-            float suffix = shfl_down(v, 1);
-            if (lane == 63) suffix = 0.f;
-            const float dalpha = Gw * c.T - suffix / c.t;
-            const float docc = 10.f * (dalpha * ((1.f - c.alpha) * c.alpha));
-            if (act) draw[r * S + lane] = F4{c.w * gr, c.w * gg, c.w * gb, docc};
-        }
-        for (int sub = 0;;) {   // ---- decoder backward for the tile of this wave
-            O.first = first_grp && sub == 0;                       // layer images: stored by the block's first sub-round
-            const DrawRef R{draw, pidx, active, inside, sub == 0};
-            Act<2> dc;
-            float dpe[3] = {0.f, 0.f, 0.f};
-            if (KIND == NSR_COARSE) {
-                mlp_nox_bwd(wl, aux, O, Sw, c, R, F, lane, dc);
-            } else if (KIND == NSR_MIDDLE) {
-                mlp_xyz_bwd<NSR_MIDDLE>(wl, aux, O, Sw, (float)px, (float)py, (float)pz, c, R, F, lane, dc, dpe);
-            } else if (KIND == NSR_FINE) {
-                Act<4> cc;
-                cc.t[0] = c.t[0]; cc.t[1] = c.t[1]; cc.t[2] = cm.t[0]; cc.t[3] = cm.t[1];
-                mlp_xyz_bwd<NSR_FINE>(wl, aux, O, Sw, (float)px, (float)py, (float)pz, cc, R, F, lane, dc, dpe);
-            } else {
-                mlp_xyz_bwd<NSR_COLOR>(wl, aux, O, Sw, (float)px, (float)py, (float)pz, c, R, F, lane, dc, dpe);
-            }
-            float dux = 0.f, duy = 0.f, duz = 0.f;
-            if (F.rays) coord_grad(G, L, g, dc, dux, duy, duz);
-            if (F.grid) scatter_merged(G, L, lane, dc, active, Sw + kStA0, Sw + kStA0 + kTile * kTxS);
-            if (F.rays && active && g == 0) {
-                // d p = d u * (n-1)/2 * 2/(hi-lo)  (+ embedding part), fp64 like autograd through Renderer.py:172
-                dpb[pidx * 3 + 0] = (double)dux * (2.0 * G.inv[0]) + (double)dpe[0];
-                dpb[pidx * 3 + 1] = (double)duy * (2.0 * G.inv[1]) + (double)dpe[1];
-                dpb[pidx * 3 + 2] = (double)duz * (2.0 * G.inv[2]) + (double)dpe[2];
-            }
-            if (++sub * nwaves >= P.tiles_per_block) break;
-            wave_fence();                                      // the scatter is done with this wave's staging region
-            tile_setup(sub);
-        }
-        block_sync();
-        if (F.rays) {
-            for (int t = tid(); t < P.rays_per_block * 6; t += nthreads()) {
-                const int r = t / 6, q = t - r * 6, a = q % 3;
-                const long long ray = ray0 + r;
-                if (ray >= P.n_rays) continue;
-                double s = 0.0;
-                for (int k = 0; k < S; ++k) {
-                    const double d = dpb[(r * S + k) * 3 + a];
-                    s += (q < 3) ? d : d * zbuf[r * S + k];
-                }
-                atomic_add_global((q < 3 ? P.d_rays_o : P.d_rays_d) + ray * 3 + a, (float)s);
-            }
-        }
-        block_sync();
-    }
-    if (F.params) {              // output-layer gradients: the per-wave slots were accumulated over all ray groups of the block
-        constexpr int NO = nout_of(KIND);
-        const Stream st = make_stream(img);
-        const int t = tid();
-        if (t < NO * 32 || (t >= 128 && t < 128 + NO)) {
-            float v = 0.f;
-            for (int w = 0; w < nwaves; ++w) v += small[w * 132 + t];
-            if (t < 128) stream_st(st, t, wo_off(KIND), v); else stream_st(st, t - 128, bo_off(KIND), v);
-        }
-    }
-}
-
-template <int STAGE>
-NSR_KERNEL NSR_BOUNDS(64 * NSR_BWD_WAVES) void render_bwd_kernel(const RenderParams P) {
-    if (STAGE == NSR_STAGE_COARSE) {
-        if (P.dec[NSR_COARSE].dparams) bwd_pass<NSR_COARSE, true>(P); else bwd_pass<NSR_COARSE, false>(P);
-    } else {
-        const int pass = bid_y();
-        if (pass == 0) {
-            if (P.dec[NSR_MIDDLE].dparams) bwd_pass<NSR_MIDDLE, true>(P); else bwd_pass<NSR_MIDDLE, false>(P);
-        } else if (pass == 1) {
-            if (STAGE >= NSR_STAGE_FINE) { if (P.dec[NSR_FINE].dparams) bwd_pass<NSR_FINE, true>(P); else bwd_pass<NSR_FINE, false>(P); }
-        } else {
-            if (STAGE == NSR_STAGE_COLOR) { if (P.dec[NSR_COLOR].dparams) bwd_pass<NSR_COLOR, true>(P); else bwd_pass<NSR_COLOR, false>(P); }
-        }
-    }
-}
+struct BwdFlags { bool grid, params, rays; };      // what the backward of one decoder pass has to produce (nsr_bwd.h)
 
 // sum the per-block partial parameter gradients:  dparams[t] += sum_b partials[b][t], one grid row (blockIdx.y) per
 // decoder pass of the stage.  block = 64 parameters x (blockDim/64) slices of the partial list (coalesced 256-byte
@@ -1654,3 +1065,5 @@ NSR_KERNEL void frustum_mask_kernel(const FrustumParams P) {
 }
 
 }  // namespace nsr
+
+#include "nsr_bwd.h"

@@ -122,5 +122,8 @@ constexpr int AUX_WO = 320;    // wo[4][32]  output weights (rows >= nout are ze
 constexpr int AUX_BO = 448;    // bo[4]
 constexpr int AUX_BM = 452;    // Bm[24][4][4]  Fourier matrix: per group of 4 channels Bx[4] | By[4] | Bz[4] | 0
 constexpr int AUX_FLOATS = 452 + 96 * 4;   // 836
+// device buffer written by nsr_pack_params for one decoder: [aux table | packed operand stream]
+constexpr int packed_buf_total(int kind) { return AUX_FLOATS + packed_total(kind); }
+static_assert(AUX_FLOATS % 4 == 0, "the operand stream behind the aux table must stay 16-byte aligned");
 
 }  // namespace nsr

@@ -37,6 +37,7 @@ class _FlatDecoder(nn.Module):
         self._grad_flat: Optional[torch.Tensor] = None
         self._grad_views = None
         self._packed = None                                 # (key, tensor) cache of the MFMA operand stream
+        self._cross_process = False                         # parameters may be written by another process (see packed_params)
         self._build_modules()
         self.reset_parameters()
 
@@ -118,12 +119,25 @@ class _FlatDecoder(nn.Module):
     def packed_params(self, lib, stream) -> torch.Tensor:
         f = self.flat_params()
         key = self._pack_key()
-        if self._packed is None or self._packed[0] != key:
+        # a decoder shared with other processes (share_memory(), or unpickled into a spawned process: the reference's
+        # tracker / mapper / coarse-mapper processes, src/NICE_SLAM.py:82-90,288-305) can be updated in place by a process
+        # whose writes never touch THIS process's version counters: re-pack on every call (one small kernel)
+        if self._packed is None or self._packed[0] != key or self._cross_process:
             slot = _capi.SLOT_NAMES.index(self.slot)
             pk = torch.empty(lib.nsr_packed_count(slot), dtype=torch.float32, device=f.device)
             lib.check(lib.nsr_pack_params(slot, f.data_ptr(), pk.data_ptr(), stream), "nsr_pack_params")
             self._packed = (key, pk)
         return self._packed[1]
+
+    def share_memory(self):
+        self._cross_process = True
+        return super().share_memory()
+
+    def __getstate__(self):                                 # pickled into a spawned process: caches stay behind
+        d = dict(self.__dict__)
+        d["_packed"], d["_grad_flat"], d["_grad_views"] = None, None, None
+        d["_cross_process"] = True
+        return d
 
     def wants_grad(self) -> bool:
         return any(p.requires_grad for p in self._views)
@@ -182,7 +196,7 @@ class _FlatDecoder(nn.Module):
         new.name, new.bound = self.name, (None if self.bound is None else self.bound.clone())
         new._spec = self._spec
         new._flat = self.flat_params().detach().clone()
-        new._grad_flat, new._grad_views, new._packed = None, None, None
+        new._grad_flat, new._grad_views, new._packed, new._cross_process = None, None, None, False
         new._build_modules()
         for a, b in zip(new._views, self._views):
             a.requires_grad_(b.requires_grad)
@@ -244,6 +258,12 @@ class NICE(nn.Module):
 
     def sub(self, slot: str) -> _FlatDecoder:
         return getattr(self, slot + "_decoder")
+
+    def share_memory(self):                                  # src/NICE_SLAM.py:88-90
+        for m in self.children():
+            if isinstance(m, _FlatDecoder):
+                m._cross_process = True
+        return super().share_memory()
 
     def forward(self, p, c_grid, stage="middle", **kwargs):
         from .renderer import eval_points_raw          # local import: renderer imports this module

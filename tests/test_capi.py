@@ -38,7 +38,7 @@ def test_sizes_and_error_reporting(lib):
     assert lib.nsr_version() == 1
     assert [lib.nsr_param_count(i) for i in range(4)] == [param_count(s) for s in ("coarse", "middle", "fine", "color")] \
         == [6337, 15800, 20920, 15899]
-    assert [lib.nsr_packed_count(i) for i in range(4)] == [6144, 15360, 20480, 15360]
+    assert [lib.nsr_packed_count(i) for i in range(4)] == [836 + 6144, 836 + 15360, 836 + 20480, 836 + 15360]    # [aux table | operand stream]
     assert lib.nsr_param_count(7) == -1
     # color stage, 1000 rays, S=48: 3 passes x min(groups, cap) blocks x the largest decoder blob
     assert lib.nsr_bwd_workspace_floats(3, 1000, 48, 7) == 3 * 7 * 20920

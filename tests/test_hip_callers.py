@@ -106,7 +106,7 @@ def test_mapping_style_iterations():
         if stage == "color":
             loss = loss + 0.2 * torch.abs(gc - col).sum()
         loss.backward()
-        assert abs(float(loss) - ref_loss) < 1e-5 * abs(ref_loss), (it, float(loss), ref_loss)
+        assert abs(float(loss.detach()) - ref_loss) < 1e-5 * abs(ref_loss), (it, float(loss.detach()), ref_loss)
         for k, gr in ref_grads.items():
             got = torch.cat([col_params[n[len("color_decoder."):]].grad.reshape(-1) for n in col_names]) if k == "color_blob" else lv[k].grad
             assert rel_err(got, gr) < 1e-4, (it, stage, k, rel_err(got, gr))
@@ -218,7 +218,9 @@ def test_masked_grid_adam_replaces_masked_leaf_flow():
     for k in keys:
         a, b = cA[k].detach().cpu(), cB[k].detach().cpu()
         assert torch.equal(b[~full[k].cpu()], sc["grids"][k][~full[k].cpu()]), k          # unmasked voxels untouched
-        assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()), (k, float((a - b).abs().max()), float(a.abs().max()))
+        # max-norm; torch's (foreach) Adam on the GPU and the fused kernel round a few operations differently: after four
+        # steps of up to lr = 0.1 the largest observed difference is 5 ulp of the largest parameter
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), (k, float((a - b).abs().max()), float(a.abs().max()))
         assert float((b - sc["grids"][k]).abs().max()) > 1e-4, k
 
 
