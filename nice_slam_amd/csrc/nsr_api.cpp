@@ -134,11 +134,6 @@ int bwd_lds_bytes(int stage, int npts, int rays, int waves) {
     return need;
 }
 
-// per-wave accumulator slabs of the fine pass (nsr_bwd.h), behind the per-block gradient images
-long long slab_floats(int stage, long long blocks) {
-    return stage >= NSR_STAGE_FINE ? blocks * kBwdWaves * nsr::kSlabFloats : 0;
-}
-
 }  // namespace
 
 extern "C" {
@@ -155,7 +150,7 @@ int64_t nsr_bwd_workspace_floats(int stage, int64_t n_rays, int n_samples_total,
     const long long groups = (n_rays + rb - 1) / rb;
     long long blocks = bwd_blocks(groups, max_blocks);
     if (blocks < 1) blocks = 1;
-    return (int64_t)stage_passes(stage) * blocks * max_param_count(stage) + slab_floats(stage, blocks);
+    return (int64_t)stage_passes(stage) * blocks * max_param_count(stage);
 }
 
 int nsr_pack_params(int slot, const float *params, float *packed, void *stream) {
@@ -209,11 +204,9 @@ int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream
     for (int s = 0; s < 4; ++s) any_params |= P.dec[s].dparams != nullptr;
     P.partial_stride = max_param_count(P.stage);
     if (any_params) {
-        const long long images = (long long)passes * nblk * P.partial_stride;
-        const long long need = images + slab_floats(P.stage, nblk);
+        const long long need = (long long)passes * nblk * P.partial_stride;
         if (!b->workspace || b->workspace_floats < need) return fail("nsr_render_bwd: workspace too small");
         P.partials = b->workspace;
-        P.slabs = b->workspace + images;
     }
     const int npts = P.rays_per_block * P.S;
     const int waves = kBwdWaves;

@@ -45,12 +45,15 @@ NSR_DEV void dw_pair(f32x4 &d0, f32x4 &d1, f32x4 a0, f32x4 a1, f32x4 x) {
 //   * the gradients of the fc_c biases are not accumulated at all: v_i = sum_p dH_i[p] and dH_{i-1}[p] = W_i^T dY_i[p], so
 //     v_{i-1} = W_i^T b_i (and v_4 = Wo^T bo) -- five 32x32 matrix-vector products per block at flush time.
 // ------------------------------------------------------------------------------------------------
-//   * the c_dim-64 (fine) decoder has 80 weight tiles; its 40 fc_c tiles (dU) live in a per-wave slab in global memory
-//     (L2-resident, 40 KB): a layer loads its 8 tiles at entry, accumulates, and stores them back.
-constexpr int lds_acc_ktiles(int kind) { return kind == 0 ? 0 : (cdim_of(kind) == 32 ? kET : 2); }
-constexpr int kSlabFloats = 5 * 2 * 4 * 256;      // u[5][2][4] tiles of 64 lanes x 4 floats
+//   * the c_dim-64 (fine) decoder has 80 weight tiles.  Its 40 fc_c tiles (dU_i = dH_i^T [c_fine | c_mid]) are
+//     OWNER-COMPUTED inside the block: wave w owns feature k-tile w of every layer (2 tiles per layer, 10 in all) and
+//     contracts over the tiles of all four waves, whose dH / c staging tiles it reads straight from their LDS regions.
+//     That costs the fine pass one block barrier per layer (dH staged ping-pong, so one barrier suffices) and nothing
+//     else: no extra registers, no memory traffic, no reduction at flush (exclusive owner).
+constexpr int lds_acc_ktiles(int kind) { return kind == 0 ? 0 : (cdim_of(kind) == 32 ? kET : 0); }
+constexpr bool owner_du(int kind) { return kind != 0 && cdim_of(kind) == 64; }
 constexpr int st_lacc(int kind) { return stg_floats(kind); }          // LDS-resident accumulator tiles: behind the C region
-constexpr int bwd_stg_floats(int kind) { return stg_floats(kind) + lds_acc_ktiles(kind) * 512; }
+constexpr int bwd_stg_floats(int kind) { return stg_floats(kind) + lds_acc_ktiles(kind) * 512 + (owner_du(kind) ? 512 : 0); }   // + second dH tile
 template <int CD>
 struct XyzAcc {
     static constexpr int NTC = CD / 16;
@@ -125,7 +128,7 @@ NSR_DEV void visit_tiles(XyzAcc<cdim_of(KIND)> &A, F &&f) {
 #pragma unroll
         for (int o = 0; o < 2; ++o)
 #pragma unroll
-            for (int k = 0; k < NTC; ++k) { f(A.u[i][o][k], xyz_mat(CD, i == 0 ? XU0 : (i == 1 ? XU1 : (i == 2 ? XU2 : (i == 3 ? XU3 : XU4)))), o, k, t); ++t; }
+            for (int k = 0; k < NTC; ++k) { f(A.u[i][o][owner_du(KIND) ? 0 : k], xyz_mat(CD, i == 0 ? XU0 : (i == 1 ? XU1 : (i == 2 ? XU2 : (i == 3 ? XU3 : XU4)))), o, k, t); ++t; }
 }
 constexpr int xyz_ntiles(int cd) { return 4 * kET + 16 + 10 * (cd / 16); }
 template <int KIND, class G>
@@ -179,7 +182,7 @@ constexpr int nvecs_of(int kind) { return kind == 0 ? 13 : xyz_nvecs(kind); }
 // write the block's image of the flat gradient blob (plain stores; every parameter exactly once).
 // ------------------------------------------------------------------------------------------------
 template <int KIND, class ACC>
-NSR_DEV void flush_acc(ACC &A, float *wl, const float *aux, float *scratch, float *img, const float *slab, int wave, int lane, const Dbg dbg) {
+NSR_DEV void flush_acc(ACC &A, float *wl, const float *aux, float *scratch, float *img, int wave, int lane, const Dbg dbg) {
     const Stream st = make_stream(img);
     const int j = lane & 15, g = lane >> 4;
     // ---- vectors first (the packed weights in `wl` are still needed): reduce over the four point groups of the lane's
@@ -250,21 +253,21 @@ NSR_DEV void flush_acc(ACC &A, float *wl, const float *aux, float *scratch, floa
     dbg.stamp(59);
 #pragma unroll
     for (int R = 0; R < NR; ++R) {
+        constexpr int t_u = 4 * kET + 16;                                // first fc_c tile in visiting order
         visit_tiles<KIND>(A, [&](f32x4 &acc, const Mat, int, int, int t) {
-            constexpr int t_u = 4 * kET + 16;                            // first fc_c tile in visiting order
-            if (t / RT == R) {
-                const bool from_slab = KIND == NSR_FINE && t >= t_u;     // the fine decoder's dU tiles live in the wave's slab
-                const F4 v = from_slab ? ld4(slab + ((t - t_u) * 64 + lane) * 4) : to_F4(acc);
-                st4(red + (((t % RT) * kBwdWaves + wave) * 64 + lane) * 4, v);
-            }
+            if (t / RT == R && !(owner_du(KIND) && t >= t_u)) st4(red + (((t % RT) * kBwdWaves + wave) * 64 + lane) * 4, to_F4(acc));
         });
         block_sync();
-        visit_tiles<KIND>(A, [&](f32x4 &, const Mat m, int To, int Tk, int t) {
-            if (t / RT == R && (t % kBwdWaves) == wave) {
-                const float *src = red + ((t % RT) * kBwdWaves * 64 + lane) * 4;
-                f32x4 s = to_v(ld4(src));
+        visit_tiles<KIND>(A, [&](f32x4 &acc, const Mat m, int To, int Tk, int t) {
+            const bool owned = owner_du(KIND) && t >= t_u;               // fine dU: wave Tk holds the complete sum already
+            if (t / RT == R && (owned ? Tk == wave : (t % kBwdWaves) == wave)) {
+                f32x4 s = acc;
+                if (!owned) {
+                    const float *src = red + ((t % RT) * kBwdWaves * 64 + lane) * 4;
+                    s = to_v(ld4(src));
 #pragma unroll
-                for (int w = 1; w < kBwdWaves; ++w) s += to_v(ld4(src + w * 256));
+                    for (int w = 1; w < kBwdWaves; ++w) s += to_v(ld4(src + w * 256));
+                }
                 if (16 * Tk + j < m.kcols) {
                     const int lo = 4 * g * m.stride + j, co = m.off + m.kbeg + 16 * Tk + 16 * To * m.stride;
 #pragma unroll
@@ -291,26 +294,20 @@ struct XyzTile {
     int lane;
     Act<2> &dc;
     Act<2> &dh;
-    float *slab;         // global-resident dU tiles of this wave (fine decoder), else unused
+    const float *stg;    // staging regions of all waves (owner-computed dU of the fine decoder)
+    int wave;
     Act<2> dY3, dY0;
 
     template <int I>
     NSR_DEV void layer() {
         const int i16 = lane & 15, g = lane >> 4;
-        constexpr bool kSlab = PARAMS && CD == 64;
-        f32x4 ug[2][NTC];
-        auto slab_load = [&]() {
-#pragma unroll
-            for (int o = 0; o < 2; ++o)
-#pragma unroll
-                for (int Tc = 0; Tc < NTC; ++Tc) ug[o][Tc] = to_v(ld4(slab + (((I * 2 + o) * 4 + Tc) * 64 + lane) * 4));
-        };
+        constexpr bool kOwn = PARAMS && owner_du(KIND);
+        constexpr int kA0 = kOwn ? (I & 1 ? kStA0 : stg_floats(KIND) + lds_acc_ktiles(KIND) * 512) : kStA0;      // dH tile, ping-pong
         constexpr int uid = I == 0 ? XU0 : (I == 1 ? XU1 : (I == 2 ? XU2 : (I == 3 ? XU3 : XU4)));
         constexpr int hid = I == 1 ? XW1 : (I == 2 ? XW2 : (I == 3 ? XW3H : XW4));
         constexpr int hacc = I == 1 ? 0 : (I == 2 ? 1 : (I == 3 ? 2 : 3));
         const Mat mu = xyz_mat(CD, uid);
-        if (PARAMS) st_store(S + kStA0, dh, i16, g);                         // dH_i: gradient of (U_i c + v_i) is dh itself
-        if (kSlab) slab_load();                                              // L2 round trip behind the 16 MFMAs below
+        if (PARAMS) st_store(S + kA0, dh, i16, g);                           // dH_i: gradient of (U_i c + v_i) is dh itself
         if (F.grid || F.rays) gemv_bwd<2>(dc.t, dh, wl + mu.pk, i16, g);      // first 32 feature columns only
         const Act<2> dY = apply_mask(dh, K.mask[I]);
         if (I == 3) dY3 = dY;
@@ -319,21 +316,25 @@ struct XyzTile {
             st_store(S + kStA1, dY, i16, g);
             if (I > 0) st_store(S + kStX0, K.h[I > 0 ? I - 1 : 0], i16, g);
             else st_store(S + kStX0, dY3, i16, g);                           // layer 0: the W0 / W3e blocks need dY3 too
-            wave_fence();
-            const f32x4 a0 = st_load_cm(S + kStA0, 0, i16, g), a1 = st_load_cm(S + kStA0, 1, i16, g);
+            if (kOwn) block_sync(); else wave_fence();                       // owner-computed dU: every wave's dH tile is staged
             const f32x4 y0 = st_load_cm(S + kStA1, 0, i16, g), y1 = st_load_cm(S + kStA1, 1, i16, g);
             A.b[I][0] += sum4(y0); A.b[I][1] += sum4(y1);
+            if (kOwn) {
+                // this wave's two dU tiles of the layer (feature k-tile = wave): contract over the tiles of all four waves
 #pragma unroll
-            for (int Tc = 0; Tc < NTC; ++Tc) {
-                const f32x4 cc = st_load_cm(S + kStC + (Tc >> 1) * 512, Tc & 1, i16, g);
-                if (kSlab) dw_pair(ug[0][Tc], ug[1][Tc], a0, a1, cc);
-                else dw_pair(A.u[I][0][Tc], A.u[I][1][Tc], a0, a1, cc);
-            }
-            if (kSlab) {
+                for (int w = 0; w < kBwdWaves; ++w) {
+                    const float *So = stg + w * bwd_stg_floats(KIND);
+                    const f32x4 a0 = st_load_cm(So + kA0, 0, i16, g), a1 = st_load_cm(So + kA0, 1, i16, g);
+                    const f32x4 cc = st_load_cm(So + kStC + (wave >> 1) * 512, wave & 1, i16, g);
+                    dw_pair(A.u[I][0][0], A.u[I][1][0], a0, a1, cc);
+                }
+            } else {
+                const f32x4 a0 = st_load_cm(S + kA0, 0, i16, g), a1 = st_load_cm(S + kA0, 1, i16, g);
 #pragma unroll
-                for (int o = 0; o < 2; ++o)
-#pragma unroll
-                    for (int Tc = 0; Tc < NTC; ++Tc) st4(slab + (((I * 2 + o) * 4 + Tc) * 64 + lane) * 4, to_F4(ug[o][Tc]));
+                for (int Tc = 0; Tc < NTC; ++Tc) {
+                    const f32x4 cc = st_load_cm(S + kStC + (Tc >> 1) * 512, Tc & 1, i16, g);
+                    dw_pair(A.u[I][0][Tc], A.u[I][1][Tc], a0, a1, cc);
+                }
             }
             if (I > 0) {
 #pragma unroll
@@ -375,12 +376,14 @@ struct XyzTile {
 // c: features (CL).  dr: d raw of this lane's point (occupancy gradient already cut outside the bound).
 // dc: gradient w.r.t. the first 32 feature channels (the decoder's own grid).  dp: gradient w.r.t. the fp32 world position
 // through the embedding (already reduced over g).
+// With owner_du(KIND) && PARAMS every wave of the block must call this function (one block barrier per layer).
 // `mid`: called once the hidden-state chain is done (before the embedding stage); the pass issues the NEXT tile's feature
 // gather there, so that its latency hides behind the embedding stage.
 template <int KIND, bool PARAMS, class Mid>
 NSR_DEV void xyz_bwd_tile(const float *pk, const float *aux, float *S, XyzAcc<cdim_of(KIND)> &A,
                           float px, float py, float pz, const Act<cdim_of(KIND) / 16> &c,
-                          const F4 dr, BwdFlags F, int lane, Act<2> &dc, float (&dp)[3], const Dbg dbg, int ts, Mid &&mid, float *slab = nullptr) {
+                          const F4 dr, BwdFlags F, int lane, Act<2> &dc, float (&dp)[3], const Dbg dbg, int ts, Mid &&mid,
+                          const float *stg, int wave) {
     constexpr int CD = cdim_of(KIND), NOUT = nout_of(KIND), NTC = CD / 16;
     const int i16 = lane & 15, g = lane >> 4;
     Kept<KIND> K;
@@ -406,6 +409,8 @@ NSR_DEV void xyz_bwd_tile(const float *pk, const float *aux, float *S, XyzAcc<cd
         dh.t[T] = v;
     }
     if (PARAMS) {
+        // owner-computed dU: the other waves may still be reading this wave's C / dH tiles of the previous round
+        if (owner_du(KIND)) block_sync();
         if (g == 0) {
             S[kStP + i16] = px; S[kStP + 16 + i16] = py; S[kStP + 32 + i16] = pz;       // [xyz][16 points]
 #pragma unroll
@@ -433,7 +438,7 @@ NSR_DEV void xyz_bwd_tile(const float *pk, const float *aux, float *S, XyzAcc<cd
 
     act_zero(dc);
     dbg.stamp(ts + 2);
-    XyzTile<KIND, PARAMS> X{pk, aux, S, A, K, F, lane, dc, dh, slab};
+    XyzTile<KIND, PARAMS> X{pk, aux, S, A, K, F, lane, dc, dh, stg, wave};
     act_zero(X.dY3);
     act_zero(X.dY0);
     X.template layer<4>(); dbg.stamp(ts + 3);
@@ -463,7 +468,7 @@ NSR_DEV void xyz_bwd_tile(const float *pk, const float *aux, float *S, XyzAcc<cd
                     dE = mfma16(a0, dY0.t[To][r], dE);
                     dE2 = mfma16(a3, dY3.t[To][r], dE2);
                 }
-            sched_fence();
+            sched_fence_emb();
             dE += dE2;
             const B4 b = load_b4(aux, 4 * Tk + g);
             const f32x4 darg = dE * cos_acc4(vfma(splat(pz), b.z, vfma(splat(py), b.y, splat(px) * b.x)));
@@ -636,11 +641,6 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
         acc_zero(A);
         for (int t = lane; t < lds_acc_ktiles(KIND) * 512; t += 64) Sw[st_lacc(KIND) + t] = 0.f;      // this wave's LDS-resident tiles
     }
-    float *slab = nullptr;
-    if (PARAMS && KIND == NSR_FINE) {
-        slab = P.slabs + ((long long)bid_x() * kBwdWaves + wave) * kSlabFloats;
-        for (int t = 0; t < kSlabFloats / 256; ++t) st4(slab + (t * 64 + lane) * 4, F4{0.f, 0.f, 0.f, 0.f});
-    }
     const int g = lane >> 4;
 
     // sample point of a tile: position, bound test, trilinear cell of this pass's grid
@@ -687,6 +687,12 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
             if (P.d_rgb) { c_gr = P.d_rgb[cray * 3 + 0]; c_gg = P.d_rgb[cray * 3 + 1]; c_gb = P.d_rgb[cray * 3 + 2]; }
             c_dep = P.g_depth[cray];
         }
+#ifdef NSR_X_EARLYWAIT
+        if (has_ray) rayb[t0] = ray_v;
+        if (has_z) zbuf[t0] = z_v;
+        if (c_act) draw[lane] = F4{c_rw.x + (float)c_gD, c_rw.y + (float)c_gV, c_rw.z + c_gr + c_gg + c_gb, c_rw.w + (float)c_dep};
+        dbg.stamp(60);
+#endif
         if (grp == (long long)bid_x()) {
             copy_f4<(AUX_FLOATS + packed_total(KIND)) / 4>(aux, D.packed);      // visible after the barrier below
             dbg.stamp(1);
@@ -749,10 +755,14 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
         dbg.stamp(3);
         block_sync();                                           // d raw of the whole group is in LDS
         dbg.stamp(4);
-        for (int tile = wave; tile < P.tiles_per_block; tile += nwaves) {      // ---- decoder backward, tile by tile
+        // ---- decoder backward, tile by tile.  With the owner-computed dU (fine pass) the tile function contains block
+        // barriers: all four waves run the same number of rounds, tiles beyond the group are inactive (zero gradients in)
+        constexpr bool kLockstep = PARAMS && owner_du(KIND);
+        const int tile_end = kLockstep ? ((P.tiles_per_block + nwaves - 1) / nwaves) * nwaves : P.tiles_per_block;
+        for (int tile = wave; tile < tile_end; tile += nwaves) {
             const int ts = 8 + 12 * ((tile / nwaves) & 3);
             dbg.stamp(ts);
-            const bool has_next = tile + nwaves < P.tiles_per_block;
+            const bool has_next = tile + nwaves < tile_end;
             TileCtx nx;
             Lvl Lm_next;
             constexpr bool kWarm = KIND != NSR_FINE;            // (the fine pass has no registers to spare for it)
@@ -773,9 +783,9 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
             } else if constexpr (KIND == NSR_FINE) {
                 Act<4> cc;
                 cc.t[0] = c.t[0]; cc.t[1] = c.t[1]; cc.t[2] = cm.t[0]; cc.t[3] = cm.t[1];
-                xyz_bwd_tile<NSR_FINE, PARAMS>(wl, aux, Sw, A, cur.px, cur.py, cur.pz, cc, dr, F, lane, dc, dpe, dbg, ts, mid, slab);
+                xyz_bwd_tile<NSR_FINE, PARAMS>(wl, aux, Sw, A, cur.px, cur.py, cur.pz, cc, dr, F, lane, dc, dpe, dbg, ts, mid, stg, wave);
             } else {
-                xyz_bwd_tile<KIND, PARAMS>(wl, aux, Sw, A, cur.px, cur.py, cur.pz, c, dr, F, lane, dc, dpe, dbg, ts, mid);
+                xyz_bwd_tile<KIND, PARAMS>(wl, aux, Sw, A, cur.px, cur.py, cur.pz, c, dr, F, lane, dc, dpe, dbg, ts, mid, stg, wave);
             }
             // every load of the next tile is consumed before this tile's atomics are issued (see the header)
             Act<2> c_next, cm_next;
@@ -832,7 +842,7 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
                 A.w3e[1][Tk] = to_v(ld4(Sw + st_lacc(KIND) + Tk * 512 + 256 + lane * 4));
             }
         }
-        flush_acc<KIND>(A, wl, aux, stg, img, slab, wave, lane, dbg);
+        flush_acc<KIND>(A, wl, aux, stg, img, wave, lane, dbg);
     }
     dbg.stamp(7);
 }

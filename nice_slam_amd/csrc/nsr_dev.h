@@ -47,6 +47,17 @@ NSR_DEV void wave_fence() {
 }
 // keep the instruction scheduler from hoisting the next operand stream above this point
 NSR_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// the same at sites that A/B builds may switch off (tools/build_ts.sh -DNSR_X_NOFENCE_GEMV / -DNSR_X_NOFENCE_EMB)
+NSR_DEV void sched_fence_gemv() {
+#ifndef NSR_X_NOFENCE_GEMV
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+NSR_DEV void sched_fence_emb() {
+#ifndef NSR_X_NOFENCE_EMB
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
 // keep a loaded value (and thereby its load) alive up to this point without doing anything with it
 NSR_DEV void keep_alive(float v) { asm volatile("" ::"v"(v)); }
 // compiler-only memory clobber: stops loop-invariant code motion of loads across loop iterations

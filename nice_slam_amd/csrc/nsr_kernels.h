@@ -75,7 +75,6 @@ struct RenderParams {
     float *d_rays_o, *d_rays_d;
     float *partials;          // [3 passes][gridDim.x][max param count]
     int partial_stride;       // floats between two blocks' partial images
-    float *slabs;             // fine pass: per-wave global accumulator slabs [gridDim.x][waves][kSlabFloats] (nsr_bwd.h)
     long long *dbg;           // profiling stamps (NSR_TS builds only), else NULL
     // eval_points only
     const double *points;
@@ -419,7 +418,7 @@ NSR_DEV void gemv_fwd(f32x4 (&acc)[2], const Act<NT> &x, const float *pk, int la
             rb[T % kD] = to_v(ld4(pk + ((T + kD) * 128 + 64 + lane) * 4));
         }
     }
-    sched_fence();
+    sched_fence_gemv();
 }
 
 // dx[Tk] += W(slice)^T * dy       (B = dy registers; A = W[16To+4g+r][16Tk+i])
@@ -444,7 +443,7 @@ NSR_DEV void gemv_bwd(f32x4 (&dx)[NTK], const Act<2> &dy, const float *w, int i,
             for (int Tk = 0; Tk < NTK; ++Tk) ra[q % kD][Tk] = w[Tk * 512 + ((q + kD) >> 2) * 256 + ((q + kD) & 3) * 4 + lo];
         }
     }
-    sched_fence();
+    sched_fence_gemv();
 }
 
 // cooperative copy of a decoder's packed operand stream into LDS (caller provides the barriers)
@@ -561,7 +560,7 @@ NSR_DEV void embed(Act<kET> &e, const float *aux, float px, float py, float pz, 
         const B4 b = load_b4(aux, 4 * T + g);
         const f32x4 arg = vfma(splat(pz), b.z, vfma(splat(py), b.y, splat(px) * b.x));     // decoder.py:29
         e.t[T] = sin_acc4(arg);                                                            // decoder.py:30
-        sched_fence();                  // bound the ILP the scheduler extracts from 24 independent sines
+        sched_fence_emb();                  // bound the ILP the scheduler extracts from 24 independent sines
     }
 }
 

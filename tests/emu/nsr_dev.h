@@ -158,6 +158,8 @@ NSR_DEV float shfl_down(float v, int d) {
 struct Dbg { long long *p; NSR_DEV void stamp(int) const {} };
 NSR_DEV void wave_fence() { emu::wave_sync(); }
 NSR_DEV void sched_fence() {}
+NSR_DEV void sched_fence_gemv() {}
+NSR_DEV void sched_fence_emb() {}
 NSR_DEV void keep_alive(float) {}
 NSR_DEV void loop_fence() {}
 NSR_DEV void block_sync() { emu::block_sync_impl(); }

@@ -43,6 +43,9 @@ for p_, nm in enumerate(("middle", "fine", "color")[:{"middle": 1, "fine": 2, "c
     for s_ in range(1, 8):
         dlt = (blk[:, :, s_] - blk[:, :, s_ - 1])[ok]
         print("   %-36s mean %8.0f  p10 %8.0f  p90 %8.0f   %5.1f %%" % (blockn[s_], dlt.mean(), np.percentile(dlt, 10), np.percentile(dlt, 90), 100 * dlt.mean() / tot.mean()))
+    if (blk[:, :, 60][ok] > 0).all():
+        dlt = (blk[:, :, 60] - blk[:, :, 0])[ok]
+        print("      %-32s mean %8.0f  p10 %8.0f  p90 %8.0f" % ("early loads landed", dlt.mean(), np.percentile(dlt, 10), np.percentile(dlt, 90)))
     for a_, b_, nm_ in ((56, 6, "flush: LDS-tile reload"), (57, 56, "flush: barrier"), (58, 57, "flush: vectors + v"), (59, 58, "flush: barrier"), (7, 59, "flush: tile rounds")):
         if (blk[:, :, a_][ok] > 0).all():
             dlt = (blk[:, :, a_] - blk[:, :, b_])[ok]
