@@ -13,6 +13,9 @@
  *   nsr_render_bwd       <- the autograd backward of the above (src/Mapper.py:503, src/Tracker.py:125)
  *   nsr_eval_points_fwd  <- src/utils/Renderer.py:23-61   Renderer.eval_points (forward only)
  *   nsr_masked_adam      <- src/Mapper.py:368-379,394-401,504,511-519  masked write-back + Adam on one feature grid
+ *   nsr_masked_adam_multi <- the same for all grids of a stage, step counts on the device (capturable)
+ *   nsr_get_samples_window <- src/Mapper.py:437-481  sampling loop over the mapping window + bounding-box pre-filter
+ *   nsr_pose_grad        <- autograd of src/common.py:74-88 for that window (local BA, src/Mapper.py:417-419)
  *
  * Conventions
  *   - all pointers are DEVICE pointers owned by the caller (PyTorch); the library never frees or
@@ -35,7 +38,7 @@
 extern "C" {
 #endif
 
-#define NSR_VERSION 1
+#define NSR_VERSION 2
 
 /* stages of NICE.forward (decoder.py:312-342) */
 enum { NSR_STAGE_COARSE = 0, NSR_STAGE_MIDDLE = 1, NSR_STAGE_FINE = 2, NSR_STAGE_COLOR = 3 };
@@ -84,6 +87,17 @@ typedef struct nsr_render_args {
                                  written by fwd, read by bwd.  May be NULL for a forward-only call.  */
     double *zvals;            /* [N][S] sorted sample depths; optional: written by fwd when non-NULL, and when non-NULL in
                                  bwd they are loaded instead of being recomputed by each decoder pass                  */
+    /* --- fused mapping loss (src/Mapper.py:487-493), optional: all NULL / 0 for the plain renderer ------------------
+     * fwd with loss != NULL adds   sum over rays r with keep[r] of  [gt_depth[r] > 0] |gt_depth[r] - depth[r]|
+     *                              + (colour stage) w_color * sum_c |gt_color[r][c] - rgb[r][c]|     to *loss (fp64);
+     * bwd with nsr_bwd_args.loss_kind == 1 differentiates exactly that sum (needs gt_depth, gt_color, keep, w_color and
+     * the forward's depth / rgb in this block) instead of taking d_depth / d_var / d_rgb. */
+    const float *gt_color;    /* [N][3] */
+    const uint8_t *keep;      /* [N] ray mask of the callers' bounding-box pre-filter (nsr_aabb_keep / nsr_get_samples_window);
+                                 NULL = every ray counts */
+    double *loss;             /* device scalar, caller-zeroed */
+    float w_color;            /* cfg mapping.w_color_loss */
+    int32_t pad2_;
 } nsr_render_args;
 
 typedef struct nsr_bwd_args {
@@ -100,6 +114,9 @@ typedef struct nsr_bwd_args {
                                  fresh gradient); 1: it is OVERWRITTEN (saves the caller the zero fill) */
     void *ev_start;           /* optional hipEvent_t pair recorded on `stream` right before / after the main   */
     void *ev_stop;            /* backward kernel (excludes the small partial-sum kernels); NULL = no timing      */
+    int32_t loss_kind;        /* 0: gradients of the outputs are given (d_depth / d_var / d_rgb); 1: fused mapping loss,
+                                 see nsr_render_args (d_depth / d_var / d_rgb are ignored and may be NULL) */
+    int32_t pad2_;
 } nsr_bwd_args;
 
 int nsr_version(void);
@@ -127,6 +144,29 @@ int nsr_get_samples(const int64_t *indices, int64_t n, int32_t H0, int32_t H1, i
                     const float *c2w, int32_t c2w_stride, const float *depth, const float *color,
                     float *rays_o, float *rays_d, float *out_depth, float *out_color, void *stream);
 
+/* --- the mapper's sampling loop in one launch -----------------------------------------------------------------------------
+ * Replaces, for the K frames of the mapping window, the K get_samples calls + torch.cat of src/Mapper.py:437-468 and the
+ * bounding-box pre-filter of :471-481 (as a mask, like nsr_aabb_keep): indices [K][n] (row-major flat indices into the crop,
+ * one draw per frame), frames[k] = that frame's depth [H][W], colour [H][W][3] and pose (row-major 3x4 or 4x4, row stride
+ * c2w_stride floats), all device pointers; outputs are the concatenation over frames, [K*n] rays.  keep / kept_max optional
+ * (kept_max caller-zeroed).  bound_lo / bound_hi: HOST arrays of 3 doubles.  K <= 32. */
+typedef struct nsr_frame {
+    const float *depth;
+    const float *color;
+    const float *c2w;
+    int32_t c2w_stride;
+    int32_t pad_;
+} nsr_frame;
+int nsr_get_samples_window(const int64_t *indices, int32_t K, int64_t n, int32_t H0, int32_t H1, int32_t W0, int32_t W1,
+                           int32_t W_full, float fx, float fy, float cx, float cy, const nsr_frame *frames,
+                           float *rays_o, float *rays_d, float *out_depth, float *out_color,
+                           const double *bound_lo, const double *bound_hi, uint8_t *keep, float *kept_max, void *stream);
+/* gradient of the K poses from the ray gradients of such a window (autograd of src/common.py:74-88; local BA,
+ * src/Mapper.py:417-419,441-453): d_c2w [K][12] = rows 0..2 of each pose, row-major. */
+int nsr_pose_grad(const int64_t *indices, int32_t K, int64_t n, int32_t H0, int32_t H1, int32_t W0, int32_t W1,
+                  float fx, float fy, float cx, float cy, const float *d_rays_o, const float *d_rays_d,
+                  float *d_c2w, void *stream);
+
 /* --- the per-iteration grid update of Mapper.optimize_map, fused ---------------------------------
  * Replaces, for one feature grid, `val[mask] = val_grad` (src/Mapper.py:394-401), the Adam step on the masked leaf
  * (:368-379,504, torch.optim.Adam defaults) and the write-back `val[mask] = val_grad.detach()` (:511-519) by one in-place
@@ -138,6 +178,25 @@ int nsr_get_samples(const int64_t *indices, int64_t n, int32_t H0, int32_t H1, i
  * lr == 0 still updates the moments, exactly like torch.optim.Adam. */
 int nsr_masked_adam(float *p, const float *g, float *m, float *v, const uint8_t *voxel_mask, int64_t n_voxels,
                     float step_size, float beta1, float beta2, float eps, float bias2_sqrt, void *stream);
+
+/* The same for up to 4 grids in ONE launch pair with the step counts kept on the device, so that a whole mapping iteration
+ * can be captured in a hipGraph (no host scalar changes between replays): steps[i] (device int32, one per grid) is
+ * incremented, step_size = lr / (1 - b1^t) and bias2_sqrt = sqrt(1 - b2^t) are formed on the device in fp64, then every
+ * grid is updated like nsr_masked_adam does.  zero_grad != 0 also clears the gradient of the voxels it read (so that a
+ * persistent, accumulated-into gradient buffer needs no separate fill).  scratch: 8 device floats. */
+typedef struct nsr_adam_grid {
+    float *p;
+    float *g;
+    float *m;
+    float *v;
+    const uint8_t *voxel_mask;
+    int64_t n_voxels;
+    int32_t *step;            /* device counter of this grid */
+    float lr;
+    int32_t pad_;
+} nsr_adam_grid;
+int nsr_masked_adam_multi(const nsr_adam_grid *grids, int32_t n_grids, float beta1, float beta2, float eps,
+                          int32_t zero_grad, float *scratch, void *stream);
 
 /* --- frustum feature selection ---------------------------------------------------------------------
  * Replaces Mapper.get_mask_from_c2w (src/Mapper.py:93-164) for one non-coarse feature grid: every voxel centre (xs[ix],

@@ -12,6 +12,7 @@ import os
 import torch  # noqa: F401  -- must be loaded first: libnsr.so binds to the HIP runtime (libamdhip64.so.7) torch already mapped
 
 MAX_SAMPLES = 64
+ABI_VERSION = 2
 STAGE_ID = {"coarse": 0, "middle": 1, "fine": 2, "color": 3}
 SLOT_NAMES = ("coarse", "middle", "fine", "color")
 
@@ -37,7 +38,8 @@ class NsrRenderArgs(C.Structure):
                 ("t_uniform", C.c_float * MAX_SAMPLES), ("t_surface", C.c_double * MAX_SAMPLES),
                 ("grid", NsrGrid * 4), ("dec", NsrDecoder * 4),
                 ("depth", C.c_void_p), ("var", C.c_void_p), ("rgb", C.c_void_p), ("raw", C.c_void_p),
-                ("zvals", C.c_void_p)]
+                ("zvals", C.c_void_p),
+                ("gt_color", C.c_void_p), ("keep", C.c_void_p), ("loss", C.c_void_p), ("w_color", C.c_float), ("pad2_", C.c_int32)]
 
 
 class NsrBwdArgs(C.Structure):
@@ -45,7 +47,16 @@ class NsrBwdArgs(C.Structure):
                 ("d_rays_o", C.c_void_p), ("d_rays_d", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
                 ("max_blocks", C.c_int32), ("overwrite_dparams", C.c_int32),
-                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
+                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p), ("loss_kind", C.c_int32), ("pad2_", C.c_int32)]
+
+
+class NsrFrame(C.Structure):
+    _fields_ = [("depth", C.c_void_p), ("color", C.c_void_p), ("c2w", C.c_void_p), ("c2w_stride", C.c_int32), ("pad_", C.c_int32)]
+
+
+class NsrAdamGrid(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("voxel_mask", C.c_void_p),
+                ("n_voxels", C.c_int64), ("step", C.c_void_p), ("lr", C.c_float), ("pad_", C.c_int32)]
 
 
 # every symbol include/nsr.h declares: (name, restype, argtypes)
@@ -64,6 +75,14 @@ SYMBOLS = (
     ("nsr_get_samples", C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("nsr_get_samples_window", C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(NsrFrame),
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("nsr_pose_grad", C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("nsr_masked_adam_multi", C.c_int, [C.POINTER(NsrAdamGrid), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32,
+                                        C.c_void_p, C.c_void_p]),
     ("nsr_aabb_keep", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     ("nsr_frustum_workspace_floats", C.c_int64, [C.c_int64]),
@@ -92,8 +111,8 @@ class Lib:
             fn.restype = res
             fn.argtypes = args
             setattr(self, name, fn)
-        if self.nsr_version() != 1:
-            raise NsrError(f"{path}: ABI version {self.nsr_version()} != 1")
+        if self.nsr_version() != ABI_VERSION:
+            raise NsrError(f"{path}: ABI version {self.nsr_version()} != {ABI_VERSION}")
 
     def check(self, rc: int, what: str = "nsr"):
         if rc != 0:

@@ -95,6 +95,7 @@ int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays,
         P.dec[s].params = d.params; P.dec[s].packed = d.packed; P.dec[s].dparams = d.dparams;
     }
     P.depth = a->depth; P.var = a->var; P.rgb = a->rgb; P.raw = a->raw; P.zvals = a->zvals;
+    P.gt_color = a->gt_color; P.keep = a->keep; P.loss = a->loss; P.w_color = a->w_color;
     return 0;
 }
 
@@ -189,11 +190,15 @@ int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream
     if (int rc = build_params(a, P, true, true)) return rc;
     if (!b) return fail("nsr_render_bwd: null backward block");
     if (!a->raw) return fail("nsr_render_bwd: the forward pass must have saved `raw`");
-    if (!b->d_depth && !b->d_var && !b->d_rgb) return fail("nsr_render_bwd: no output gradient given");
+    if (b->loss_kind != 0 && b->loss_kind != 1) return fail("nsr_render_bwd: unknown loss_kind");
+    if (b->loss_kind == 0 && !b->d_depth && !b->d_var && !b->d_rgb) return fail("nsr_render_bwd: no output gradient given");
+    if (b->loss_kind == 1 && (!a->rgb || (a->stage == NSR_STAGE_COLOR && !a->gt_color)))
+        return fail("nsr_render_bwd: the fused mapping loss needs the forward's rgb (and gt_color in the colour stage)");
     if (!b->depth) return fail("nsr_render_bwd: forward depth is required");
     if ((b->d_rays_o == nullptr) != (b->d_rays_d == nullptr)) return fail("nsr_render_bwd: d_rays_o / d_rays_d must be given together");
     if (P.n_rays == 0) return 0;
     P.d_depth = b->d_depth; P.d_var = b->d_var; P.d_rgb = b->d_rgb; P.g_depth = b->depth;
+    P.loss_kind = b->loss_kind;
     P.d_rays_o = b->d_rays_o; P.d_rays_d = b->d_rays_d;
 #ifdef NSR_TS
     if (const char *e = getenv("NSR_DBG_PTR")) P.dbg = reinterpret_cast<long long *>(strtoull(e, nullptr, 16));
@@ -326,6 +331,72 @@ int nsr_frustum_mask(const float *w2c, const float *cam_center, double fx, doubl
     NSR_LAUNCH(nsr::frustum_mask_kernel<0>, dim3((unsigned)P.nblocks), dim3(tb), tb * sizeof(float), stream, P);
     NSR_LAUNCH(nsr::frustum_mask_kernel<1>, dim3((unsigned)P.nblocks), dim3(tb), tb * sizeof(float), stream, P);
     return finish("nsr_frustum_mask");
+}
+
+int nsr_get_samples_window(const int64_t *indices, int32_t K, int64_t n, int32_t H0, int32_t H1, int32_t W0, int32_t W1,
+                           int32_t W_full, float fx, float fy, float cx, float cy, const nsr_frame *frames,
+                           float *rays_o, float *rays_d, float *out_depth, float *out_color,
+                           const double *bound_lo, const double *bound_hi, uint8_t *keep, float *kept_max, void *stream) {
+    if (K < 0 || K > NSR_MAX_WINDOW) return fail("nsr_get_samples_window: K must be in [0, 32]");
+    if (n < 0 || H1 <= H0 || W1 <= W0 || W_full < W1) return fail("nsr_get_samples_window: bad crop");
+    if (K == 0 || n == 0) return 0;
+    if (!indices || !frames || !rays_o || !rays_d || !out_depth || !out_color || !bound_lo || !bound_hi)
+        return fail("nsr_get_samples_window: null pointer");
+    nsr::WindowParams P;
+    std::memset(&P, 0, sizeof(P));
+    P.indices = reinterpret_cast<const long long *>(indices);
+    P.n = n; P.K = K; P.H0 = H0; P.W0 = W0; P.crop_w = W1 - W0; P.W_full = W_full;
+    P.fx = fx; P.fy = fy; P.cx = cx; P.cy = cy;
+    for (int k = 0; k < K; ++k) {
+        if (!frames[k].depth || !frames[k].color || !frames[k].c2w) return fail("nsr_get_samples_window: null frame pointer");
+        P.depth[k] = frames[k].depth; P.color[k] = frames[k].color; P.c2w[k] = frames[k].c2w; P.c2w_stride[k] = frames[k].c2w_stride;
+    }
+    P.rays_o = rays_o; P.rays_d = rays_d; P.out_depth = out_depth; P.out_color = out_color;
+    for (int a = 0; a < 3; ++a) { P.lo[a] = bound_lo[a]; P.hi[a] = bound_hi[a]; }
+    P.keep = keep; P.kept_max = kept_max;
+    const int tb = 256;
+    NSR_LAUNCH(nsr::get_samples_window_kernel, dim3((unsigned)((n + tb - 1) / tb), K), dim3(tb), 0, stream, P);
+    return finish("nsr_get_samples_window");
+}
+
+int nsr_pose_grad(const int64_t *indices, int32_t K, int64_t n, int32_t H0, int32_t H1, int32_t W0, int32_t W1,
+                  float fx, float fy, float cx, float cy, const float *d_rays_o, const float *d_rays_d,
+                  float *d_c2w, void *stream) {
+    if (K < 0 || n < 0 || H1 <= H0 || W1 <= W0) return fail("nsr_pose_grad: bad arguments");
+    if (K == 0) return 0;
+    if (!indices || !d_rays_o || !d_rays_d || !d_c2w) return fail("nsr_pose_grad: null pointer");
+    nsr::PoseGradParams P;
+    P.indices = reinterpret_cast<const long long *>(indices);
+    P.n = n; P.H0 = H0; P.W0 = W0; P.crop_w = W1 - W0;
+    P.fx = fx; P.fy = fy; P.cx = cx; P.cy = cy;
+    P.d_rays_o = d_rays_o; P.d_rays_d = d_rays_d; P.out = d_c2w;
+    const int tb = 256;
+    NSR_LAUNCH(nsr::pose_grad_kernel, dim3((unsigned)K), dim3(tb), 12 * tb * sizeof(float), stream, P);
+    return finish("nsr_pose_grad");
+}
+
+int nsr_masked_adam_multi(const nsr_adam_grid *grids, int32_t n_grids, float beta1, float beta2, float eps,
+                          int32_t zero_grad, float *scratch, void *stream) {
+    if (n_grids < 0 || n_grids > 4) return fail("nsr_masked_adam_multi: 0..4 grids");
+    if (n_grids == 0) return 0;
+    if (!grids || !scratch) return fail("nsr_masked_adam_multi: null pointer");
+    nsr::AdamMulti A;
+    std::memset(&A, 0, sizeof(A));
+    long long nmax = 0;
+    for (int i = 0; i < n_grids; ++i) {
+        const nsr_adam_grid &g = grids[i];
+        if (!g.p || !g.g || !g.m || !g.v || !g.step || g.n_voxels < 0) return fail("nsr_masked_adam_multi: bad grid entry");
+        A.p[i] = g.p; A.g[i] = g.g; A.m[i] = g.m; A.v[i] = g.v; A.mask[i] = g.voxel_mask; A.n_vox[i] = g.n_voxels;
+        A.step[i] = g.step; A.lr[i] = g.lr;
+        nmax = g.n_voxels > nmax ? g.n_voxels : nmax;
+    }
+    A.n = n_grids; A.b1 = beta1; A.b2 = beta2; A.eps = eps; A.zero_grad = zero_grad; A.scal = scratch;
+    NSR_LAUNCH(nsr::adam_tick_kernel, dim3(1), dim3(64), 0, stream, A);
+    if (nmax > 0) {
+        const int tb = 256;
+        NSR_LAUNCH(nsr::masked_adam_multi_kernel, dim3((unsigned)((nmax * 8 + tb - 1) / tb), n_grids), dim3(tb), 0, stream, A);
+    }
+    return finish("nsr_masked_adam_multi");
 }
 
 int nsr_aabb_keep(const float *rays_o, const float *rays_d, const float *gt_depth, int64_t n,

@@ -75,6 +75,12 @@ struct RenderParams {
     float *d_rays_o, *d_rays_d;
     float *partials;          // [3 passes][gridDim.x][max param count]
     int partial_stride;       // floats between two blocks' partial images
+    // fused mapping loss (Mapper.py:487-493), optional
+    const float *gt_color;    // [N][3]
+    const unsigned char *keep; // [N] bounding-box mask of the callers' pre-filter, or NULL (all rays count)
+    double *loss;             // forward: += sum over rays of the loss terms
+    float w_color;            // weight of the colour term (colour stage only)
+    int loss_kind;            // backward: 1 = d outputs are those of the mapping loss, computed here from the forward results
     long long *dbg;           // profiling stamps (NSR_TS builds only), else NULL
     // eval_points only
     const double *points;
@@ -757,6 +763,7 @@ NSR_KERNEL NSR_BOUNDS(768) void render_fwd_kernel(const RenderParams P) {
     load_stage_aux<STAGE>(P, aux);
     if (STAGE == NSR_STAGE_COARSE) load_packed<NSR_COARSE>(wl, P.dec[NSR_COARSE].packed);     // only one decoder: staged once
     if (STAGE == NSR_STAGE_MIDDLE) load_packed<NSR_MIDDLE>(wl, P.dec[NSR_MIDDLE].packed);
+    double loss_acc = 0.0;                         // lane 0 of every wave: loss terms of the rays it composited
     for (long long grp = bid_x(); grp < P.n_groups; grp += nblk_x()) {
         loop_fence();
         const long long ray0 = grp * P.rays_per_block;
@@ -797,10 +804,18 @@ NSR_KERNEL NSR_BOUNDS(768) void render_fwd_kernel(const RenderParams P) {
                 P.depth[rayq] = depth;
                 P.var[rayq] = var;
                 P.rgb[rayq * 3 + 0] = cr; P.rgb[rayq * 3 + 1] = cg; P.rgb[rayq * 3 + 2] = cb;
+                if (P.loss && (!P.keep || P.keep[rayq])) {      // Mapper.py:487-493 on the rays the pre-filter keeps
+                    const float gd = P.gt_depth ? P.gt_depth[rayq] : 0.f;
+                    if (gd > 0.f) loss_acc += fabs((double)gd - depth);
+                    if (STAGE == NSR_STAGE_COLOR && P.gt_color)
+                        loss_acc += (double)(P.w_color * ((fabsf(P.gt_color[rayq * 3 + 0] - cr) + fabsf(P.gt_color[rayq * 3 + 1] - cg)) +
+                                                          fabsf(P.gt_color[rayq * 3 + 2] - cb)));
+                }
             }
         }
         block_sync();
     }
+    if (P.loss && lane == 0 && loss_acc != 0.0) atomic_add_global_d(P.loss, loss_acc);
 }
 
 // Renderer.eval_points forward over a flat list of points (Renderer.py:23-61).  Same decoder phases as the render
@@ -900,6 +915,52 @@ NSR_KERNEL void masked_adam_kernel(const AdamParams A) {
     st4(A.p + o, p);
 }
 
+// The same for all grids of a stage with the step counts on the device (capturable iterations): adam_tick_kernel bumps
+// each grid's counter and forms the two bias-correction scalars in fp64 (what torch.optim.Adam does on the host); the update
+// kernel takes the grid from blockIdx.y.
+struct AdamMulti {
+    float *p[4];
+    float *g[4];
+    float *m[4], *v[4];
+    const unsigned char *mask[4];
+    long long n_vox[4];
+    int *step[4];
+    float lr[4];
+    int n;
+    float b1, b2, eps;
+    int zero_grad;
+    float *scal;              // [4][2]: step_size, bias2_sqrt
+};
+NSR_KERNEL void adam_tick_kernel(const AdamMulti A) {
+    const int i = tid();
+    if (i >= A.n) return;
+    const int t = A.step[i][0] + 1;
+    A.step[i][0] = t;
+    A.scal[2 * i + 0] = (float)((double)A.lr[i] / (1.0 - pow((double)A.b1, (double)t)));
+    A.scal[2 * i + 1] = (float)sqrt(1.0 - pow((double)A.b2, (double)t));
+}
+NSR_KERNEL void masked_adam_multi_kernel(const AdamMulti A) {
+    const int i = bid_y();
+    const long long t = (long long)bid_x() * nthreads() + tid();
+    const long long vox = t >> 3;
+    if (vox >= A.n_vox[i]) return;
+    if (A.mask[i] && A.mask[i][vox] == 0) return;
+    const long long o = vox * kC + (t & 7) * 4;
+    const F4 g = ld4(A.g[i] + o);
+    F4 m = ld4(A.m[i] + o), v = ld4(A.v[i] + o), p = ld4(A.p[i] + o);
+    const float step = A.scal[2 * i], rs2 = A.scal[2 * i + 1], omb1 = 1.f - A.b1, omb2 = 1.f - A.b2;
+#define NSR_ADAM1(c)                                                    \
+    m.c = m.c + omb1 * (g.c - m.c);                                      \
+    v.c = v.c * A.b2 + (omb2 * g.c) * g.c;                               \
+    p.c = p.c - step * (m.c / (sqrtf(v.c) / rs2 + A.eps));
+    NSR_ADAM1(x) NSR_ADAM1(y) NSR_ADAM1(z) NSR_ADAM1(w)
+#undef NSR_ADAM1
+    st4(A.m[i] + o, m);
+    st4(A.v[i] + o, v);
+    st4(A.p[i] + o, p);
+    if (A.zero_grad) st4(A.g[i] + o, F4{0.f, 0.f, 0.f, 0.f});
+}
+
 // ------------------------------------------------------------------------------------------------
 // get_samples after the index draw (common.py:74-134)
 // ------------------------------------------------------------------------------------------------
@@ -931,6 +992,96 @@ NSR_KERNEL void get_samples_kernel(const SampleParams P) {
         // torch.sum(dirs * c2w[:3,:3], -1): products, then left-to-right sum (common.py:87)
         P.rays_d[t * 3 + a] = (dx * R[0] + dy * R[1]) + dzv * R[2];
         P.rays_o[t * 3 + a] = R[3];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The mapper's sampling loop in one launch (Mapper.py:437-468: get_samples per keyframe of the window, torch.cat) together
+// with its bounding-box pre-filter (:471-481) as a byte mask + the kept rays' maximum depth.  grid.y = frame.
+// ------------------------------------------------------------------------------------------------
+#define NSR_MAX_WINDOW 32
+struct WindowParams {
+    const long long *indices;          // [K][n]
+    long long n;
+    int K, H0, W0, crop_w, W_full;
+    float fx, fy, cx, cy;
+    const float *depth[NSR_MAX_WINDOW], *color[NSR_MAX_WINDOW], *c2w[NSR_MAX_WINDOW];
+    int c2w_stride[NSR_MAX_WINDOW];
+    float *rays_o, *rays_d, *out_depth, *out_color;      // [K*n] concatenated in frame order
+    double lo[3], hi[3];
+    unsigned char *keep;               // optional
+    float *kept_max;                   // optional, caller-zeroed
+};
+
+NSR_KERNEL void get_samples_window_kernel(const WindowParams P) {
+    const long long i = (long long)bid_x() * nthreads() + tid();
+    const int k = bid_y();
+    if (i >= P.n) return;
+    const long long t = (long long)k * P.n + i;
+    const long long idx = P.indices[t];
+    const int row = (int)(idx / P.crop_w) + P.H0, col = (int)(idx % P.crop_w) + P.W0;
+    const long long pix = (long long)row * P.W_full + col;
+    const float gd = P.depth[k][pix];
+    P.out_depth[t] = gd;
+    P.out_color[t * 3 + 0] = P.color[k][pix * 3 + 0];
+    P.out_color[t * 3 + 1] = P.color[k][pix * 3 + 1];
+    P.out_color[t * 3 + 2] = P.color[k][pix * 3 + 2];
+    const float dx = ((float)col - P.cx) / P.fx, dy = -(((float)row - P.cy) / P.fy), dzv = -1.f;
+    double tb = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float *R = P.c2w[k] + a * P.c2w_stride[k];
+        const float d = (dx * R[0] + dy * R[1]) + dzv * R[2];       // common.py:87: products, then left-to-right sum
+        const float o = R[3];
+        P.rays_d[t * 3 + a] = d;
+        P.rays_o[t * 3 + a] = o;
+        const double t0 = (P.lo[a] - (double)o) / (double)d, t1 = (P.hi[a] - (double)o) / (double)d;
+        const double m = tmax(t0, t1);
+        tb = (a == 0) ? m : tmin(tb, m);
+    }
+    const bool kp = tb >= (double)gd;
+    if (P.keep) P.keep[t] = kp ? 1 : 0;
+    if (kp && P.kept_max && gd > 0.f) atomic_max_pos(P.kept_max, gd);
+}
+
+// gradient of the window's poses from the ray gradients (autograd of common.py:74-88): per frame k
+//   d c2w[k][a][j] = sum_i d_rays_d[i][a] * dirs[i][j] (j < 3),   d c2w[k][a][3] = sum_i d_rays_o[i][a]
+// one block per frame, out [K][12] (rows 0..2 of the pose)
+struct PoseGradParams {
+    const long long *indices;
+    long long n;
+    int H0, W0, crop_w;
+    float fx, fy, cx, cy;
+    const float *d_rays_o, *d_rays_d;
+    float *out;
+};
+NSR_KERNEL void pose_grad_kernel(const PoseGradParams P) {
+    float *red = reinterpret_cast<float *>(lds_base());          // [12][nthreads]
+    const int k = bid_x(), nt = nthreads();
+    float acc[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc[q] = 0.f;
+    for (long long i = tid(); i < P.n; i += nt) {
+        const long long t = (long long)k * P.n + i;
+        const long long idx = P.indices[t];
+        const int row = (int)(idx / P.crop_w) + P.H0, col = (int)(idx % P.crop_w) + P.W0;
+        const float dir[3] = {((float)col - P.cx) / P.fx, -(((float)row - P.cy) / P.fy), -1.f};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float gd = P.d_rays_d[t * 3 + a];
+            acc[a * 4 + 0] = fmaf(gd, dir[0], acc[a * 4 + 0]);
+            acc[a * 4 + 1] = fmaf(gd, dir[1], acc[a * 4 + 1]);
+            acc[a * 4 + 2] = fmaf(gd, dir[2], acc[a * 4 + 2]);
+            acc[a * 4 + 3] += P.d_rays_o[t * 3 + a];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 12; ++q) red[q * nt + tid()] = acc[q];
+    block_sync();
+    if (tid() < 12) {
+        float s = 0.f;
+        for (int j = 0; j < nt; ++j) s += red[tid() * nt + j];
+        P.out[k * 12 + tid()] = s;
     }
 }
 

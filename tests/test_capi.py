@@ -35,7 +35,7 @@ def test_header_symbols_are_bound_and_exported(lib):
 
 def test_sizes_and_error_reporting(lib):
     from nice_slam_amd.layout import param_count
-    assert lib.nsr_version() == 1
+    assert lib.nsr_version() == 2
     assert [lib.nsr_param_count(i) for i in range(4)] == [param_count(s) for s in ("coarse", "middle", "fine", "color")] \
         == [6337, 15800, 20920, 15899]
     assert [lib.nsr_packed_count(i) for i in range(4)] == [836 + 6144, 836 + 15360, 836 + 20480, 836 + 15360]    # [aux table | operand stream]
