@@ -89,13 +89,15 @@ typedef struct nsr_render_args {
                                  bwd they are loaded instead of being recomputed by each decoder pass                  */
     /* --- fused mapping loss (src/Mapper.py:487-493), optional: all NULL / 0 for the plain renderer ------------------
      * fwd with loss != NULL adds   sum over rays r with keep[r] of  [gt_depth[r] > 0] |gt_depth[r] - depth[r]|
-     *                              + (colour stage) w_color * sum_c |gt_color[r][c] - rgb[r][c]|     to *loss (fp64);
-     * bwd with nsr_bwd_args.loss_kind == 1 differentiates exactly that sum (needs gt_depth, gt_color, keep, w_color and
-     * the forward's depth / rgb in this block) instead of taking d_depth / d_var / d_rgb. */
+     *                              + (colour stage) w_color * sum_c |gt_color[r][c] - rgb[r][c]|     to *loss (fp64)
+     * and writes that sum's derivative w.r.t. each ray's outputs to dl_depth / dl_rgb -- exactly the arrays
+     * nsr_render_bwd takes as d_depth / d_rgb (d_var = NULL), so the caller's loss and its backward cost no launch. */
     const float *gt_color;    /* [N][3] */
     const uint8_t *keep;      /* [N] ray mask of the callers' bounding-box pre-filter (nsr_aabb_keep / nsr_get_samples_window);
                                  NULL = every ray counts */
     double *loss;             /* device scalar, caller-zeroed */
+    double *dl_depth;         /* [N]    out, optional */
+    float *dl_rgb;            /* [N][3] out, optional */
     float w_color;            /* cfg mapping.w_color_loss */
     int32_t pad2_;
 } nsr_render_args;
@@ -114,9 +116,6 @@ typedef struct nsr_bwd_args {
                                  fresh gradient); 1: it is OVERWRITTEN (saves the caller the zero fill) */
     void *ev_start;           /* optional hipEvent_t pair recorded on `stream` right before / after the main   */
     void *ev_stop;            /* backward kernel (excludes the small partial-sum kernels); NULL = no timing      */
-    int32_t loss_kind;        /* 0: gradients of the outputs are given (d_depth / d_var / d_rgb); 1: fused mapping loss,
-                                 see nsr_render_args (d_depth / d_var / d_rgb are ignored and may be NULL) */
-    int32_t pad2_;
 } nsr_bwd_args;
 
 int nsr_version(void);

@@ -39,7 +39,8 @@ class NsrRenderArgs(C.Structure):
                 ("grid", NsrGrid * 4), ("dec", NsrDecoder * 4),
                 ("depth", C.c_void_p), ("var", C.c_void_p), ("rgb", C.c_void_p), ("raw", C.c_void_p),
                 ("zvals", C.c_void_p),
-                ("gt_color", C.c_void_p), ("keep", C.c_void_p), ("loss", C.c_void_p), ("w_color", C.c_float), ("pad2_", C.c_int32)]
+                ("gt_color", C.c_void_p), ("keep", C.c_void_p), ("loss", C.c_void_p), ("dl_depth", C.c_void_p), ("dl_rgb", C.c_void_p),
+                ("w_color", C.c_float), ("pad2_", C.c_int32)]
 
 
 class NsrBwdArgs(C.Structure):
@@ -47,7 +48,7 @@ class NsrBwdArgs(C.Structure):
                 ("d_rays_o", C.c_void_p), ("d_rays_d", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
                 ("max_blocks", C.c_int32), ("overwrite_dparams", C.c_int32),
-                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p), ("loss_kind", C.c_int32), ("pad2_", C.c_int32)]
+                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
 
 
 class NsrFrame(C.Structure):

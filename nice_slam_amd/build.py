@@ -35,13 +35,38 @@ def is_fresh() -> bool:
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and is_fresh():
         return OUT
-    cmd = [hipcc_path(), *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", OUT]
+    cmd = [hipcc_path(), *FLAGS, "-Rpass-analysis=kernel-resource-usage", *[os.path.join(CSRC, s) for s in SOURCES], "-o", OUT]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    _write_resources(res.stderr)
     return OUT
+
+
+RESOURCES = os.path.join(HERE, "libnsr.resources.json")
+
+
+def _write_resources(remarks: str):
+    """Per-kernel register / scratch usage as the compiler reports it (the backward kernels run one wave per SIMD on the
+    whole 512-entry register file; a change that pushes them into heavy scratch use shows up here, and in tests/test_capi.py)."""
+    import json
+    import re
+    out, name = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            out[name] = {}
+            continue
+        for key, pat in (("vgprs", r" VGPRs: (\d+)"), ("agprs", r"AGPRs: (\d+)"), ("scratch_bytes_per_lane", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                         ("sgprs", r"TotalSGPRs: (\d+)"), ("occupancy_waves_per_simd", r"Occupancy \[waves/SIMD\]: (\d+)")):
+            m = re.search(pat, line)
+            if m and name:
+                out[name][key] = int(m.group(1))
+    with open(RESOURCES, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

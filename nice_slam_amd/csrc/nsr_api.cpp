@@ -96,6 +96,7 @@ int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays,
     }
     P.depth = a->depth; P.var = a->var; P.rgb = a->rgb; P.raw = a->raw; P.zvals = a->zvals;
     P.gt_color = a->gt_color; P.keep = a->keep; P.loss = a->loss; P.w_color = a->w_color;
+    P.dl_depth = a->dl_depth; P.dl_rgb = a->dl_rgb;
     return 0;
 }
 
@@ -190,15 +191,11 @@ int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream
     if (int rc = build_params(a, P, true, true)) return rc;
     if (!b) return fail("nsr_render_bwd: null backward block");
     if (!a->raw) return fail("nsr_render_bwd: the forward pass must have saved `raw`");
-    if (b->loss_kind != 0 && b->loss_kind != 1) return fail("nsr_render_bwd: unknown loss_kind");
-    if (b->loss_kind == 0 && !b->d_depth && !b->d_var && !b->d_rgb) return fail("nsr_render_bwd: no output gradient given");
-    if (b->loss_kind == 1 && (!a->rgb || (a->stage == NSR_STAGE_COLOR && !a->gt_color)))
-        return fail("nsr_render_bwd: the fused mapping loss needs the forward's rgb (and gt_color in the colour stage)");
+    if (!b->d_depth && !b->d_var && !b->d_rgb) return fail("nsr_render_bwd: no output gradient given");
     if (!b->depth) return fail("nsr_render_bwd: forward depth is required");
     if ((b->d_rays_o == nullptr) != (b->d_rays_d == nullptr)) return fail("nsr_render_bwd: d_rays_o / d_rays_d must be given together");
     if (P.n_rays == 0) return 0;
     P.d_depth = b->d_depth; P.d_var = b->d_var; P.d_rgb = b->d_rgb; P.g_depth = b->depth;
-    P.loss_kind = b->loss_kind;
     P.d_rays_o = b->d_rays_o; P.d_rays_d = b->d_rays_d;
 #ifdef NSR_TS
     if (const char *e = getenv("NSR_DBG_PTR")) P.dbg = reinterpret_cast<long long *>(strtoull(e, nullptr, 16));

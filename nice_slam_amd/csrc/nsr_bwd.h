@@ -680,35 +680,12 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
         F4 c_rw = F4{0.f, 0.f, 0.f, 0.f};
         double c_gD = 0.0, c_gV = 0.0, c_dep = 0.0;
         float c_gr = 0.f, c_gg = 0.f, c_gb = 0.f;
-        // gradient of the caller's loss w.r.t. the outputs of one ray: handed in (autograd), or -- fused mapping loss,
-        // Mapper.py:487-493 -- formed here from the forward results: d|gt - depth| = sign(depth - gt) on rays with gt > 0,
-        // w_color * sign(rgb - gt_rgb) in the colour stage, both only on rays the bounding-box pre-filter keeps
-        auto load_dout = [&](long long ray, double &gD, double &gV, float &gr, float &gg, float &gb, double &dep) {
-            dep = P.g_depth[ray];
-            if (P.loss_kind == 1) {
-                const bool kp = !P.keep || P.keep[ray];
-                const float gd = P.gt_depth ? P.gt_depth[ray] : 0.f;
-                const double df = dep - (double)gd;
-                gD = (kp && gd > 0.f) ? (df > 0.0 ? 1.0 : (df < 0.0 ? -1.0 : 0.0)) : 0.0;
-                gV = 0.0;
-                gr = gg = gb = 0.f;
-                if (P.stage == NSR_STAGE_COLOR && P.gt_color && kp) {
-                    const float e0 = P.rgb[ray * 3 + 0] - P.gt_color[ray * 3 + 0], e1 = P.rgb[ray * 3 + 1] - P.gt_color[ray * 3 + 1],
-                                e2 = P.rgb[ray * 3 + 2] - P.gt_color[ray * 3 + 2];
-                    gr = e0 > 0.f ? P.w_color : (e0 < 0.f ? -P.w_color : 0.f);
-                    gg = e1 > 0.f ? P.w_color : (e1 < 0.f ? -P.w_color : 0.f);
-                    gb = e2 > 0.f ? P.w_color : (e2 < 0.f ? -P.w_color : 0.f);
-                }
-            } else {
-                gD = P.d_depth ? P.d_depth[ray] : 0.0;
-                gV = P.d_var ? P.d_var[ray] : 0.0;
-                gr = gg = gb = 0.f;
-                if (P.d_rgb) { gr = P.d_rgb[ray * 3 + 0]; gg = P.d_rgb[ray * 3 + 1]; gb = P.d_rgb[ray * 3 + 2]; }
-            }
-        };
         if (c_ok) {
             if (c_act) c_rw = ld4(P.raw + (cray * S + lane) * 4);
-            load_dout(cray, c_gD, c_gV, c_gr, c_gg, c_gb, c_dep);
+            if (P.d_depth) c_gD = P.d_depth[cray];
+            if (P.d_var) c_gV = P.d_var[cray];
+            if (P.d_rgb) { c_gr = P.d_rgb[cray * 3 + 0]; c_gg = P.d_rgb[cray * 3 + 1]; c_gb = P.d_rgb[cray * 3 + 2]; }
+            c_dep = P.g_depth[cray];
         }
 #ifdef NSR_X_EARLYWAIT
         if (has_ray) rayb[t0] = ray_v;
@@ -750,7 +727,11 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
             float gr = c_gr, gg = c_gg, gb = c_gb;
             if (r != wave) {                                    // further rays of this wave (more rays than waves per group)
                 rw = act ? ld4(P.raw + (ray * S + lane) * 4) : F4{0.f, 0.f, 0.f, 0.f};
-                load_dout(ray, gD, gV, gr, gg, gb, dep);
+                gD = P.d_depth ? P.d_depth[ray] : 0.0;
+                gV = P.d_var ? P.d_var[ray] : 0.0;
+                gr = gg = gb = 0.f;
+                if (P.d_rgb) { gr = P.d_rgb[ray * 3 + 0]; gg = P.d_rgb[ray * 3 + 1]; gb = P.d_rgb[ray * 3 + 2]; }
+                dep = P.g_depth[ray];
             }
             const double z = act ? zbuf[r * S + lane] : 0.0;
             const Comp cw = comp_weights(rw.w, act, lane);

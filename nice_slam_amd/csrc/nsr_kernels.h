@@ -79,8 +79,9 @@ struct RenderParams {
     const float *gt_color;    // [N][3]
     const unsigned char *keep; // [N] bounding-box mask of the callers' pre-filter, or NULL (all rays count)
     double *loss;             // forward: += sum over rays of the loss terms
+    double *dl_depth;         // forward: d loss / d depth per ray  [N]      (handed to the backward as d_depth / d_rgb)
+    float *dl_rgb;            // forward: d loss / d rgb per ray    [N][3]
     float w_color;            // weight of the colour term (colour stage only)
-    int loss_kind;            // backward: 1 = d outputs are those of the mapping loss, computed here from the forward results
     long long *dbg;           // profiling stamps (NSR_TS builds only), else NULL
     // eval_points only
     const double *points;
@@ -804,12 +805,26 @@ NSR_KERNEL NSR_BOUNDS(768) void render_fwd_kernel(const RenderParams P) {
                 P.depth[rayq] = depth;
                 P.var[rayq] = var;
                 P.rgb[rayq * 3 + 0] = cr; P.rgb[rayq * 3 + 1] = cg; P.rgb[rayq * 3 + 2] = cb;
-                if (P.loss && (!P.keep || P.keep[rayq])) {      // Mapper.py:487-493 on the rays the pre-filter keeps
+                if (P.loss) {
+                    // Mapper.py:487-493 on the rays the pre-filter keeps, and its derivative w.r.t. this ray's outputs:
+                    // d|gt - depth| = sign(depth - gt) where gt > 0, w_color * sign(rgb - gt_rgb) in the colour stage
+                    const bool kp = !P.keep || P.keep[rayq];
                     const float gd = P.gt_depth ? P.gt_depth[rayq] : 0.f;
-                    if (gd > 0.f) loss_acc += fabs((double)gd - depth);
-                    if (STAGE == NSR_STAGE_COLOR && P.gt_color)
-                        loss_acc += (double)(P.w_color * ((fabsf(P.gt_color[rayq * 3 + 0] - cr) + fabsf(P.gt_color[rayq * 3 + 1] - cg)) +
-                                                          fabsf(P.gt_color[rayq * 3 + 2] - cb)));
+                    double gD = 0.0;
+                    float g3[3] = {0.f, 0.f, 0.f};
+                    if (kp && gd > 0.f) {
+                        const double df = depth - (double)gd;
+                        loss_acc += fabs(df);
+                        gD = df > 0.0 ? 1.0 : (df < 0.0 ? -1.0 : 0.0);
+                    }
+                    if (kp && STAGE == NSR_STAGE_COLOR && P.gt_color) {
+                        const float e[3] = {cr - P.gt_color[rayq * 3 + 0], cg - P.gt_color[rayq * 3 + 1], cb - P.gt_color[rayq * 3 + 2]};
+                        loss_acc += (double)(P.w_color * ((fabsf(e[0]) + fabsf(e[1])) + fabsf(e[2])));
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) g3[q] = e[q] > 0.f ? P.w_color : (e[q] < 0.f ? -P.w_color : 0.f);
+                    }
+                    if (P.dl_depth) P.dl_depth[rayq] = gD;
+                    if (P.dl_rgb) { P.dl_rgb[rayq * 3 + 0] = g3[0]; P.dl_rgb[rayq * 3 + 1] = g3[1]; P.dl_rgb[rayq * 3 + 2] = g3[2]; }
                 }
             }
         }

@@ -94,3 +94,22 @@ def test_ctypes_struct_fields_follow_the_header():
                 if m:
                     names.append(m.group(1))
         assert names == [f[0] for f in ctype._fields_], cname
+
+
+def test_kernel_register_budget():
+    """The backward kernels hold every parameter-gradient accumulator in registers (one wave per SIMD, 256 VGPR + 256 AGPR);
+    the build records what the compiler made of it.  A change that tips them into heavy scratch use is a 1.5x slowdown that
+    no numerical test notices -- it shows up here."""
+    import json
+    import os
+    from nice_slam_amd import build
+    if not os.path.exists(build.RESOURCES):
+        pytest.skip("libnsr.resources.json not present (library built by an older build.py)")
+    res = json.load(open(build.RESOURCES))
+    bwd = {k: v for k, v in res.items() if "render_bwd_kernel" in k}
+    fwd = {k: v for k, v in res.items() if "render_fwd_kernel" in k or "eval_points_kernel" in k}
+    assert len(bwd) == 4 and len(fwd) == 8
+    for k, v in bwd.items():
+        assert v["occupancy_waves_per_simd"] == 1 and v["scratch_bytes_per_lane"] <= 1024, (k, v)
+    for k, v in fwd.items():
+        assert v["occupancy_waves_per_simd"] >= 3 and v["scratch_bytes_per_lane"] <= 64, (k, v)
