@@ -161,10 +161,11 @@ int nsr_get_samples_window(const int64_t *indices, int32_t K, int64_t n, int32_t
                            float *rays_o, float *rays_d, float *out_depth, float *out_color,
                            const double *bound_lo, const double *bound_hi, uint8_t *keep, float *kept_max, void *stream);
 /* gradient of the K poses from the ray gradients of such a window (autograd of src/common.py:74-88; local BA,
- * src/Mapper.py:417-419,441-453): d_c2w [K][12] = rows 0..2 of each pose, row-major. */
+ * src/Mapper.py:417-419,441-453): d_c2w + k * out_stride holds rows 0..2 of pose k's gradient, row-major (12 floats;
+ * out_stride = 12 for 3x4 poses, 16 for 4x4 ones whose last row the caller zero-fills). */
 int nsr_pose_grad(const int64_t *indices, int32_t K, int64_t n, int32_t H0, int32_t H1, int32_t W0, int32_t W1,
                   float fx, float fy, float cx, float cy, const float *d_rays_o, const float *d_rays_d,
-                  float *d_c2w, void *stream);
+                  float *d_c2w, int32_t out_stride, void *stream);
 
 /* --- the per-iteration grid update of Mapper.optimize_map, fused ---------------------------------
  * Replaces, for one feature grid, `val[mask] = val_grad` (src/Mapper.py:394-401), the Adam step on the masked leaf

@@ -358,15 +358,15 @@ int nsr_get_samples_window(const int64_t *indices, int32_t K, int64_t n, int32_t
 
 int nsr_pose_grad(const int64_t *indices, int32_t K, int64_t n, int32_t H0, int32_t H1, int32_t W0, int32_t W1,
                   float fx, float fy, float cx, float cy, const float *d_rays_o, const float *d_rays_d,
-                  float *d_c2w, void *stream) {
-    if (K < 0 || n < 0 || H1 <= H0 || W1 <= W0) return fail("nsr_pose_grad: bad arguments");
+                  float *d_c2w, int32_t out_stride, void *stream) {
+    if (K < 0 || n < 0 || H1 <= H0 || W1 <= W0 || out_stride < 12) return fail("nsr_pose_grad: bad arguments");
     if (K == 0) return 0;
     if (!indices || !d_rays_o || !d_rays_d || !d_c2w) return fail("nsr_pose_grad: null pointer");
     nsr::PoseGradParams P;
     P.indices = reinterpret_cast<const long long *>(indices);
     P.n = n; P.H0 = H0; P.W0 = W0; P.crop_w = W1 - W0;
     P.fx = fx; P.fy = fy; P.cx = cx; P.cy = cy;
-    P.d_rays_o = d_rays_o; P.d_rays_d = d_rays_d; P.out = d_c2w;
+    P.d_rays_o = d_rays_o; P.d_rays_d = d_rays_d; P.out = d_c2w; P.out_stride = out_stride;
     const int tb = 256;
     NSR_LAUNCH(nsr::pose_grad_kernel, dim3((unsigned)K), dim3(tb), 12 * tb * sizeof(float), stream, P);
     return finish("nsr_pose_grad");

@@ -1069,6 +1069,7 @@ struct PoseGradParams {
     float fx, fy, cx, cy;
     const float *d_rays_o, *d_rays_d;
     float *out;
+    int out_stride;
 };
 NSR_KERNEL void pose_grad_kernel(const PoseGradParams P) {
     float *red = reinterpret_cast<float *>(lds_base());          // [12][nthreads]
@@ -1096,7 +1097,7 @@ NSR_KERNEL void pose_grad_kernel(const PoseGradParams P) {
     if (tid() < 12) {
         float s = 0.f;
         for (int j = 0; j < nt; ++j) s += red[tid() * nt + j];
-        P.out[k * 12 + tid()] = s;
+        P.out[k * P.out_stride + tid()] = s;
     }
 }
 

@@ -1,0 +1,230 @@
+"""The mapper's iteration as three launches (src/Mapper.py:437-503).
+
+The reference's mapping iteration is: ``get_samples`` per keyframe of the window + ``torch.cat`` (Mapper.py:437-468), the
+bounding-box pre-filter (:471-481), ``render_batch_ray`` (:482), the L1 losses (:487-493) and ``loss.backward()`` (:503) --
+about forty small ATen launches around two big kernels.  Here:
+
+* ``get_samples_window``  : all frames of the window in ONE kernel (rays, depth / colour gathers, the pre-filter as a byte
+  mask, the kept rays' maximum depth), differentiable w.r.t. the poses (local BA) through ``nsr_pose_grad``;
+* ``mapping_loss``        : sampling + render + loss as one autograd node.  The forward kernel accumulates the loss and
+  writes its derivative w.r.t. every ray's outputs, so the loss and its backward add no launch; the backward is the one
+  render-backward launch (+ the partial-sum kernel) writing dense grid gradients, the decoder-gradient blob and -- with BA --
+  the pose gradients.
+
+Same numbers as the unfused path (tests/test_hip_mapping.py); per iteration: the index draw, one zero-fill, the window kernel,
+render forward, render backward, the partial sum.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _capi
+from .common import _as_f32c, _require_cuda, _stream
+from .layout import param_count, stage_slots
+from .renderer import _SLOT_IDX, _fill_common, _gate, _prep_grids, render_backward
+
+
+class WindowSamples:
+    """Rays of one mapping iteration: the concatenation over the window's frames (frame-major, like ``torch.cat``)."""
+    __slots__ = ("rays_o", "rays_d", "gt_depth", "gt_color", "keep", "kept_max", "indices", "geom")
+
+
+def _frames_block(c2ws, depths, colors, dev):
+    K = len(depths)
+    fr = (_capi.NsrFrame * K)()
+    hold = []
+    for k in range(K):
+        d = _as_f32c(depths[k], dev)
+        col = _as_f32c(colors[k], dev)
+        p = _as_f32c(c2ws[k].detach(), dev)
+        hold += [d, col, p]
+        fr[k].depth, fr[k].color, fr[k].c2w, fr[k].c2w_stride = d.data_ptr(), col.data_ptr(), p.data_ptr(), p.stride(0)
+    return fr, hold
+
+
+def _bound_arrays(bound):
+    lo = (C.c_double * 3)(*[float(bound[a][0]) for a in range(3)])
+    hi = (C.c_double * 3)(*[float(bound[a][1]) for a in range(3)])
+    return lo, hi
+
+
+def _launch_window(indices, K, n, crop, intr, frames, bound6, sbuf, keep, kmax_ptr, dev):
+    lib = _capi.get_lib()
+    H0, H1, W0, W1, W_full = crop
+    fx, fy, cx, cy = intr
+    N = K * n
+    lib.check(lib.nsr_get_samples_window(indices.data_ptr(), K, n, H0, H1, W0, W1, W_full, fx, fy, cx, cy, frames,
+                                         sbuf.data_ptr(), sbuf.data_ptr() + 12 * N, sbuf.data_ptr() + 24 * N, sbuf.data_ptr() + 28 * N,
+                                         bound6[0], bound6[1], keep.data_ptr(), kmax_ptr, _stream(dev)), "nsr_get_samples_window")
+
+
+class _WindowFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, meta, *c2ws):
+        indices, K, n, crop, intr, depths, colors, bound, dev = meta
+        N = K * n
+        frames, hold = _frames_block(c2ws, depths, colors, dev)
+        sbuf = torch.empty((10 * N + (N + 3) // 4,), dtype=torch.float32, device=dev)      # o | d | depth | colour | keep bytes
+        keep = sbuf[10 * N:].view(torch.uint8)[:N]
+        kmax = torch.zeros((1,), dtype=torch.float32, device=dev)
+        _launch_window(indices, K, n, crop, intr, frames, _bound_arrays(bound), sbuf, keep, kmax.data_ptr(), dev)
+        ctx.meta = (indices, K, n, crop, intr, [tuple(c.shape) for c in c2ws], [c.dtype for c in c2ws], [c.device for c in c2ws])
+        outs = (sbuf[:3 * N].view(N, 3), sbuf[3 * N:6 * N].view(N, 3), sbuf[6 * N:7 * N], sbuf[7 * N:10 * N].view(N, 3), keep, kmax)
+        ctx.mark_non_differentiable(*outs[2:])
+        return outs
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_o, g_d, *_):
+        indices, K, n, crop, intr, shapes, dtypes, devs = ctx.meta
+        grads = pose_grads(indices, K, n, crop, intr, g_o.contiguous(), g_d.contiguous(), shapes)
+        return (None, *[g.to(device=dv, dtype=dt) for g, dv, dt in zip(grads, devs, dtypes)])
+
+
+def pose_grads(indices, K, n, crop, intr, g_o, g_d, shapes) -> List[torch.Tensor]:
+    """d c2w[k] (shape of the pose, rows 0..2 filled) from the gradients of the window's rays: one launch."""
+    lib = _capi.get_lib()
+    dev = g_o.device
+    H0, H1, W0, W1, _ = crop
+    fx, fy, cx, cy = intr
+    out = torch.zeros((K, 4, 4), dtype=torch.float32, device=dev)
+    lib.check(lib.nsr_pose_grad(indices.data_ptr(), K, n, H0, H1, W0, W1, fx, fy, cx, cy, g_o.data_ptr(), g_d.data_ptr(),
+                                out.data_ptr(), 16, _stream(dev)), "nsr_pose_grad")
+    return [out[k, :shp[0], :] for k, shp in enumerate(shapes)]
+
+
+def _window_meta(H0, H1, W0, W1, n, W, fx, fy, cx, cy, c2ws, depths, colors, bound, device, indices):
+    K = len(depths)
+    dev = torch.device(device)
+    if indices is None:
+        indices = torch.randint((H1 - H0) * (W1 - W0), (K * n,), device=dev)      # one draw for the window (common.py:99 per frame)
+    else:
+        indices = indices.to(dev).reshape(-1).contiguous()
+    c2ws = [c if isinstance(c, torch.Tensor) else torch.as_tensor(c) for c in c2ws]
+    crop = (int(H0), int(H1), int(W0), int(W1), int(W))
+    intr = (float(fx), float(fy), float(cx), float(cy))
+    return (indices, K, int(n), crop, intr, list(depths), list(colors), bound, dev), c2ws
+
+
+def get_samples_window(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, c2ws: Sequence[torch.Tensor], depths: Sequence[torch.Tensor],
+                       colors: Sequence[torch.Tensor], bound, device, indices: Optional[torch.Tensor] = None) -> WindowSamples:
+    """``n`` pixels from each of the K frames (pose ``c2ws[k]``: 3x4 or 4x4, may require grad; ``depths[k]`` [H,W],
+    ``colors[k]`` [H,W,3] on the device), concatenated in frame order -- the sampling loop of Mapper.py:437-468 -- plus the
+    bounding-box pre-filter of :471-481 as ``keep`` (bool per ray) and ``kept_max`` (1-element tensor: maximum depth over
+    the kept rays, to be passed as ``render_batch_ray(..., gt_max=kept_max)``).  ``indices``: optional [K*n] flat crop
+    indices (default: one ``torch.randint`` draw)."""
+    meta, c2ws = _window_meta(H0, H1, W0, W1, n, W, fx, fy, cx, cy, c2ws, depths, colors, bound, device, indices)
+    _require_cuda(depths[0] if depths[0].is_cuda else torch.empty(0, device=meta[-1]), "get_samples_window: frames")
+    ro, rd, gd, gc, keep, kmax = _WindowFn.apply(meta, *c2ws)
+    w = WindowSamples()
+    w.rays_o, w.rays_d, w.gt_depth, w.gt_color, w.keep, w.kept_max, w.indices, w.geom = ro, rd, gd, gc, keep.bool(), kmax, meta[0], meta[1:5]
+    return w
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# sampling + render + mapping loss as one autograd node
+# --------------------------------------------------------------------------------------------------------------------
+class _MappingLossFn(torch.autograd.Function):
+    """inputs: K poses, one grid per decoder of the stage, one gate per decoder (see renderer._RenderFn)."""
+
+    @staticmethod
+    def forward(ctx, meta, *tensors):
+        renderer, decoders, stage, wmeta, w_color, coarse, out = meta
+        indices, K, n, crop, intr, depths, colors, bound, dev = wmeta
+        lib = _capi.get_lib()
+        slots = stage_slots(stage)
+        c2ws = tensors[:K]
+        grids = dict(zip(slots, tensors[K:K + len(slots)]))
+        stream = _stream(dev)
+        N = K * n
+        guided = stage != "coarse" and not coarse
+        S = renderer.N_samples + (renderer.N_surface if guided else 0)
+        need_pose = any(ctx.needs_input_grad[1:1 + K])
+        need_grid = ctx.needs_input_grad[1 + K:1 + K + len(slots)]
+        need_par = ctx.needs_input_grad[1 + K + len(slots):1 + K + 2 * len(slots)]
+        need_bwd = need_pose or any(need_grid) or any(need_par)
+        # ONE zero-filled buffer: loss (fp64) | kept_max | pad | every gradient of the backward (renderer.render_backward)
+        n_grad = 0
+        if need_bwd:
+            n_grad = sum(grids[s].numel() for s, nd in zip(slots, need_grid) if nd) + (6 * N if need_pose else 0) + \
+                sum(param_count(s) for s, nd in zip(slots, need_par) if nd)
+        Z = torch.zeros((4 + n_grad,), dtype=torch.float32, device=dev)
+        loss = Z[:2].view(torch.float64)
+        kmax = Z[2:3]
+        frames, hold = _frames_block(c2ws, depths, colors, dev)
+        sbuf = torch.empty((10 * N + (N + 3) // 4,), dtype=torch.float32, device=dev)
+        keep = sbuf[10 * N:].view(torch.uint8)[:N]
+        _launch_window(indices, K, n, crop, intr, frames, _bound_arrays(bound), sbuf, keep, kmax.data_ptr(), dev)
+        rays_o, rays_d = sbuf[:3 * N].view(N, 3), sbuf[3 * N:6 * N].view(N, 3)
+        gt_depth, gt_color = sbuf[6 * N:7 * N], sbuf[7 * N:10 * N].view(N, 3)
+        # forward results in ONE buffer: depth | var | dl_depth | zvals (fp64), then raw | rgb | dl_rgb (fp32)
+        n64 = 3 * N + N * S
+        F = torch.empty((n64 + (N * S * 4 + 6 * N + 1) // 2,), dtype=torch.float64, device=dev)
+        f32 = F[n64:].view(torch.float32)
+        depth, var, dl_depth, zvals = F[:N], F[N:2 * N], F[2 * N:3 * N], F[3 * N:n64].view(N, S)
+        raw, rgb, dl_rgb = f32[:N * S * 4].view(N, S, 4), f32[N * S * 4:N * S * 4 + 3 * N].view(N, 3), f32[N * S * 4 + 3 * N:N * S * 4 + 6 * N].view(N, 3)
+        flats = {s: decoders.sub(s).flat_params() for s in slots}
+        packed = {s: decoders.sub(s).packed_params(lib, stream) for s in slots}
+        a = _capi.NsrRenderArgs.from_buffer_copy(renderer._arg_template)
+        a.n_samples, a.n_surface, a.n_rays = renderer.N_samples, renderer.N_surface, N
+        a.rays_o, a.rays_d = rays_o.data_ptr(), rays_d.data_ptr()
+        a.gt_depth, a.gt_max = gt_depth.data_ptr(), kmax.data_ptr()
+        _fill_common(a, stage, renderer.bound, decoders, grids, packed, flats)
+        if not guided:
+            a.n_surface = 0
+        a.depth, a.var, a.rgb, a.raw, a.zvals = depth.data_ptr(), var.data_ptr(), rgb.data_ptr(), raw.data_ptr(), zvals.data_ptr()
+        a.gt_color, a.keep, a.loss, a.w_color = gt_color.data_ptr(), keep.data_ptr(), loss.data_ptr(), float(w_color)
+        a.dl_depth, a.dl_rgb = dl_depth.data_ptr(), dl_rgb.data_ptr()
+        lib.check(lib.nsr_render_fwd(C.byref(a), stream), "nsr_render_fwd")
+        if out is not None:
+            out.update(rays_o=rays_o, rays_d=rays_d, gt_depth=gt_depth, gt_color=gt_color, keep=keep, kept_max=kmax, depth=depth,
+                       uncertainty=var, color=rgb, indices=indices)
+        if need_bwd:
+            ctx.state = (a, (renderer, decoders, stage, S, renderer._reduce_hook),
+                         ([kmax, F, sbuf, Z, hold], rays_o, rays_d, gt_depth, grids, flats, packed, raw, depth),
+                         (need_pose, need_grid, need_par), dl_depth, dl_rgb if stage == "color" else None, Z[4:],
+                         (indices, K, n, crop, intr, [tuple(c.shape) for c in c2ws], [c.dtype for c in c2ws], [c.device for c in c2ws]))
+        return loss[0]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_loss):
+        a, meta, kept, (need_pose, need_grid, need_par), dl_depth, dl_rgb, zero_buf, wm = ctx.state
+        # the loss is the root of the caller's graph (loss.backward(), Mapper.py:503): its incoming gradient is 1
+        d_o, d_d, d_grids = render_backward(a, meta, kept, (need_pose, need_pose, need_grid, need_par), dl_depth, None, dl_rgb,
+                                            zero_buf=zero_buf)
+        indices, K, n, crop, intr, shapes, dtypes, devs = wm
+        g_pose = [None] * K
+        if need_pose:
+            gp = pose_grads(indices, K, n, crop, intr, d_o, d_d, shapes)
+            g_pose = [g.to(device=dv, dtype=dt) if nd else None for g, dv, dt, nd in zip(gp, devs, dtypes, ctx.needs_input_grad[1:1 + K])]
+        ctx.state = None
+        nslots = len(d_grids)
+        return (None, *g_pose, *d_grids, *([None] * nslots))
+
+
+def mapping_loss(renderer, c, decoders, frames: Sequence[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], pixs_per_image: int,
+                 stage: str, w_color: float = 0.2, device=None, indices: Optional[torch.Tensor] = None, coarse_mapper: bool = False,
+                 crop: Optional[Tuple[int, int, int, int]] = None, out: Optional[dict] = None) -> torch.Tensor:
+    """One mapping iteration's loss (src/Mapper.py:437-493) as a single autograd node.
+
+    ``frames``: ``(c2w, depth [H,W], color [H,W,3])`` per frame of the window, in the reference's order; a pose that requires
+    grad gets its gradient (local BA).  Samples ``pixs_per_image`` pixels per frame, applies the bounding-box pre-filter as a
+    mask, renders ``stage`` and returns ``sum_{kept, gt>0} |gt - depth| (+ w_color * sum_kept |gt_rgb - rgb|`` in the colour
+    stage) as an fp64 scalar -- call ``.backward()`` on it directly (it must be the root of the backward pass).
+    ``out`` (optional dict) receives the sampled rays, masks and rendered outputs."""
+    if coarse_mapper or stage == "coarse":
+        raise NotImplementedError("the coarse mapper renders unguided (gt_depth=None): use get_samples_window + render_batch_ray")
+    dev = torch.device(device) if device is not None else frames[0][1].device
+    H0, H1, W0, W1 = crop if crop is not None else (0, renderer.H, 0, renderer.W)
+    wmeta, c2ws = _window_meta(H0, H1, W0, W1, pixs_per_image, renderer.W, renderer.fx, renderer.fy, renderer.cx, renderer.cy,
+                               [f[0] for f in frames], [f[1] for f in frames], [f[2] for f in frames], renderer.bound, dev, indices)
+    slots = stage_slots(stage)
+    grids = _prep_grids(c, stage, dev)
+    gates = [_gate(dev, torch.is_grad_enabled() and decoders.sub(s).wants_grad() and
+                   (renderer.decoder_grads is None or s in renderer.decoder_grads)) for s in slots]
+    meta = (renderer, decoders, stage, wmeta, w_color, False, out)
+    return _MappingLossFn.apply(meta, *c2ws, *[grids[s] for s in slots], *gates)

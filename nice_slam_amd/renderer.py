@@ -148,105 +148,119 @@ class _RenderFn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_depth, g_var, g_rgb):
-        lib = _capi.get_lib()
-        renderer, decoders, stage, S, reduce_hook = ctx.meta
-        keep, rays_o, rays_d, gt_depth, grids, flats, packed, raw, depth = ctx.keep
-        a = ctx.args
-        slots = stage_slots(stage)
-        dev = rays_o.device
-        stream = _stream(dev)
-        n = rays_o.shape[0]
-        need_o, need_d = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
-        need_grid = ctx.needs_input_grad[3:3 + len(slots)]
-        need_par = ctx.needs_input_grad[3 + len(slots):3 + 2 * len(slots)]
-        b = _capi.NsrBwdArgs()
+        slots = stage_slots(ctx.meta[2])
+        need = (ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3:3 + len(slots)],
+                ctx.needs_input_grad[3 + len(slots):3 + 2 * len(slots)])
         g_depth = g_depth.to(torch.float64).contiguous()
         g_var = g_var.to(torch.float64).contiguous()
         g_rgb = g_rgb.to(torch.float32).contiguous()
-        b.d_depth, b.d_var, b.d_rgb, b.depth = g_depth.data_ptr(), g_var.data_ptr(), g_rgb.data_ptr(), depth.data_ptr()
-        # every gradient this call produces lives in ONE zero-filled buffer (a single fill kernel): channels-last views for
-        # the dense grid gradients, then the ray gradients, then the flat decoder-gradient blob
-        need_ray = need_o or need_d
-        n_grid = [grids[s].numel() if need else 0 for s, need in zip(slots, need_grid)]
-        # decoder gradients: straight into each decoder's persistent blob when possible (see _FlatDecoder.grad_target);
-        # the multi-GPU path and foreign .grad tensors use a temporary blob inside the fused buffer
-        direct = {}
-        if reduce_hook is None:
-            for s, need in zip(slots, need_par):
-                if need:
-                    tgt, mode = decoders.sub(s).grad_target()
-                    if tgt is not None:
-                        direct[s] = (tgt, mode)
-            modes = {m for _, m in direct.values()}
-            if len(modes) > 1:                                    # mixed: make everything "accumulate"
-                for s, (tgt, mode) in list(direct.items()):
-                    if mode == "overwrite":
-                        tgt.zero_()
-            b.overwrite_dparams = 1 if modes == {"overwrite"} else 0
-        n_par = [param_count(s) if (need and s not in direct) else 0 for s, need in zip(slots, need_par)]
-        buf = torch.zeros((sum(n_grid) + (6 * n if need_ray else 0) + sum(n_par),), dtype=torch.float32, device=dev)
-        off = 0
-        d_grids = []
-        for s, cnt in zip(slots, n_grid):
-            i = _SLOT_IDX[s]
-            if cnt:
-                _, ch, Z, Y, X = grids[s].shape
-                dg = buf[off:off + cnt].view(1, Z, Y, X, ch).permute(0, 4, 1, 2, 3)      # [1,C,Z,Y,X], channels-last strides
-                off += cnt
-                a.grid[i].dfeat = dg.data_ptr()
-                d_grids.append(dg)
-            else:
-                a.grid[i].dfeat = None
-                d_grids.append(None)
-        d_o = d_d = None
-        if need_ray:
-            d_od = buf[off:off + 6 * n].view(2, n, 3)
-            off += 6 * n
-            d_o, d_d = d_od[0], d_od[1]
-            b.d_rays_o, b.d_rays_d = d_o.data_ptr(), d_d.data_ptr()
-        gflat = None
-        offs = {}
-        if any(need_par):
-            if sum(n_par):
-                gflat = buf[off:off + sum(n_par)]
-            poff = 0
-            for s, cnt, need in zip(slots, n_par, need_par):
-                i = _SLOT_IDX[s]
-                if s in direct:
-                    a.dec[i].dparams = direct[s][0].data_ptr()
-                elif cnt:
-                    offs[s] = poff
-                    a.dec[i].dparams = gflat.data_ptr() + 4 * poff
-                    poff += cnt
-                else:
-                    a.dec[i].dparams = None
-            nws = lib.nsr_bwd_workspace_floats(_capi.STAGE_ID[stage], n, S, renderer.bwd_max_blocks)
-            ws = renderer._workspace(nws, dev)
-            b.workspace, b.workspace_floats = ws.data_ptr(), nws
-        else:
-            for s in slots:
-                a.dec[_SLOT_IDX[s]].dparams = None
-        b.max_blocks = renderer.bwd_max_blocks
-        if renderer.profile_events is not None:           # bench.py: hipEvent pair around the main backward kernel
-            b.ev_start, b.ev_stop = renderer.profile_events(stage)
-        lib.check(lib.nsr_render_bwd(C.byref(a), C.byref(b), stream), "nsr_render_bwd")
-        def publish():
-            for s, need in zip(slots, need_par):
-                if need:
-                    if s in direct:
-                        decoders.sub(s).grad_done(direct[s][1])
-                    else:
-                        decoders.sub(s).publish_grads(gflat[offs[s]:offs[s] + param_count(s)])
-
-        # multi-GPU (parallel.py): the hook sums the shard gradients.  It may DEFER the decoder blob (to let it ride in the
-        # same collective as the grid rows, which autograd hands over a moment later); the `.grad` tensors are then
-        # published by the hook after that exchange -- never before, or an accumulation into pre-existing `.grad`s would
-        # consume rank-local values
-        deferred = reduce_hook is not None and bool(reduce_hook([g for g in d_grids if g is not None], gflat, publish))
-        if not deferred:
-            publish()
+        d_o, d_d, d_grids = render_backward(ctx.args, ctx.meta, ctx.keep, need, g_depth, g_var, g_rgb)
         ctx.keep = ctx.args = None
-        return (None, d_o if need_o else None, d_d if need_d else None, *d_grids, *([None] * len(slots)))
+        return (None, d_o, d_d, *d_grids, *([None] * len(slots)))
+
+
+def render_backward(a, meta, kept, need, g_depth, g_var, g_rgb, zero_buf=None):
+    """The backward launch of one render call (shared by ``_RenderFn`` and the fused mapping loss, mapping.py).
+    ``a``: the forward's argument block; ``need`` = (rays_o, rays_d, per-grid, per-decoder) gradient requests;
+    ``g_*``: gradients of the outputs (contiguous, fp64 / fp64 / fp32) or None; ``zero_buf``: an already zero-filled fp32
+    buffer of the size ``backward_buffer_floats`` returns (saves the fill launch).  -> (d_rays_o, d_rays_d, [d_grid ...])."""
+    lib = _capi.get_lib()
+    renderer, decoders, stage, S, reduce_hook = meta
+    keep, rays_o, rays_d, gt_depth, grids, flats, packed, raw, depth = kept
+    slots = stage_slots(stage)
+    dev = rays_o.device
+    stream = _stream(dev)
+    n = rays_o.shape[0]
+    need_o, need_d, need_grid, need_par = need
+    b = _capi.NsrBwdArgs()
+    b.d_depth = g_depth.data_ptr() if g_depth is not None else None
+    b.d_var = g_var.data_ptr() if g_var is not None else None
+    b.d_rgb = g_rgb.data_ptr() if g_rgb is not None else None
+    b.depth = depth.data_ptr()
+    # every gradient this call produces lives in ONE zero-filled buffer (a single fill kernel): channels-last views for
+    # the dense grid gradients, then the ray gradients, then the flat decoder-gradient blob
+    need_ray = need_o or need_d
+    n_grid = [grids[s].numel() if nd else 0 for s, nd in zip(slots, need_grid)]
+    # decoder gradients: straight into each decoder's persistent blob when possible (see _FlatDecoder.grad_target);
+    # the multi-GPU path and foreign .grad tensors use a temporary blob inside the fused buffer
+    direct = {}
+    if reduce_hook is None:
+        for s, nd in zip(slots, need_par):
+            if nd:
+                tgt, mode = decoders.sub(s).grad_target()
+                if tgt is not None:
+                    direct[s] = (tgt, mode)
+        modes = {m for _, m in direct.values()}
+        if len(modes) > 1:                                    # mixed: make everything "accumulate"
+            for s, (tgt, mode) in list(direct.items()):
+                if mode == "overwrite":
+                    tgt.zero_()
+        b.overwrite_dparams = 1 if modes == {"overwrite"} else 0
+    n_par = [param_count(s) if (nd and s not in direct) else 0 for s, nd in zip(slots, need_par)]
+    total = sum(n_grid) + (6 * n if need_ray else 0) + sum(n_par)
+    buf = zero_buf if (zero_buf is not None and zero_buf.numel() >= total) else torch.zeros((total,), dtype=torch.float32, device=dev)
+    off = 0
+    d_grids = []
+    for s, cnt in zip(slots, n_grid):
+        i = _SLOT_IDX[s]
+        if cnt:
+            _, ch, Z, Y, X = grids[s].shape
+            dg = buf[off:off + cnt].view(1, Z, Y, X, ch).permute(0, 4, 1, 2, 3)      # [1,C,Z,Y,X], channels-last strides
+            off += cnt
+            a.grid[i].dfeat = dg.data_ptr()
+            d_grids.append(dg)
+        else:
+            a.grid[i].dfeat = None
+            d_grids.append(None)
+    d_o = d_d = None
+    if need_ray:
+        d_od = buf[off:off + 6 * n].view(2, n, 3)
+        off += 6 * n
+        d_o, d_d = d_od[0], d_od[1]
+        b.d_rays_o, b.d_rays_d = d_o.data_ptr(), d_d.data_ptr()
+    gflat = None
+    offs = {}
+    if any(need_par):
+        if sum(n_par):
+            gflat = buf[off:off + sum(n_par)]
+        poff = 0
+        for s, cnt, nd in zip(slots, n_par, need_par):
+            i = _SLOT_IDX[s]
+            if s in direct:
+                a.dec[i].dparams = direct[s][0].data_ptr()
+            elif cnt:
+                offs[s] = poff
+                a.dec[i].dparams = gflat.data_ptr() + 4 * poff
+                poff += cnt
+            else:
+                a.dec[i].dparams = None
+        nws = lib.nsr_bwd_workspace_floats(_capi.STAGE_ID[stage], n, S, renderer.bwd_max_blocks)
+        ws = renderer._workspace(nws, dev)
+        b.workspace, b.workspace_floats = ws.data_ptr(), nws
+    else:
+        for s in slots:
+            a.dec[_SLOT_IDX[s]].dparams = None
+    b.max_blocks = renderer.bwd_max_blocks
+    if renderer.profile_events is not None:           # bench.py: hipEvent pair around the main backward kernel
+        b.ev_start, b.ev_stop = renderer.profile_events(stage)
+    lib.check(lib.nsr_render_bwd(C.byref(a), C.byref(b), stream), "nsr_render_bwd")
+
+    def publish():
+        for s, nd in zip(slots, need_par):
+            if nd:
+                if s in direct:
+                    decoders.sub(s).grad_done(direct[s][1])
+                else:
+                    decoders.sub(s).publish_grads(gflat[offs[s]:offs[s] + param_count(s)])
+
+    # multi-GPU (parallel.py): the hook sums the shard gradients.  It may DEFER the decoder blob (to let it ride in the
+    # same collective as the grid rows, which autograd hands over a moment later); the `.grad` tensors are then
+    # published by the hook after that exchange -- never before, or an accumulation into pre-existing `.grad`s would
+    # consume rank-local values
+    deferred = reduce_hook is not None and bool(reduce_hook([g for g in d_grids if g is not None], gflat, publish))
+    if not deferred:
+        publish()
+    return (d_o if need_o else None, d_d if need_d else None, d_grids)
 
 
 class Renderer(object):

@@ -1,0 +1,181 @@
+"""GPU: the fused mapping iteration (nice_slam_amd/mapping.py, optim.MaskedGridAdam(capturable=True)) against the unfused
+drop-in path it replaces -- which tests/test_hip_parity.py / test_hip_real_callers.py hold to the oracle and to the real
+Mapper.  Window sampling is bit-exact; the fused loss + backward agree with render_batch_ray + torch loss + autograd to the
+noise of the gradient atomics."""
+import numpy as np
+import pytest
+import torch
+
+from scene_util import build_product, make_scene, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _frames(sc, K, dev, grad=False):
+    g = torch.Generator().manual_seed(17)
+    H, W = sc["intr"][:2]
+    out = []
+    for k in range(K):
+        c2w = sc["c2w"].clone()
+        c2w[:3, 3] += 0.02 * k
+        depth = (sc["depth_img"] * (1.0 + 0.03 * k)).to(dev)
+        color = torch.rand((H, W, 3), generator=g).to(dev)
+        c2w = c2w[:3].contiguous().to(dev) if k % 2 else c2w.to(dev)        # 3x4 and 4x4 poses mixed, like the reference
+        out.append((c2w.requires_grad_(grad), depth, color))
+    return out
+
+
+def test_window_sampling_is_the_per_frame_loop():
+    import nice_slam_amd as nsa
+    from nice_slam_amd.common import samples_from_indices
+    sc = make_scene(seed=81, n_rays=8, small=True)
+    H, W, fx, fy, cx, cy = sc["intr"]
+    K, n = 3, 77
+    frames = _frames(sc, K, DEV, grad=True)
+    idx = torch.randint((H - 8) * (W - 10), (K * n,), generator=torch.Generator().manual_seed(3))
+    w = nsa.get_samples_window(4, H - 4, 5, W - 5, n, H, W, fx, fy, cx, cy, [f[0] for f in frames], [f[1] for f in frames],
+                               [f[2] for f in frames], sc["bound"], DEV, indices=idx)
+    parts = [samples_from_indices(idx[k * n:(k + 1) * n].to(DEV), 4, H - 4, 5, W - 5, fx, fy, cx, cy, *frames[k]) for k in range(K)]
+    ro, rd, gd, gc = (torch.cat([p[i] for p in parts]) for i in range(4))
+    for a, b in ((w.rays_o, ro), (w.rays_d, rd), (w.gt_depth, gd), (w.gt_color, gc)):
+        assert torch.equal(a.detach(), b.detach())
+    keep, kmax = nsa.aabb_keep(ro.detach(), rd.detach(), gd, sc["bound"])
+    assert torch.equal(w.keep, keep) and torch.equal(w.kept_max, kmax) and 0.05 < keep.float().mean() < 0.98
+    # pose gradients (local BA): one kernel vs autograd through the per-frame path
+    gen = torch.Generator().manual_seed(4)
+    wo, wd = torch.randn((K * n, 3), generator=gen).to(DEV), torch.randn((K * n, 3), generator=gen).to(DEV)
+    ((w.rays_o * wo).sum() + (w.rays_d * wd).sum()).backward()
+    got = [f[0].grad.clone() for f in frames]
+    for f in frames:
+        f[0].grad = None
+    ((ro * wo).sum() + (rd * wd).sum()).backward()
+    for k in range(K):
+        assert got[k].shape == frames[k][0].shape
+        assert rel_err(got[k], frames[k][0].grad) < 1e-5, k
+
+
+@pytest.mark.parametrize("stage", ["middle", "fine", "color"])
+def test_fused_mapping_loss_equals_unfused_path(stage):
+    import nice_slam_amd as nsa
+    sc = make_scene(seed=82, n_rays=8, small=True)
+    H, W, fx, fy, cx, cy = sc["intr"]
+    renderer, dec, grids_dev = build_product(sc, DEV)
+    K, n = 4, 150
+    idx = torch.randint(H * W, (K * n,), generator=torch.Generator().manual_seed(5))
+
+    def run(fused):
+        frames = _frames(sc, K, DEV, grad=True)
+        c = {k: v.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) for k, v in grids_dev.items()}
+        for p in dec.parameters():
+            p.requires_grad_(True); p.grad = None
+        if fused:
+            loss = nsa.mapping_loss(renderer, c, dec, frames, n, stage, w_color=0.2, indices=idx)
+        else:
+            w = nsa.get_samples_window(0, H, 0, W, n, H, W, fx, fy, cx, cy, [f[0] for f in frames], [f[1] for f in frames],
+                                       [f[2] for f in frames], sc["bound"], DEV, indices=idx)
+            depth, _, color = renderer.render_batch_ray(c, dec, w.rays_d, w.rays_o, DEV, stage, gt_depth=w.gt_depth, gt_max=w.kept_max)
+            loss = (torch.abs(w.gt_depth - depth) * (w.keep & (w.gt_depth > 0))).sum()          # Mapper.py:487-493, mask form
+            if stage == "color":
+                loss = loss + 0.2 * (torch.abs(w.gt_color - color) * w.keep[:, None]).sum()
+        loss.backward()
+        return (float(loss.detach()), {k: v.grad.clone() for k, v in c.items() if v.grad is not None},
+                {k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None}, [f[0].grad.clone() for f in frames])
+
+    l0, g0, p0, c0 = run(False)
+    l1, g1, p1, c1 = run(True)
+    # (the colour term of the unfused path is an fp32 torch.sum, Mapper.py:491: 1e-7 of summation noise)
+    assert abs(l0 - l1) <= (1e-6 if stage == "color" else 1e-9) * abs(l0), (l0, l1)
+    assert set(g0) == set(g1) and set(p0) == set(p1) and len(g0) == {"middle": 1, "fine": 2, "color": 3}[stage]
+    for k in g0:
+        assert rel_err(g1[k], g0[k]) < 1e-5, k
+    for k in p0:
+        assert rel_err(p1[k], p0[k]) < 2e-5, k
+    for k in range(K):
+        assert rel_err(c1[k], c0[k]) < 1e-4, (k, c1[k], c0[k])
+
+
+def test_masked_adam_multi_equals_per_grid_steps():
+    import nice_slam_amd as nsa
+    sc = make_scene(seed=83, n_rays=8, small=True)
+    _, _, grids_dev = build_product(sc, DEV)
+    keys = ("grid_middle", "grid_fine", "grid_color")
+    g = torch.Generator().manual_seed(6)
+    masks = {k: (torch.rand(grids_dev[k].shape[2:], generator=g) < 0.6) for k in keys}
+    A = {k: grids_dev[k].detach().clone(memory_format=torch.preserve_format) for k in keys}
+    B = {k: grids_dev[k].detach().clone(memory_format=torch.preserve_format) for k in keys}
+    oa, ob = nsa.MaskedGridAdam(A, masks), nsa.MaskedGridAdam(B, masks, capturable=True)
+    lrs = [{"grid_middle": 0.1}, {"grid_middle": 0.005, "grid_fine": 0.005}, {k: 0.005 for k in keys}, {k: 0.005 for k in keys}]
+    for it, lr in enumerate(lrs):
+        grads = {k: nsa.to_channels_last(torch.randn(A[k].shape, generator=g).to(DEV) * 1e-3) for k in lr}
+        gb = {k: v.clone(memory_format=torch.preserve_format) for k, v in grads.items()}
+        oa.step(lr, grads=grads)
+        ob.step(lr, grads=gb, zero_grad=(it % 2 == 1))
+        for k in lr:
+            full = masks[k][None, None].expand_as(gb[k]).to(DEV)
+            if it % 2 == 1:
+                assert float(gb[k][full].abs().max()) == 0.0 and torch.equal(gb[k][~full], grads[k][~full])
+            else:
+                assert torch.equal(gb[k], grads[k])
+    assert ob._dev_steps.tolist() == [4, 3, 2]
+    for k in keys:
+        # (step size: fp64 on the device from the fp32 lr vs python floats on the host -- a few ulp after four steps)
+        assert float((A[k] - B[k]).abs().max()) <= 1e-5 * float(A[k].abs().max()), k
+        assert float((A[k] - grids_dev[k]).abs().max()) > 1e-4
+
+
+def test_captured_fused_iteration_replays_like_eager():
+    """A whole colour-stage mapping iteration -- index draw, window sampling, render, fused loss, backward, capturable grid
+    Adam (device step counts) and a capturable torch Adam on the colour decoder -- captured once in a hipGraph; replays
+    must walk the same trajectory as the eager loop."""
+    import nice_slam_amd as nsa
+    sc = make_scene(seed=84, n_rays=8, small=True)
+    renderer, dec0, grids_dev = build_product(sc, DEV)
+    keys = ("grid_middle", "grid_fine", "grid_color")
+    K, n, iters = 3, 120, 4
+    frames = _frames(sc, K, DEV)
+    H, W = sc["intr"][:2]
+    idx_all = [torch.randint(H * W, (K * n,), generator=torch.Generator().manual_seed(50 + i)).to(DEV) for i in range(iters)]
+
+    def build():
+        import copy
+        dec = copy.deepcopy(dec0)
+        for p in dec.parameters():
+            p.requires_grad_(True)
+        c = {k: v.detach().clone(memory_format=torch.preserve_format).requires_grad_(k in keys) for k, v in grids_dev.items()}
+        gopt = nsa.MaskedGridAdam({k: c[k] for k in keys}, capturable=True)
+        dopt = torch.optim.Adam(list(dec.color_decoder.parameters()), lr=torch.tensor(0.005, device=DEV), capturable=True, foreach=True)
+        idx = idx_all[0].clone()
+        losses = torch.zeros(1, dtype=torch.float64, device=DEV)
+
+        def it():
+            for t in c.values():
+                t.grad = None
+            dopt.zero_grad(set_to_none=True)
+            for p in dec.parameters():
+                p.grad = None
+            loss = nsa.mapping_loss(renderer, c, dec, frames, n, "color", indices=idx)
+            loss.backward()
+            dopt.step()
+            with torch.no_grad():
+                gopt.step({k: 0.005 for k in keys})
+            losses.copy_(loss.detach().reshape(1))
+        return c, dec, idx, losses, it
+
+    # the captured loop: CapturedStep EXECUTES the iteration once (warm-up) before it records it (recording executes
+    # nothing) -- that run is part of the trajectory, so the eager twin takes the same iteration on the same pixels first
+    c_g, dec_g, idx_g, loss_g, it_g = build()
+    idx_g.copy_(idx_all[0])
+    step = nsa.graphs.CapturedStep(it_g, warmup=1)
+    c_e, dec_e, idx_e, loss_e, it_e = build()
+    idx_e.copy_(idx_all[0]); it_e()
+    for i in range(1, iters):
+        idx_g.copy_(idx_all[i]); step()
+        idx_e.copy_(idx_all[i]); it_e()
+        a, b = float(loss_g), float(loss_e)
+        assert abs(a - b) <= 1e-6 * abs(b), (i, a, b)
+    for k in keys:
+        assert rel_err(c_g[k], c_e[k]) < 1e-5, k
+        assert float((c_g[k] - grids_dev[k]).abs().max()) > 1e-3, k
+    for (n_, p), q in zip(dec_g.color_decoder.named_parameters(), dec_e.color_decoder.parameters()):
+        assert rel_err(p, q) < 1e-4, n_
