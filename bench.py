@@ -2,19 +2,22 @@
 """bench.py -- rendered rays/s (forward + backward) of the NICE-SLAM mapping render hot path on MI355X.
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 launched under
-torch.distributed.run, one rank per GPU.  One STEP = one mapping iteration's pass of the hot path over one
-ray batch of BASELINE configs[1] (Replica room0 full config): get_samples for the 5-keyframe window ->
-render_batch_ray -> mapping loss -> backward (grid, decoder and nothing else; no optimiser: Adam and the
-masked write-back belong to the unchanged caller).  The stage of step i follows the reference
-schedule of a 60-iteration frame batch (25 middle / 12 fine / 23 color, src/Mapper.py:403-410), so the
-default K=60 reproduces the Replica mapping mix exactly.  Prints ONE JSON line.
+torch.distributed.run, one rank per GPU.  One STEP = one mapping iteration's pass of the hot path over one ray batch:
+index draw -> window sampling (all keyframes, bounding-box mask) -> render forward -> mapping loss -> backward (every grid,
+every decoder, like the reference's autograd; no optimiser: Adam and the masked write-back belong to the caller,
+SURVEY §8(f)).  Default workload = BASELINE configs[1] (Replica room0 full config); ``--config {0,2,3,4,tracking}`` selects
+the other BASELINE configurations.  For the staged configurations the stage of step i follows the reference schedule of a
+60-iteration frame batch (25 middle / 12 fine / 23 color, src/Mapper.py:403-410), interleaved so that any window carries that
+mix.  The K steps are timed ``--windows`` (default 3) times; the MEDIAN window is reported.  Prints ONE JSON line.
 """
 import argparse
 import ctypes
 import json
+import math
 import os
 import sys
 import time
+import types
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -22,16 +25,32 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-RAYS_PER_GPU = 1000            # mapping.pixels (configs/Replica/replica.yaml)
-WINDOW = 5                     # mapping_window_size -> 5 x 200 pixels
 FP32_PEAK = 157.3e12           # MI355X dense fp32 MFMA peak (MI355X_MICROARCH.md)
-# necessary backward FLOP per ray of the dominant kernel (color-stage backward): SURVEY §8(d)
-#   (106 140 - 51 653) MAC/pt * 2 FLOP * 48 pts  (dX chain + stepped dW + d-embedding; the forward is a separate launch)
-BWD_COLOR_FLOP_PER_RAY = (106140 - 51653) * 2 * 48
-# what the colour backward kernel EXECUTES on the MFMA pipe: forward re-run + dX + dW of all three decoders, like the
-# reference's autograd (SURVEY §8(d) "reference-equivalent" column: 154 959 MAC/pt)
-BWD_COLOR_EXEC_FLOP_PER_RAY = 154959 * 2 * 48
-FWD_FLOP_PER_RAY = {"middle": 15479 * 2 * 48, "fine": 36078 * 2 * 48, "color": 51653 * 2 * 48}
+HBM_PEAK = 8.0e12
+# necessary / executed MAC per sample point, SURVEY §8(d)
+FWD_MAC = {"coarse": 6176, "middle": 15479, "fine": 36078, "color": 51653}
+NEC_MAC = {"coarse": 12352, "middle": 24727, "fine": 59694, "color": 106140}          # fwd + bwd, what the optimiser needs
+EXEC_BWD_MAC = {k: 2 * v for k, v in FWD_MAC.items()}                                     # + dW of every decoder: 3x fwd in total
+
+# ---- BASELINE.json configs ------------------------------------------------------------------------
+GRID_LEN = {"coarse": 2, "middle": 0.32, "fine": 0.16, "color": 0.16, "bound_divisible": 0.32}
+CONFIGS = {
+    "0": dict(name="Replica room0, 32x32 pixel batch, coarse grid only (BASELINE configs[0])", bound=[[-2.9, 8.9], [-3.2, 5.5], [-3.5, 3.3]],
+              cam=(680, 1200, 600.0, 600.0, 599.5, 339.5), rays=1024, window=1, stages=("coarse",), kind="mapping"),
+    "1": dict(name="Replica room0 full config (BASELINE configs[1])", bound=[[-2.9, 8.9], [-3.2, 5.5], [-3.5, 3.3]],
+              cam=(680, 1200, 600.0, 600.0, 599.5, 339.5), rays=1000, window=5, stages="mix", kind="mapping"),
+    "2": dict(name="ScanNet scene0000_00 full config (BASELINE configs[2])", bound=[[-2.0, 11.0], [-2.0, 11.5], [-2.0, 5.5]],
+              cam=(460, 620, 577.590698, 578.729797, 308.905426, 232.683609), rays=5000, window=10, stages="mix", kind="mapping"),
+    "3": dict(name="Apartment large-scene config (BASELINE configs[3])", bound=[[-5.8, 11.3], [-4.0, 4.5], [-7.9, 4.9]],
+              cam=(720, 1280, 607.4694213867188, 607.4534912109375, 636.9967041015625, 369.2689514160156), rays=5000, window=10,
+              stages="mix", kind="mapping"),
+    "4": dict(name="Synthetic 1024x1024 RGB-D, 64^3 fine grid, 100k rays/iter (BASELINE configs[4])",
+              bound=[[-5.12, 5.11], [-5.12, 5.11], [-5.12, 5.11]], cam=(1024, 1024, 512.0, 512.0, 511.5, 511.5), rays=100000, window=5,
+              stages=("color",), kind="mapping"),
+    "tracking": dict(name="Replica room0 tracking (BASELINE configs[1], tracker side: 200 pixels, 100-pixel border, pose gradient only)",
+                     bound=[[-2.9, 8.9], [-3.2, 5.5], [-3.5, 3.3]], cam=(680, 1200, 600.0, 600.0, 599.5, 339.5), rays=200, window=1,
+                     stages=("color",), kind="tracking", crop=100),
+}
 
 
 def _stage_cycle(n=60):
@@ -50,10 +69,6 @@ def _stage_cycle(n=60):
 
 
 _CYCLE = _stage_cycle()
-
-
-def stage_of(it, n=60):
-    return _CYCLE[it % n]
 
 
 class HipEvents:
@@ -86,78 +101,75 @@ class HipEvents:
         return out
 
 
-# configs/Replica/room0.yaml + replica.yaml + nice_slam.yaml (BASELINE configs[1])
-REPLICA_ROOM0 = {
-    "scale": 1, "occupancy": True, "coarse": True,
-    "mapping": {"bound": [[-2.9, 8.9], [-3.2, 5.5], [-3.5, 3.3]]},
-    "grid_len": {"coarse": 2, "middle": 0.32, "fine": 0.16, "color": 0.16, "bound_divisible": 0.32},
-    "model": {"c_dim": 32, "coarse_bound_enlarge": 2},
-    "rendering": {"lindisp": False, "perturb": 0.0, "N_samples": 32, "N_surface": 16, "N_importance": 0},
-    "cam": {"H": 680, "W": 1200, "fx": 600.0, "fy": 600.0, "cx": 599.5, "cy": 339.5},
-}
-
-
-def build_scene(dev, seed=0):
-    """Synthetic workload of BASELINE configs[1], built with the product's own set-up code (no oracle involved): grids with
-    the reference's init statistics (NICE_SLAM.py:223-247), random-init decoders (no pretrained weights exist here), one
-    680x1200 RGB-D frame with depth U(1,4) m and 1 % zeros, a pose at the centre of the bound."""
-    import math
-    import types
+def build_scene(cfg_id, dev, seed=0):
+    """Synthetic workload of a BASELINE configuration, built with the product's own set-up code (no oracle involved): grids
+    with the reference's init statistics (NICE_SLAM.py:223-247), random-init decoders (no pretrained weights exist here),
+    `window` RGB-D frames with depth U(1,4) m and 1 % zeros, poses near the centre of the bound."""
     import nice_slam_amd as nsa
     from nice_slam_amd.common import set_decoder_bounds
-    cfg = REPLICA_ROOM0
+    C = CONFIGS[cfg_id]
+    H, W, fx, fy, cx, cy = C["cam"]
+    cfg = {"scale": 1, "occupancy": True, "coarse": True, "mapping": {"bound": C["bound"]}, "grid_len": GRID_LEN,
+           "model": {"c_dim": 32, "coarse_bound_enlarge": 2},
+           "rendering": {"lindisp": False, "perturb": 0.0, "N_samples": 32, "N_surface": 16, "N_importance": 0}}
     torch.manual_seed(seed)
     bound = nsa.load_bound(cfg)
-    cam = cfg["cam"]
-    slam = types.SimpleNamespace(nice=True, bound=bound, H=cam["H"], W=cam["W"], fx=cam["fx"], fy=cam["fy"], cx=cam["cx"], cy=cam["cy"])
+    slam = types.SimpleNamespace(nice=True, bound=bound, H=H, W=W, fx=fx, fy=fy, cx=cx, cy=cy)
     renderer = nsa.Renderer(cfg, None, slam)
     dec = nsa.NICE(coarse=True).to(dev)
     set_decoder_bounds(dec, bound, cfg["model"]["coarse_bound_enlarge"])
     grids = {k: v.to(dev) for k, v in nsa.grid_init(cfg, bound).items()}
     g = torch.Generator().manual_seed(seed + 1)
-    depth = torch.rand((cam["H"], cam["W"]), generator=g) * 3.0 + 1.0
-    depth[torch.rand((cam["H"], cam["W"]), generator=g) < 0.01] = 0.0
-    color = torch.rand((cam["H"], cam["W"], 3), generator=g)
-    ang = 0.15
-    c2w = torch.eye(4)
-    c2w[:3, :3] = torch.tensor([[math.cos(ang), 0, math.sin(ang)], [0, 1, 0], [-math.sin(ang), 0, math.cos(ang)]])
-    c2w[:3, 3] = bound.mean(1).float()
-    return {"cfg": cfg, "bound": bound, "renderer": renderer, "dec": dec, "grids": grids, "c2w": c2w,
-            "depth_img": depth, "color_img": color, "intr": (cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])}
+    frames = []
+    for k in range(C["window"]):
+        depth = torch.rand((H, W), generator=g) * 3.0 + 1.0
+        depth[torch.rand((H, W), generator=g) < 0.01] = 0.0
+        color = torch.rand((H, W, 3), generator=g)
+        ang = 0.15 + 0.05 * k
+        c2w = torch.eye(4)
+        c2w[:3, :3] = torch.tensor([[math.cos(ang), 0, math.sin(ang)], [0, 1, 0], [-math.sin(ang), 0, math.cos(ang)]])
+        c2w[:3, 3] = bound.mean(1).float() + 0.05 * k
+        frames.append((c2w, depth, color))
+    return {"cfg": cfg, "C": C, "bound": bound, "renderer": renderer, "dec": dec, "grids": grids, "frames": frames,
+            "intr": (H, W, fx, fy, cx, cy)}
 
 
-def cpu_baseline(sc, n_rays, reps=1):
-    """The CPU oracle (a torch restatement of the reference path, kind='port') on this box's host cores, fed with the SAME
-    grids / decoder parameters / frame as the GPU run: one forward+backward per stage on an `n_rays` batch, stage-weighted
-    like the GPU run.  The only place of this file that touches oracle/."""
+def cpu_baseline(sc, n_rays, stages, weights):
+    """The CPU oracle (a torch restatement of the reference path, kind='port') on this box's host cores, in the mode that
+    calls ATen's grid_sampler_3d exactly like the reference (decoder.py:173; its backward is 59 % of the reference's CPU time),
+    fed with the SAME grids / decoder parameters / frames as the GPU run: one forward+backward per stage on a bounded ray
+    sample, stage-weighted like the GPU run.  The only place of this file that touches oracle/."""
     from oracle import nice_oracle as orc
-    torch.set_num_threads(min(16, os.cpu_count() or 1))       # small-op torch CPU code scales poorly past ~16 threads
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)                               # small-op torch CPU code scales poorly past ~16 threads
+    orc.TRILINEAR_IMPL = "grid_sample"
     H, W, fx, fy, cx, cy = sc["intr"]
     grids = {k: v.detach().cpu().contiguous() for k, v in sc["grids"].items()}                # NCDHW, standard strides
     params = {k: v.detach().cpu().clone() for k, v in sc["dec"].state_dict().items()}
-    idx = torch.randint(H * W, (n_rays,), generator=torch.Generator().manual_seed(5))
-    rays_o, rays_d, gt_depth, gt_color = orc.pixel_rays(idx, 0, H, 0, W, fx, fy, cx, cy, sc["c2w"], sc["depth_img"], sc["color_img"])
+    c2w, depth_img, color_img = sc["frames"][0]
+    n = min(n_rays, 1000)                                       # bounded sample: ~10-20 s of CPU work
+    idx = torch.randint(H * W, (n,), generator=torch.Generator().manual_seed(5))
+    rays_o, rays_d, gt_depth, gt_color = orc.pixel_rays(idx, 0, H, 0, W, fx, fy, cx, cy, c2w, depth_img, color_img)
 
-    def once(stage, n):
+    def once(stage, m):
         G = {k: v.clone().requires_grad_(True) for k, v in grids.items()}
         P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-        depth, _, col = orc.render_batch_ray(G, P, rays_d[:n], rays_o[:n], stage, gt_depth[:n], sc["bound"])
-        loss = (torch.abs(gt_depth[:n] - depth) * (gt_depth[:n] > 0)).sum()
+        depth, _, col = orc.render_batch_ray(G, P, rays_d[:m], rays_o[:m], stage, gt_depth[:m], sc["bound"])
+        loss = (torch.abs(gt_depth[:m] - depth) * (gt_depth[:m] > 0)).sum()
         if stage == "color":
-            loss = loss + 0.2 * torch.abs(gt_color[:n] - col).sum()
+            loss = loss + 0.2 * torch.abs(gt_color[:m] - col).sum()
         loss.backward()
 
     t = {}
-    for stage in ("middle", "fine", "color"):
+    for stage in stages:
         once(stage, 64)                                        # warm-up
         t0 = time.perf_counter()
-        for _ in range(reps):
-            once(stage, n_rays)
-        t[stage] = (time.perf_counter() - t0) / reps
-    mix = (25 * t["middle"] + 12 * t["fine"] + 23 * t["color"]) / 60.0
-    return {"value": n_rays / mix, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle fwd+bwd, {n_rays} rays, 1 iter per stage (middle {t['middle']*1e3:.0f} ms, fine {t['fine']*1e3:.0f} ms, "
-                      f"color {t['color']*1e3:.0f} ms), weighted 25/12/23"}
+        once(stage, n)
+        t[stage] = time.perf_counter() - t0
+    mix = sum(weights[s] * t[s] for s in stages) / sum(weights.values())
+    return {"value": n / mix, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": "oracle (grid_sampler_3d mode) fwd+bwd, %d rays, 1 iteration per stage (%s), weighted like the GPU run"
+                      % (n, ", ".join(f"{s} {t[s]*1e3:.0f} ms" for s in stages))}
 
 
 def main():
@@ -165,14 +177,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="1", choices=sorted(CONFIGS), help="BASELINE.json configuration (default 1 = the headline one)")
+    ap.add_argument("--windows", type=int, default=3, help="the K timed steps are run this many times; the median window is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage", default=None, help="pin every step to one stage (profiling)")
-    ap.add_argument("--rays", type=int, default=RAYS_PER_GPU)
+    ap.add_argument("--rays", type=int, default=None, help="rays per iteration (default: the configuration's)")
     ap.add_argument("--eager", action="store_true", help="do not capture the iteration in a hipGraph")
+    ap.add_argument("--unfused", action="store_true", help="the drop-in call sequence (get_samples per frame, render_batch_ray, torch loss) instead of mapping_loss")
     ap.add_argument("--stepped-grads-only", action="store_true",
                     help="parameter gradients only for the decoder the reference's optimiser steps (colour); default: all, like the reference autograd")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="multi-GPU: weak = --rays per GPU (default), strong = --rays in total, split over the ranks")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="multi-GPU: weak = the configuration's rays per GPU, strong = in total (default: strong for config 3 / 4, else weak)")
     ap.add_argument("--dense-exchange", action="store_true",
                     help="multi-GPU: all-reduce the whole feature-grid gradients instead of the frustum-selected voxel rows")
     args = ap.parse_args()
@@ -194,7 +209,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_dist = os.environ.get("NSR_FORCE_SHARDED") == "1"        # exercise the RCCL path with a single rank (CI on a 1-GPU box)
-    if world > 1 or force_dist:
+    sharded = world > 1 or force_dist
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         backend = os.environ.get("NSR_DIST_BACKEND", "nccl")       # "nccl" = RCCL; "gloo" only to exercise the multi-rank
@@ -204,65 +220,104 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import nice_slam_amd as nsa
-    from nice_slam_amd.parallel import ShardedRenderer
+    from nice_slam_amd.parallel import ShardedMapping
 
-    n_total = args.rays * world if args.scaling == "weak" else args.rays      # weak: fixed rays per GPU; strong: fixed batch
-    sc = build_scene(dev)                                          # same seed -> identical scene on every rank
-    renderer, dec, grids = sc["renderer"], sc["dec"], sc["grids"]
-    grids = {k: v.requires_grad_(True) for k, v in grids.items()}
-    for n_, p in dec.named_parameters():                          # reference: every decoder parameter has requires_grad=True
-        p.requires_grad_(True)
+    C = CONFIGS[args.config]
+    scaling = args.scaling or ("strong" if args.config in ("3", "4") else "weak")
+    rays_cfg = args.rays or C["rays"]
+    n_total = rays_cfg * world if scaling == "weak" else rays_cfg      # weak: fixed rays per GPU; strong: fixed batch
+    sc = build_scene(args.config, dev)                              # same seed -> identical scene on every rank
+    renderer, dec = sc["renderer"], sc["dec"]
+    grids = {k: v.requires_grad_(True) for k, v in sc["grids"].items()}
+    tracking = C["kind"] == "tracking"
+    for p in dec.parameters():                                      # reference: every decoder parameter has requires_grad=True
+        p.requires_grad_(not tracking)                              # (the tracker works on a detached copy, Tracker.py:138)
+    if tracking:
+        grids = {k: v.detach() for k, v in grids.items()}
     if args.stepped_grads_only:
         renderer.decoder_grads = ("color",)
     H, W, fx, fy, cx, cy = sc["intr"]
-    depth_img, color_img, c2w = sc["depth_img"].to(dev), sc["color_img"].to(dev), sc["c2w"].to(dev)
+    frames = [(c.to(dev), d.to(dev), col.to(dev)) for c, d, col in sc["frames"]]
+    K = len(frames)
     params = list(dec.parameters())
     ev = HipEvents()
     renderer.profile_events = ev.pair_for
-    rend = ShardedRenderer(renderer) if (world > 1 or force_dist) else renderer
+    stages_cfg = ("middle", "fine", "color") if C["stages"] == "mix" else tuple(C["stages"])
+    if args.stage:
+        stages_cfg = (args.stage,)
+    mix = {s: _CYCLE.count(s) for s in stages_cfg} if C["stages"] == "mix" and not args.stage else {s: 1 for s in stages_cfg}
+
+    def stage_of(it):
+        if len(stages_cfg) == 1:
+            return stages_cfg[0]
+        return _CYCLE[it % 60]
+
     exchange = "single GPU"
-    if world > 1 or force_dist:
-        exchange = f"ray-sharded x{world}, dense RCCL all-reduce of grid grads"
-        if not args.dense_exchange:
+    shard = None
+    if sharded:
+        shard = ShardedMapping(renderer)
+        exchange = f"rays sharded x{world}: each rank samples, renders and differentiates its share; one MAX all-reduce of 1 float " \
+                   f"(batch-global depth cap) + ONE packed SUM all-reduce per iteration (dense grid gradients + decoder blob)"
+        if not args.dense_exchange and not tracking:
             # The mapper optimises only the voxels inside the current frame's frustum mask (Mapper.py:315-333), identical
-            # on every rank: exchange those voxel rows only (parallel.ShardedRenderer.set_voxel_masks).
+            # on every rank: exchange those voxel rows only
             sel = nsa.FrustumSelector(sc["bound"], H, W, fx, fy, cx, cy)
             pose = torch.eye(4)
-            pose[:3] = sc["c2w"][:3].detach().cpu().float()
-            masks = {k: sel.voxel_mask(pose, k, v.shape[2:], depth_img) for k, v in grids.items() if k != "grid_coarse"}
-            rend.set_voxel_masks(masks)
+            pose[:3] = sc["frames"][-1][0][:3].detach().cpu().float()
+            masks = {k: sel.voxel_mask(pose, k, v.shape[2:], frames[-1][1]) for k, v in grids.items() if k != "grid_coarse"}
+            shard.set_voxel_masks(masks)
             frac = {k[5:]: round(float(m.float().mean()), 3) for k, m in masks.items()}
-            exchange = (f"ray-sharded x{world}, one packed RCCL all-reduce per iteration over the frustum-selected voxel rows "
-                        f"(selected fraction {frac}) + decoder grads")
-    torch.manual_seed(1234)                                       # identical index draws on every rank
-    per_frame = n_total // WINDOW
+            exchange = exchange.replace("dense grid gradients", f"frustum-selected voxel rows {frac}")
+    torch.manual_seed(1234 + rank)                                 # every rank draws its own pixels
+    per_frame = max(1, (n_total // world) // K)                    # this rank's pixels per frame
+    rays_rank = per_frame * K
+    crop = C.get("crop", 0)
+    cam = None
+    if tracking:
+        cam = frames[0][0][:3].clone().requires_grad_(True)       # the pose under optimisation (gradient w.r.t. the 3x4 matrix)
 
     def step(it, timed):
-        stage = args.stage or stage_of(it)
-        ro, rd, gd, gc = [], [], [], []
-        for _ in range(WINDOW):
-            o, d, dep, col = nsa.get_samples(0, H, 0, W, per_frame, H, W, fx, fy, cx, cy, c2w, depth_img, color_img, dev)
-            ro.append(o); rd.append(d); gd.append(dep); gc.append(col)
-        rays_o, rays_d, gt_depth, gt_color = torch.cat(ro), torch.cat(rd), torch.cat(gd), torch.cat(gc)
+        stage = stage_of(it)
         for g in grids.values():
             g.grad = None
         for p in params:
             p.grad = None
         if not timed:
             renderer.profile_events = None
-        depth, unc, color = rend.render_batch_ray(grids, dec, rays_d, rays_o, dev, stage, gt_depth=gt_depth)
-        # src/Mapper.py:487-489 sums |gt - depth| over gt > 0; written as a masked product so that no boolean-index
-        # (nonzero -> host sync) sits inside the iteration: same value, the host keeps running ahead of the GPU
-        loss = (torch.abs(gt_depth - depth) * (gt_depth > 0)).sum()
-        if stage == "color":
-            loss = loss + 0.2 * torch.abs(gt_color - color).sum()  # :490-493
-        loss.backward()
+        if tracking:                                              # Tracker.optimize_cam_in_batch (Tracker.py:87-125), sync-free form
+            cam.grad = None
+            o, d, gd, gc = nsa.get_samples(crop, H - crop, crop, W - crop, rays_rank, H, W, fx, fy, cx, cy, cam, frames[0][1], frames[0][2], dev)
+            keep, kmax = nsa.aabb_keep(o, d, gd, sc["bound"])
+            depth, unc, color = renderer.render_batch_ray(grids, dec, d, o, dev, "color", gt_depth=gd, gt_max=kmax)
+            unc = unc.detach()
+            tmp = torch.abs(gd - depth) / torch.sqrt(unc + 1e-10)
+            med = torch.nanmedian(torch.where(keep, tmp.detach(), torch.full_like(tmp, float("nan"))))
+            mask = (tmp < 10 * med) & (gd > 0) & keep
+            loss = torch.where(mask, tmp, torch.zeros_like(tmp)).sum() + 0.5 * torch.where(mask[:, None], torch.abs(gc - color), torch.zeros_like(color)).sum()
+            loss.backward()
+        elif shard is not None:
+            loss = shard.mapping_loss(grids, dec, frames, per_frame, stage)
+            loss.backward()
+        elif args.unfused:                                        # the reference's call sequence through the drop-in surface
+            ro, rd, gd, gc = [], [], [], []
+            for c2w, dimg, cimg in frames:
+                o, d, dep, col = nsa.get_samples(0, H, 0, W, per_frame, H, W, fx, fy, cx, cy, c2w, dimg, cimg, dev)
+                ro.append(o); rd.append(d); gd.append(dep); gc.append(col)
+            rays_o, rays_d, gt_depth, gt_color = torch.cat(ro), torch.cat(rd), torch.cat(gd), torch.cat(gc)
+            depth, unc, color = renderer.render_batch_ray(grids, dec, rays_d, rays_o, dev, stage, gt_depth=None if stage == "coarse" else gt_depth)
+            loss = (torch.abs(gt_depth - depth) * (gt_depth > 0)).sum()
+            if stage == "color":
+                loss = loss + 0.2 * torch.abs(gt_color - color).sum()
+            loss.backward()
+        else:                                                      # Mapper.py:437-503 as one autograd node (mapping.py)
+            loss = nsa.mapping_loss(renderer, grids, dec, frames, per_frame, stage, w_color=0.2, coarse_mapper=(stage == "coarse"))
+            loss.backward()
         renderer.profile_events = ev.pair_for
         return stage
 
     # Warm-up: eager iterations.  First untimed ones (code load, allocator, LDS attribute), then 5 per stage with HIP
     # events around the backward kernel -- these feed `roofline` / `kernel_ms`.
-    reps = tuple(_CYCLE.index(k) for k in ("middle", "fine", "color")) if args.stage is None else (0,)
+    reps = tuple(_CYCLE.index(k) if len(stages_cfg) > 1 else 0 for k in stages_cfg)
     for i in range(max(args.warmup, 2 * len(reps))):
         step(reps[i % len(reps)], False)
     torch.cuda.synchronize()
@@ -271,12 +326,12 @@ def main():
             step(st_i, True)
     torch.cuda.synchronize()
     # RCCL collectives are capturable too; NSR_DIST_GRAPH=0 forces the eager path for multi-rank runs
-    use_graph = not args.eager and ((world == 1 and not force_dist) or os.environ.get("NSR_DIST_GRAPH", "1") == "1") \
+    use_graph = not args.eager and ((not sharded) or os.environ.get("NSR_DIST_GRAPH", "1") == "1") \
         and os.environ.get("NSR_DIST_BACKEND", "nccl") == "nccl"
     graphs = {}
     if use_graph:
-        # The mapping iteration is launch-bound on the host (~25 small launches around three big kernels): capture one
-        # hipGraph per stage (identical kernel sequence, fresh torch.randint draws on every replay) and replay it.
+        # The iteration is a handful of launches; one hipGraph per stage (identical kernel sequence, fresh torch.randint
+        # draws on every replay) removes the host from the loop.
         renderer.profile_events = None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -307,67 +362,80 @@ def main():
     def timed_step(i):
         if not use_graph:
             return step(i, False)
-        stage = args.stage or stage_of(i)
+        stage = stage_of(i)
         graphs[stage].replay()
         return stage
 
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    stages = [timed_step(i) for i in range(args.steps)]
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    windows, stages = [], []
+    for w in range(max(1, args.windows)):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        stages = [timed_step(i) for i in range(args.steps)]
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        windows.append(dt)
+    dt = sorted(windows)[len(windows) // 2]
+    rays_iter = rays_rank * world
 
     if rank == 0:
         ksum = ev.summary()
+        dom = "color" if "color" in ksum else (list(ksum)[-1] if ksum else None)
         res = {
-            "metric": "rendered rays/sec (fwd+bwd) per mapping iter", "value": n_total * args.steps / dt, "unit": "rays/s",
+            "metric": "rendered rays/sec (fwd+bwd) per mapping iter", "value": rays_iter * args.steps / dt, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32 (f64 sample placement / depth)",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32 (f64 sample placement / depth)",
             "data": "synthetic",
-            "config": {"workload": "Replica room0 full config (BASELINE configs[1]): grids 21x28x37 / 43x56x74 x2, 32 ch fp32, "
-                                   "random-init decoders, 680x1200 synthetic RGB-D, 5x200 pixels/iter, S=32+16",
-                       "rays_per_gpu": n_total // world, "rays_per_iteration": n_total, "stage_mix": {s: stages.count(s) for s in sorted(set(stages))},
-                       "timed_region": "get_samples x5 + render_batch_ray + mapping loss (sync-free form) + backward (all grid + all decoder grads, like the reference autograd), no optimiser",
-                       "decoder_grads": "colour decoder only (what Mapper's optimiser steps)" if args.stepped_grads_only else "all decoders (reference autograd semantics)",
+            "config": {"workload": C["name"] + ": grids " + " / ".join("x".join(str(v) for v in grids[k].shape[2:]) for k in grids) +
+                                   f", 32 ch fp32, random-init decoders, {H}x{W} synthetic RGB-D, {K}x{per_frame} pixels/iter/GPU, S=32+16",
+                       "rays_per_gpu": rays_rank, "rays_per_iteration": rays_iter,
+                       "stage_mix": {s: stages.count(s) for s in sorted(set(stages))},
+                       "timed_region": ("get_samples (crop) + bounding-box mask + render_batch_ray(color) + tracking loss + backward to the pose"
+                                        if tracking else
+                                        ("get_samples x window + cat + render_batch_ray + torch loss + backward" if args.unfused else
+                                         "index draw + window sampling kernel + render forward (with the mapping loss) + render backward") +
+                                        " (all grid + all decoder grads, like the reference autograd), no optimiser"),
+                       "decoder_grads": "none (tracking)" if tracking else ("colour decoder only (what Mapper's optimiser steps)" if args.stepped_grads_only else "all decoders (reference autograd semantics)"),
                        "launch": "hipGraph replay (one captured graph per stage)" if use_graph else "eager",
+                       "timed_windows_ms": [round(w_ * 1e3, 3) for w_ in windows], "reported": "median window",
                        "parallelism": exchange},
         }
-        if "color" in ksum:
-            ms, cnt = ksum["color"]
-            rays_launch = n_total // world                      # rays per backward launch on this rank
-            ach = rays_launch * BWD_COLOR_FLOP_PER_RAY / (ms * 1e-3)
+        if dom is not None:
+            ms, cnt = ksum[dom]
+            pts = rays_rank * (32 if dom == "coarse" else 48)
+            nec = pts * (NEC_MAC[dom] - FWD_MAC[dom]) * 2
+            ach = nec / (ms * 1e-3)
             traffic, tsrc = None, None
-            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")      # from a separate rocprofv3 --pmc run (tools/pmc_summary.py)
-            if os.path.exists(tpath) and rays_launch == RAYS_PER_GPU:
+            tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")      # from a separate rocprofv3 --pmc run (tools/pmc_summary.py)
+            if os.path.exists(tpath) and args.config == "1" and rays_rank == 1000:
                 tj = json.load(open(tpath)).get("nsr::render_bwd_kernel<3>", {})
-                traffic, tsrc = tj.get("hbm_bytes_per_launch"), "profiles/r01_traffic.json: " + tj.get("note", "")
-            res["roofline"] = {"bound": "mfma", "kernel": "render_bwd_kernel<color>", "achieved": ach / 1e12, "peak": FP32_PEAK / 1e12,
+                traffic, tsrc = tj.get("hbm_bytes_per_launch"), "profiles/r02_traffic.json: " + tj.get("note", "")
+            res["roofline"] = {"bound": "mfma", "kernel": f"render_bwd_kernel<{dom}>", "achieved": ach / 1e12, "peak": FP32_PEAK / 1e12,
                                "unit": "TFLOP/s", "frac": ach / FP32_PEAK, "traffic": traffic, "traffic_source": tsrc,
                                "avg_kernel_ms": ms, "launches": cnt,
                                "measured": "HIP events recorded inside nsr_render_bwd on the launch stream, eager iterations of this process"
                                            + (" (the timed region replays the captured graph of the same kernels)" if use_graph else ""),
-                               "algorithmic_flop_per_launch": rays_launch * BWD_COLOR_FLOP_PER_RAY,
-                               "executed_frac": (rays_launch * BWD_COLOR_EXEC_FLOP_PER_RAY / (ms * 1e-3)) / FP32_PEAK
-                               if not args.stepped_grads_only else None,
+                               "algorithmic_flop_per_launch": nec,
+                               "executed_frac": (pts * EXEC_BWD_MAC[dom] * 2 / (ms * 1e-3)) / FP32_PEAK
+                               if not (args.stepped_grads_only or tracking) else None,
                                "executed_note": "MFMA work the kernel actually issues (forward re-run + dX + dW for every decoder, "
                                                 "the reference autograd's semantics) over the same peak; `frac` counts only the necessary part"}
-        if world > 1 or force_dist:
-            res["config"]["grad_exchange_MB_last_iter"] = round(rend.last_exchange_floats * 4 / 1e6, 2)
+        if shard is not None:
+            res["config"]["grad_exchange_MB_last_iter"] = round(shard.last_exchange_floats * 4 / 1e6, 2)
         res["kernel_ms"] = {f"render_bwd<{s}>": round(v[0], 4) for s, v in ksum.items()}
-        if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(sc, args.rays)
+        if not args.no_cpu_baseline and world == 1 and not tracking:
+            res["cpu_baseline"] = cpu_baseline(sc, rays_rank, stages_cfg, mix)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(res) + "\n").encode())
-    if world > 1 or force_dist:
+    if sharded:
         dist.destroy_process_group()
 
 

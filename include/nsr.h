@@ -16,6 +16,7 @@
  *   nsr_masked_adam_multi <- the same for all grids of a stage, step counts on the device (capturable)
  *   nsr_get_samples_window <- src/Mapper.py:437-481  sampling loop over the mapping window + bounding-box pre-filter
  *   nsr_pose_grad        <- autograd of src/common.py:74-88 for that window (local BA, src/Mapper.py:417-419)
+ *   nsr_pack_rows        <- (none) gather / scatter of the voxel rows + blobs that travel in the multi-GPU all-reduce
  *
  * Conventions
  *   - all pointers are DEVICE pointers owned by the caller (PyTorch); the library never frees or
@@ -88,7 +89,8 @@ typedef struct nsr_render_args {
     double *zvals;            /* [N][S] sorted sample depths; optional: written by fwd when non-NULL, and when non-NULL in
                                  bwd they are loaded instead of being recomputed by each decoder pass                  */
     /* --- fused mapping loss (src/Mapper.py:487-493), optional: all NULL / 0 for the plain renderer ------------------
-     * fwd with loss != NULL adds   sum over rays r with keep[r] of  [gt_depth[r] > 0] |gt_depth[r] - depth[r]|
+     * fwd with loss != NULL adds   sum over rays r with keep[r] of  [gt_depth[r] > 0] |gt_depth[r] - depth[r]|   (gt_depth
+     *                              as passed in this block, also in the coarse stage whose SAMPLING ignores it)
      *                              + (colour stage) w_color * sum_c |gt_color[r][c] - rgb[r][c]|     to *loss (fp64)
      * and writes that sum's derivative w.r.t. each ray's outputs to dl_depth / dl_rgb -- exactly the arrays
      * nsr_render_bwd takes as d_depth / d_rgb (d_var = NULL), so the caller's loss and its backward cost no launch. */
@@ -197,6 +199,23 @@ typedef struct nsr_adam_grid {
 } nsr_adam_grid;
 int nsr_masked_adam_multi(const nsr_adam_grid *grids, int32_t n_grids, float beta1, float beta2, float eps,
                           int32_t zero_grad, float *scratch, void *stream);
+
+/* --- packing for the one-collective gradient exchange -------------------------------------------------------
+ * Gathers (unpack = 0) the listed voxel rows (32 floats each, rows[] = voxel indices in [Z][Y][X] raster order) of up to 4
+ * channels-last grid-gradient tensors and up to 4 flat spans into `packed` (rows of grid 0, grid 1, ..., then the spans), or
+ * scatters `packed` back (unpack = 1).  The caller all-reduces `packed` in between (torch.distributed / RCCL): the library
+ * itself stays free of communication.  Replaces the nsr_comm_* / nsr_reduce_grid_grads entry points sketched in SURVEY §8(b). */
+typedef struct nsr_rows {
+    float *grid;
+    const int64_t *rows;
+    int64_t n_rows;
+} nsr_rows;
+typedef struct nsr_span {
+    float *ptr;
+    int64_t n;
+} nsr_span;
+int nsr_pack_rows(const nsr_rows *grids, int32_t n_grids, const nsr_span *spans, int32_t n_spans, float *packed,
+                  int32_t unpack, void *stream);
 
 /* --- frustum feature selection ---------------------------------------------------------------------
  * Replaces Mapper.get_mask_from_c2w (src/Mapper.py:93-164) for one non-coarse feature grid: every voxel centre (xs[ix],

@@ -55,6 +55,14 @@ class NsrFrame(C.Structure):
     _fields_ = [("depth", C.c_void_p), ("color", C.c_void_p), ("c2w", C.c_void_p), ("c2w_stride", C.c_int32), ("pad_", C.c_int32)]
 
 
+class NsrRows(C.Structure):
+    _fields_ = [("grid", C.c_void_p), ("rows", C.c_void_p), ("n_rows", C.c_int64)]
+
+
+class NsrSpan(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("n", C.c_int64)]
+
+
 class NsrAdamGrid(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("voxel_mask", C.c_void_p),
                 ("n_voxels", C.c_int64), ("step", C.c_void_p), ("lr", C.c_float), ("pad_", C.c_int32)]
@@ -84,6 +92,7 @@ SYMBOLS = (
                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     ("nsr_masked_adam_multi", C.c_int, [C.POINTER(NsrAdamGrid), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32,
                                         C.c_void_p, C.c_void_p]),
+    ("nsr_pack_rows", C.c_int, [C.POINTER(NsrRows), C.c_int32, C.POINTER(NsrSpan), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     ("nsr_aabb_keep", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     ("nsr_frustum_workspace_floats", C.c_int64, [C.c_int64]),

@@ -96,7 +96,7 @@ int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays,
     }
     P.depth = a->depth; P.var = a->var; P.rgb = a->rgb; P.raw = a->raw; P.zvals = a->zvals;
     P.gt_color = a->gt_color; P.keep = a->keep; P.loss = a->loss; P.w_color = a->w_color;
-    P.dl_depth = a->dl_depth; P.dl_rgb = a->dl_rgb;
+    P.dl_depth = a->dl_depth; P.dl_rgb = a->dl_rgb; P.loss_depth = a->gt_depth;
     return 0;
 }
 
@@ -394,6 +394,30 @@ int nsr_masked_adam_multi(const nsr_adam_grid *grids, int32_t n_grids, float bet
         NSR_LAUNCH(nsr::masked_adam_multi_kernel, dim3((unsigned)((nmax * 8 + tb - 1) / tb), n_grids), dim3(tb), 0, stream, A);
     }
     return finish("nsr_masked_adam_multi");
+}
+
+int nsr_pack_rows(const nsr_rows *grids, int32_t n_grids, const nsr_span *spans, int32_t n_spans, float *packed,
+                  int32_t unpack, void *stream) {
+    if (n_grids < 0 || n_grids > 4 || n_spans < 0 || n_spans > 4) return fail("nsr_pack_rows: at most 4 grids and 4 spans");
+    if ((n_grids && !grids) || (n_spans && !spans) || !packed) return fail("nsr_pack_rows: null pointer");
+    nsr::PackParams P;
+    std::memset(&P, 0, sizeof(P));
+    long long total = 0;
+    for (int i = 0; i < n_grids; ++i) {
+        if (grids[i].n_rows < 0 || (grids[i].n_rows && (!grids[i].grid || !grids[i].rows))) return fail("nsr_pack_rows: bad grid entry");
+        P.grid[i] = grids[i].grid; P.rows[i] = reinterpret_cast<const long long *>(grids[i].rows); P.n_rows[i] = grids[i].n_rows;
+        total += grids[i].n_rows * nsr::kC;
+    }
+    for (int i = 0; i < n_spans; ++i) {
+        if (spans[i].n < 0 || (spans[i].n && !spans[i].ptr)) return fail("nsr_pack_rows: bad span entry");
+        P.span[i] = spans[i].ptr; P.span_n[i] = spans[i].n;
+        total += spans[i].n;
+    }
+    P.n_grids = n_grids; P.n_spans = n_spans; P.unpack = unpack ? 1 : 0; P.packed = packed; P.total = total;
+    if (total == 0) return 0;
+    const int tb = 256;
+    NSR_LAUNCH(nsr::pack_rows_kernel, dim3((unsigned)((total + tb - 1) / tb)), dim3(tb), 0, stream, P);
+    return finish("nsr_pack_rows");
 }
 
 int nsr_aabb_keep(const float *rays_o, const float *rays_d, const float *gt_depth, int64_t n,

@@ -76,6 +76,7 @@ struct RenderParams {
     float *partials;          // [3 passes][gridDim.x][max param count]
     int partial_stride;       // floats between two blocks' partial images
     // fused mapping loss (Mapper.py:487-493), optional
+    const float *loss_depth;  // [N] sensor depth of the loss (also set where the SAMPLING is unguided: coarse mapper, Mapper.py:484-489)
     const float *gt_color;    // [N][3]
     const unsigned char *keep; // [N] bounding-box mask of the callers' pre-filter, or NULL (all rays count)
     double *loss;             // forward: += sum over rays of the loss terms
@@ -809,7 +810,7 @@ NSR_KERNEL NSR_BOUNDS(768) void render_fwd_kernel(const RenderParams P) {
                     // Mapper.py:487-493 on the rays the pre-filter keeps, and its derivative w.r.t. this ray's outputs:
                     // d|gt - depth| = sign(depth - gt) where gt > 0, w_color * sign(rgb - gt_rgb) in the colour stage
                     const bool kp = !P.keep || P.keep[rayq];
-                    const float gd = P.gt_depth ? P.gt_depth[rayq] : 0.f;
+                    const float gd = P.loss_depth ? P.loss_depth[rayq] : 0.f;
                     double gD = 0.0;
                     float g3[3] = {0.f, 0.f, 0.f};
                     if (kp && gd > 0.f) {
@@ -974,6 +975,45 @@ NSR_KERNEL void masked_adam_multi_kernel(const AdamMulti A) {
     st4(A.v[i] + o, v);
     st4(A.p[i] + o, p);
     if (A.zero_grad) st4(A.g[i] + o, F4{0.f, 0.f, 0.f, 0.f});
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU gradient exchange: gather the frustum-selected voxel rows (32 floats) of up to 4 grid gradients
+// and up to 4 flat spans (decoder-gradient blob, pose gradients, loss) into ONE contiguous buffer for a single all-reduce,
+// and scatter the sums back.  One thread per float.
+// ------------------------------------------------------------------------------------------------
+struct PackParams {
+    float *grid[4];
+    const long long *rows[4];
+    long long n_rows[4];
+    float *span[4];
+    long long span_n[4];
+    int n_grids, n_spans, unpack;
+    float *packed;
+    long long total;
+};
+NSR_KERNEL void pack_rows_kernel(const PackParams P) {
+    long long t = (long long)bid_x() * nthreads() + tid();
+    if (t >= P.total) return;
+    const long long t0 = t;
+    float *where = nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (!where && i < P.n_grids) {
+            const long long seg = P.n_rows[i] * kC;
+            if (t < seg) where = P.grid[i] + P.rows[i][t / kC] * kC + (t % kC);
+            else t -= seg;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (!where && i < P.n_spans) {
+            if (t < P.span_n[i]) where = P.span[i] + t;
+            else t -= P.span_n[i];
+        }
+    }
+    if (!where) return;
+    if (P.unpack) *where = P.packed[t0]; else P.packed[t0] = *where;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -80,7 +80,7 @@ class _WindowFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_o, g_d, *_):
         indices, K, n, crop, intr, shapes, dtypes, devs = ctx.meta
-        grads = pose_grads(indices, K, n, crop, intr, g_o.contiguous(), g_d.contiguous(), shapes)
+        grads, _ = pose_grads(indices, K, n, crop, intr, g_o.contiguous(), g_d.contiguous(), shapes)
         return (None, *[g.to(device=dv, dtype=dt) for g, dv, dt in zip(grads, devs, dtypes)])
 
 
@@ -93,7 +93,7 @@ def pose_grads(indices, K, n, crop, intr, g_o, g_d, shapes) -> List[torch.Tensor
     out = torch.zeros((K, 4, 4), dtype=torch.float32, device=dev)
     lib.check(lib.nsr_pose_grad(indices.data_ptr(), K, n, H0, H1, W0, W1, fx, fy, cx, cy, g_o.data_ptr(), g_d.data_ptr(),
                                 out.data_ptr(), 16, _stream(dev)), "nsr_pose_grad")
-    return [out[k, :shp[0], :] for k, shp in enumerate(shapes)]
+    return [out[k, :shp[0], :] for k, shp in enumerate(shapes)], out
 
 
 def _window_meta(H0, H1, W0, W1, n, W, fx, fy, cx, cy, c2ws, depths, colors, bound, device, indices):
@@ -132,7 +132,7 @@ class _MappingLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, meta, *tensors):
-        renderer, decoders, stage, wmeta, w_color, coarse, out = meta
+        renderer, decoders, stage, wmeta, w_color, sharder, out = meta
         indices, K, n, crop, intr, depths, colors, bound, dev = wmeta
         lib = _capi.get_lib()
         slots = stage_slots(stage)
@@ -140,7 +140,7 @@ class _MappingLossFn(torch.autograd.Function):
         grids = dict(zip(slots, tensors[K:K + len(slots)]))
         stream = _stream(dev)
         N = K * n
-        guided = stage != "coarse" and not coarse
+        guided = stage != "coarse"
         S = renderer.N_samples + (renderer.N_surface if guided else 0)
         need_pose = any(ctx.needs_input_grad[1:1 + K])
         need_grid = ctx.needs_input_grad[1 + K:1 + K + len(slots)]
@@ -158,6 +158,8 @@ class _MappingLossFn(torch.autograd.Function):
         sbuf = torch.empty((10 * N + (N + 3) // 4,), dtype=torch.float32, device=dev)
         keep = sbuf[10 * N:].view(torch.uint8)[:N]
         _launch_window(indices, K, n, crop, intr, frames, _bound_arrays(bound), sbuf, keep, kmax.data_ptr(), dev)
+        if sharder is not None:                                # the depth cap is a scalar of the WHOLE batch (Renderer.py:109,144)
+            sharder.reduce_max(kmax)
         rays_o, rays_d = sbuf[:3 * N].view(N, 3), sbuf[3 * N:6 * N].view(N, 3)
         gt_depth, gt_color = sbuf[6 * N:7 * N], sbuf[7 * N:10 * N].view(N, 3)
         # forward results in ONE buffer: depth | var | dl_depth | zvals (fp64), then raw | rgb | dl_rgb (fp32)
@@ -183,7 +185,8 @@ class _MappingLossFn(torch.autograd.Function):
             out.update(rays_o=rays_o, rays_d=rays_d, gt_depth=gt_depth, gt_color=gt_color, keep=keep, kept_max=kmax, depth=depth,
                        uncertainty=var, color=rgb, indices=indices)
         if need_bwd:
-            ctx.state = (a, (renderer, decoders, stage, S, renderer._reduce_hook),
+            ctx.sharder, ctx.loss32 = sharder, Z[3:4]
+            ctx.state = (a, (renderer, decoders, stage, S, None if sharder is None else sharder.collect),
                          ([kmax, F, sbuf, Z, hold], rays_o, rays_d, gt_depth, grids, flats, packed, raw, depth),
                          (need_pose, need_grid, need_par), dl_depth, dl_rgb if stage == "color" else None, Z[4:],
                          (indices, K, n, crop, intr, [tuple(c.shape) for c in c2ws], [c.dtype for c in c2ws], [c.device for c in c2ws]))
@@ -198,8 +201,13 @@ class _MappingLossFn(torch.autograd.Function):
                                             zero_buf=zero_buf)
         indices, K, n, crop, intr, shapes, dtypes, devs = wm
         g_pose = [None] * K
+        gp, pose_base = None, None
         if need_pose:
-            gp = pose_grads(indices, K, n, crop, intr, d_o, d_d, shapes)
+            gp, pose_base = pose_grads(indices, K, n, crop, intr, d_o, d_d, shapes)
+        if ctx.sharder is not None:                            # multi-GPU: ONE packed all-reduce of everything this iteration produced
+            ctx.loss32.copy_(kept[0][3][:2].view(torch.float64).to(torch.float32))
+            ctx.sharder.exchange([("grid_" + s_, g) for s_, g in zip(stage_slots(meta[2]), d_grids) if g is not None], pose_base, ctx.loss32)
+        if need_pose:
             g_pose = [g.to(device=dv, dtype=dt) if nd else None for g, dv, dt, nd in zip(gp, devs, dtypes, ctx.needs_input_grad[1:1 + K])]
         ctx.state = None
         nslots = len(d_grids)
@@ -208,16 +216,17 @@ class _MappingLossFn(torch.autograd.Function):
 
 def mapping_loss(renderer, c, decoders, frames: Sequence[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], pixs_per_image: int,
                  stage: str, w_color: float = 0.2, device=None, indices: Optional[torch.Tensor] = None, coarse_mapper: bool = False,
-                 crop: Optional[Tuple[int, int, int, int]] = None, out: Optional[dict] = None) -> torch.Tensor:
+                 crop: Optional[Tuple[int, int, int, int]] = None, out: Optional[dict] = None, sharder=None) -> torch.Tensor:
     """One mapping iteration's loss (src/Mapper.py:437-493) as a single autograd node.
 
     ``frames``: ``(c2w, depth [H,W], color [H,W,3])`` per frame of the window, in the reference's order; a pose that requires
     grad gets its gradient (local BA).  Samples ``pixs_per_image`` pixels per frame, applies the bounding-box pre-filter as a
     mask, renders ``stage`` and returns ``sum_{kept, gt>0} |gt - depth| (+ w_color * sum_kept |gt_rgb - rgb|`` in the colour
     stage) as an fp64 scalar -- call ``.backward()`` on it directly (it must be the root of the backward pass).
-    ``out`` (optional dict) receives the sampled rays, masks and rendered outputs."""
-    if coarse_mapper or stage == "coarse":
-        raise NotImplementedError("the coarse mapper renders unguided (gt_depth=None): use get_samples_window + render_batch_ray")
+    ``out`` (optional dict) receives the sampled rays, masks and rendered outputs.  ``sharder``: a
+    ``nice_slam_amd.parallel.ShardedMapping`` (multi-GPU; use its ``mapping_loss`` method)."""
+    if coarse_mapper and stage != "coarse":
+        raise ValueError("the coarse mapper optimises in stage 'coarse' (Mapper.py:403-404)")
     dev = torch.device(device) if device is not None else frames[0][1].device
     H0, H1, W0, W1 = crop if crop is not None else (0, renderer.H, 0, renderer.W)
     wmeta, c2ws = _window_meta(H0, H1, W0, W1, pixs_per_image, renderer.W, renderer.fx, renderer.fy, renderer.cx, renderer.cy,
@@ -226,5 +235,5 @@ def mapping_loss(renderer, c, decoders, frames: Sequence[Tuple[torch.Tensor, tor
     grids = _prep_grids(c, stage, dev)
     gates = [_gate(dev, torch.is_grad_enabled() and decoders.sub(s).wants_grad() and
                    (renderer.decoder_grads is None or s in renderer.decoder_grads)) for s in slots]
-    meta = (renderer, decoders, stage, wmeta, w_color, False, out)
+    meta = (renderer, decoders, stage, wmeta, w_color, sharder, out)
     return _MappingLossFn.apply(meta, *c2ws, *[grids[s] for s in slots], *gates)

@@ -229,3 +229,91 @@ class ShardedRenderer:
             self.renderer._gt_max = None
             self.renderer._reduce_hook = None
         return _GatherOutputs.apply(depth, unc, col, lo, hi, sizes, self.group)
+
+
+class ShardedMapping:
+    """The mapping iteration sharded over the ranks of a process group (one process per GPU), built on ``mapping_loss``:
+
+    * every rank draws ITS OWN ``pixs_per_image`` pixels per keyframe (independent draws: the union over ranks is the
+      iteration's batch), renders them and forms its partial loss -- nothing is gathered, the loss is a sum over rays;
+    * one MAX all-reduce of a single float between the sampling kernel and the render: the bounding-box pre-filter's kept
+      rays' maximum depth is a scalar of the WHOLE batch (Renderer.py:109,144) and must agree on every rank;
+    * ONE packed SUM all-reduce per iteration carries everything the backward produced: the frustum-selected voxel rows of
+      every grid gradient (``set_voxel_masks``; dense grid gradients without masks), the flat decoder-gradient blobs, the pose
+      gradients (local BA) and the partial loss.  Gather and scatter around it are one kernel each (``nsr_pack_rows``).
+
+    The grids, decoders and poses are replicated; after ``loss.backward()`` every rank holds the full-batch gradients (inside
+    the voxel masks for the grids), so the replicated optimiser steps stay identical."""
+
+    def __init__(self, renderer, group=None):
+        self.renderer, self.group = renderer, group
+        self._rows = {}
+        self._pending = None
+        self.last_exchange_floats = 0
+        self.last_total_loss = None          # 1-element fp32 tensor: the all-rank loss of the last backward (logging)
+
+    def set_voxel_masks(self, masks):
+        """dict grid key -> bool/uint8 [Z,Y,X] voxel mask (``FrustumSelector.voxel_mask``), identical on every rank;
+        None returns to the dense exchange."""
+        self._rows = {}
+        for k, m in (masks or {}).items():
+            if m is not None:
+                self._rows[k] = torch.as_tensor(m).reshape(-1).ne(0).nonzero().squeeze(1).contiguous()
+
+    def reduce_max(self, kmax: torch.Tensor):
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX, group=self.group)
+
+    def collect(self, d_grids, gflat, publish) -> bool:          # renderer.render_backward hook: park, exchange() follows
+        self._pending = (gflat, publish)
+        return True
+
+    def exchange(self, named_grads, pose_base, loss32):
+        """``named_grads``: [(grid key, channels-last gradient)] of this backward; ``pose_base``: [K,4,4] pose gradients or
+        None; ``loss32``: 1-element fp32 tensor holding this rank's partial loss.  All are summed over the ranks in place."""
+        from . import _capi
+        from .common import _stream
+        gflat, publish = self._pending if self._pending is not None else (None, None)
+        self._pending = None
+        lib = _capi.get_lib()
+        dev = loss32.device
+        rows_arr = (_capi.NsrRows * max(1, len(named_grads)))()
+        n_rows_total, dense = 0, []
+        ng = 0
+        for k, g in named_grads:
+            rows = self._rows.get(k)
+            if rows is None:
+                dense.append(g)
+                continue
+            if rows.device != dev:
+                rows = self._rows[k] = rows.to(dev)
+            if not g.is_contiguous(memory_format=torch.channels_last_3d):
+                raise RuntimeError("ShardedMapping: grid gradients must be channels-last (what render backward produces)")
+            rows_arr[ng].grid, rows_arr[ng].rows, rows_arr[ng].n_rows = g.data_ptr(), rows.data_ptr(), rows.numel()
+            n_rows_total += rows.numel()
+            ng += 1
+        spans = [t for t in (gflat, None if pose_base is None else pose_base.view(-1), loss32) if t is not None]
+        span_arr = (_capi.NsrSpan * len(spans))()
+        for i, t in enumerate(spans):
+            span_arr[i].ptr, span_arr[i].n = t.data_ptr(), t.numel()
+        total = n_rows_total * 32 + sum(t.numel() for t in spans)
+        buf = torch.empty((total,), dtype=torch.float32, device=dev)
+        stream = _stream(dev)
+        lib.check(lib.nsr_pack_rows(rows_arr, ng, span_arr, len(spans), buf.data_ptr(), 0, stream), "nsr_pack_rows")
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        lib.check(lib.nsr_pack_rows(rows_arr, ng, span_arr, len(spans), buf.data_ptr(), 1, stream), "nsr_pack_rows")
+        floats = total
+        for g in dense:                                          # grids without a mask: dense, in place (one more collective each)
+            _, v, _ = _voxel_rows(g)
+            dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+            floats += v.numel()
+        self.last_exchange_floats = floats
+        self.last_total_loss = loss32
+        if publish is not None:
+            publish()
+
+    def mapping_loss(self, c, decoders, frames, pixs_per_image, stage, w_color: float = 0.2, indices=None, out=None):
+        """This rank's share of one mapping iteration (``pixs_per_image`` pixels per frame HERE); returns the rank's partial
+        loss -- ``backward()`` leaves the all-rank gradients on every rank (and the all-rank loss in ``last_total_loss``)."""
+        from .mapping import mapping_loss
+        return mapping_loss(self.renderer, c, decoders, frames, pixs_per_image, stage, w_color=w_color, indices=indices,
+                            coarse_mapper=(stage == "coarse"), out=out, sharder=self)

@@ -197,6 +197,13 @@ def sample_depths(rays_o: torch.Tensor, rays_d: torch.Tensor, gt_depth: Optional
 # --------------------------------------------------------------------------------------------
 # a7: trilinear feature lookup   (decoder.py:168-175 + common.py:269-284 + ATen GridSampler.h)
 # --------------------------------------------------------------------------------------------
+# "index": the restatement below (explicit corner gathers; documents the ATen semantics the kernels reproduce).
+# "grid_sample": call ATen's grid_sampler_3d exactly like the reference does -- same numbers (tests/test_oracle_golden.py),
+# and the op mix of the reference's CPU path (grid_sampler_3d_backward is 59 % of it): bench.py's cpu_baseline
+# leg runs in this mode.
+TRILINEAR_IMPL = "index"
+
+
 def trilinear(grid: torch.Tensor, p: torch.Tensor, bound: torch.Tensor, lo=F32) -> torch.Tensor:
     """``F.grid_sample(grid, vgrid, mode='bilinear', padding_mode='border', align_corners=True)`` for
     a ``[1,C,Z,Y,X]`` grid and points ``p`` (M,3) in world coordinates, restated with index ops.
@@ -213,6 +220,10 @@ def trilinear(grid: torch.Tensor, p: torch.Tensor, bound: torch.Tensor, lo=F32) 
     b = bound.to(device=p.device, dtype=p.dtype)
     g = ((p - b[:, 0]) / (b[:, 1] - b[:, 0])) * 2 - 1.0
     g = g.to(lo)
+    if TRILINEAR_IMPL == "grid_sample":                      # the reference's own call (decoder.py:171-175), verbatim
+        vgrid = g[None, :, None, None].to(lo)
+        c = torch.nn.functional.grid_sample(grid.to(lo), vgrid, padding_mode="border", align_corners=True, mode="bilinear")
+        return c.squeeze(-1).squeeze(-1)[0].transpose(0, 1)
     gv = grid[0].to(lo).permute(1, 2, 3, 0)                  # (Z,Y,X,C) view
 
     def axis(gc, n):

@@ -103,3 +103,105 @@ def test_two_ranks_on_the_hip_renderer(masked):
     if masked:                                                    # last stage rendered: middle -> its masked rows + the decoder blob
         from nice_slam_amd.layout import param_count
         assert int(res[0]["exchange_floats"]) == int(masks["grid_middle"].sum()) * 32 + param_count("middle")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the fused mapping iteration sharded over two ranks (nice_slam_amd.parallel.ShardedMapping): each rank samples its own
+# pixels; one MAX all-reduce (depth cap) + one packed SUM all-reduce (voxel rows, decoder blobs, pose gradients, loss)
+# ----------------------------------------------------------------------------------------------------------------------
+K_FR, M_PIX = 3, 40
+
+
+def _map_frames(sc, dev, grad):
+    H, W = sc["intr"][:2]
+    g = torch.Generator().manual_seed(33)
+    out = []
+    for k in range(K_FR):
+        c2w = sc["c2w"].clone()
+        c2w[:3, 3] += 0.02 * k
+        out.append((c2w.to(dev).requires_grad_(grad), (sc["depth_img"] * (1.0 + 0.05 * k)).to(dev), torch.rand((H, W, 3), generator=g).to(dev)))
+    return out
+
+
+def _map_indices(sc):
+    H, W = sc["intr"][:2]
+    return torch.randint(H * W, (K_FR, 2 * M_PIX), generator=torch.Generator().manual_seed(34))
+
+
+def _map_worker(rank, world, port, masked, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scene_util import make_scene, build_product
+    from nice_slam_amd.parallel import ShardedMapping
+    dev = "cuda:0"
+    sc = make_scene(seed=5, n_rays=8, small=True)
+    renderer, dec, grids = build_product(sc, dev)
+    sh = ShardedMapping(renderer)
+    if masked:
+        sh.set_voxel_masks({k: m.to(dev) for k, m in _masks(grids).items()})
+    idx = _map_indices(sc)[:, rank * M_PIX:(rank + 1) * M_PIX].reshape(-1)
+    out = {}
+    for stage in ("color", "fine"):
+        frames = _map_frames(sc, dev, grad=True)
+        c = {k: v.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) for k, v in grids.items()}
+        for p in dec.parameters():
+            p.requires_grad_(True); p.grad = None
+        loss = sh.mapping_loss(c, dec, frames, M_PIX, stage, indices=idx)
+        loss.backward()
+        out[f"{stage}/loss_total"] = sh.last_total_loss.cpu().numpy().copy()
+        out.update({f"{stage}/d_{k}": v.grad.cpu().numpy().copy() for k, v in c.items() if v.grad is not None})
+        out.update({f"{stage}/dparam/{k}": p.grad.cpu().numpy().copy() for k, p in dec.named_parameters() if p.grad is not None})
+        out.update({f"{stage}/dpose/{i}": f[0].grad.cpu().numpy().copy() for i, f in enumerate(frames)})
+    out["exchange_floats"] = np.array(sh.last_exchange_floats)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_two_ranks_sharded_fused_mapping(masked):
+    import nice_slam_amd as nsa
+    from scene_util import make_scene, build_product, rel_err
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_map_worker, args=(r, 2, port, masked, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sc = make_scene(seed=5, n_rays=8, small=True)
+    renderer, dec, grids = build_product(sc, "cuda:0")
+    masks = _masks(grids)
+    idx = _map_indices(sc).reshape(-1)                               # both ranks' pixels, frame-major
+    for stage in ("color", "fine"):
+        frames = _map_frames(sc, "cuda:0", grad=True)
+        c = {k: v.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) for k, v in grids.items()}
+        for p in dec.parameters():
+            p.requires_grad_(True); p.grad = None
+        loss = nsa.mapping_loss(renderer, c, dec, frames, 2 * M_PIX, stage, indices=idx)
+        loss.backward()
+        for rank in (0, 1):
+            r = res[rank]
+            assert abs(float(r[f"{stage}/loss_total"][0]) - float(loss)) < 1e-5 * abs(float(loss)), (stage, rank)
+            for k, v in c.items():
+                if v.grad is None:
+                    continue
+                got, ref = r[f"{stage}/d_{k}"], v.grad.cpu().numpy()
+                if masked:
+                    m = masks[k].numpy()[None, None].repeat(32, 1)
+                    got, ref = got[m], ref[m]
+                assert rel_err(got, ref) < 2e-6, (masked, stage, rank, k)
+            for k, p in dec.named_parameters():
+                if p.grad is not None:
+                    assert rel_err(r[f"{stage}/dparam/{k}"], p.grad.cpu().numpy()) < 2e-5, (masked, stage, rank, k)
+            for i, f in enumerate(frames):
+                assert rel_err(r[f"{stage}/dpose/{i}"], f[0].grad.cpu().numpy()) < 1e-4, (masked, stage, rank, i)
+    if masked:
+        from nice_slam_amd.layout import param_count
+        want = sum(int(masks[k].sum()) for k in ("grid_middle", "grid_fine")) * 32 + param_count("middle") + param_count("fine") + K_FR * 16 + 1
+        assert int(res[0]["exchange_floats"]) == want

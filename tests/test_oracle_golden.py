@@ -98,3 +98,21 @@ def test_backward_matches_reference(golden, stage):
         else:
             assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
     assert n_checked > 5
+
+
+def test_oracle_grid_sample_mode_equals_index_mode():
+    """oracle.TRILINEAR_IMPL = "grid_sample" calls ATen's grid_sampler_3d like the reference (decoder.py:173); the explicit
+    restatement must give the same outputs and gradients (this is also what bench.py's cpu_baseline leg executes)."""
+    import torch
+    from oracle import nice_oracle as orc
+    from scene_util import make_scene, oracle_render, rel_err
+    sc = make_scene(seed=9, n_rays=40, small=True)
+    a = oracle_render(sc, "color", backward=True)
+    try:
+        orc.TRILINEAR_IMPL = "grid_sample"
+        b = oracle_render(sc, "color", backward=True)
+    finally:
+        orc.TRILINEAR_IMPL = "index"
+    assert set(a) == set(b)
+    for k in a:
+        assert rel_err(b[k], a[k]) < 2e-5, (k, rel_err(b[k], a[k]))
