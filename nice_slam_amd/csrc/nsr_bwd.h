@@ -242,9 +242,10 @@ NSR_DEV void flush_acc(ACC &A, float *wl, const float *aux, float *scratch, floa
             stream_st(st, t & 31, fcb_off(KX, i), v);
         }
     }
-    // ---- weight tiles: sum the four waves' accumulators through LDS (`wl`: the region that held the packed weights) and
+    // ---- weight tiles: sum the four waves' accumulators through LDS (from `wl`, the region that held the packed weights, on) and
     // write the block's image of the flat gradient blob (plain stores; every parameter exactly once)
-    constexpr int RT = packed_total(KIND) / (kBwdWaves * 256);           // tiles per round that fit
+    // (everything from the packed weights to the end of the staging regions is free now: sample / d-raw buffers included)
+    constexpr int RT = (packed_total(KIND) + kBwdWaves * bwd_stg_floats(KIND)) / (kBwdWaves * 256);   // tiles per round that fit
     constexpr int NT = ntiles_of(KIND), NR = (NT + RT - 1) / RT;
     static_assert(RT >= 1, "reduction buffer too small");
     float *red = wl;

@@ -34,19 +34,23 @@ class TorchMaskedAdam:
 
 
 class OracleOps:
-    def __init__(self, seq, seed=0):
-        self.device = torch.device("cpu")
+    def __init__(self, seq, seed=0, device="cpu", grids=None, params=None):
+        """``device="cuda:0"``: the same oracle functions on the GPU, i.e. the reference's operator sequence on stock ATen /
+        rocBLAS kernels (tests/perf/ate_compare.py); ``grids`` / ``params``: start from given values (e.g. the product's)."""
+        self.device = torch.device(device)
         g = torch.Generator().manual_seed(seed)
         self.bound = orc.scene_bound(seq.bound_cfg, 1.0, 0.32)
-        self.bound_dev = self.bound
+        self.bound_dev = self.bound.to(self.device)
         shapes = orc.grid_shapes(self.bound, GRID_LEN, 2.0)
-        self.c = {k: v.requires_grad_(True) for k, v in orc.make_grids(shapes, generator=g).items()}
-        self.P = {k: v.requires_grad_(True) for k, v in orc.init_decoder_params(seed=seed + 1).items()}
+        grids = grids if grids is not None else orc.make_grids(shapes, generator=g)
+        params = params if params is not None else orc.init_decoder_params(seed=seed + 1)
+        self.c = {k: v.detach().to(self.device).contiguous().clone().requires_grad_(True) for k, v in grids.items()}
+        self.P = {k: v.detach().to(self.device).clone().requires_grad_(True) for k, v in params.items()}
         self.seq = seq
 
     def get_samples(self, H0, H1, W0, W1, n, c2w, depth, color):
         s = self.seq
-        idx = torch.randint((H1 - H0) * (W1 - W0), (n,))
+        idx = torch.randint((H1 - H0) * (W1 - W0), (n,), device=self.device)
         return orc.pixel_rays(idx, H0, H1, W0, W1, s.fx, s.fy, s.cx, s.cy, c2w, depth, color)
 
     def render(self, stage, rays_d, rays_o, gt_depth, gt_max=None):
@@ -58,7 +62,7 @@ class OracleOps:
 
     def keep_mask(self, rays_o, rays_d, gt_depth):
         with torch.no_grad():                       # Mapper.py:471-481 / Tracker.py:95-104, fp64 by promotion
-            t = (self.bound.unsqueeze(0) - rays_o.detach().unsqueeze(-1)) / rays_d.detach().unsqueeze(-1)
+            t = (self.bound_dev.unsqueeze(0) - rays_o.detach().unsqueeze(-1)) / rays_d.detach().unsqueeze(-1)
             t, _ = torch.min(torch.max(t, dim=2)[0], dim=1)
             keep = t >= gt_depth
             kmax = torch.where(keep, gt_depth, torch.zeros_like(gt_depth)).max().reshape(1)
@@ -69,14 +73,14 @@ class OracleOps:
 
     def frustum_masks(self, c2w, depth):
         s = self.seq
-        c = c2w.detach().numpy().astype(np.float32)
+        c = c2w.detach().cpu().numpy().astype(np.float32)
         if c.shape[0] == 3:
             c = np.concatenate([c, np.array([[0, 0, 0, 1]], dtype=np.float32)], 0)
         out = {}
         for k, v in self.c.items():
             if k != "grid_coarse":
-                m = fo.get_mask_from_c2w(c, k, tuple(v.shape[2:]), depth.numpy(), self.bound.numpy(), s.H, s.W, s.fx, s.fy, s.cx, s.cy)
-                out[k] = torch.from_numpy(np.ascontiguousarray(m.transpose(2, 1, 0)))
+                m = fo.get_mask_from_c2w(c, k, tuple(v.shape[2:]), depth.cpu().numpy(), self.bound.numpy(), s.H, s.W, s.fx, s.fy, s.cx, s.cy)
+                out[k] = torch.from_numpy(np.ascontiguousarray(m.transpose(2, 1, 0))).to(self.device)
         return out
 
     def grid_optimizer(self, masks):

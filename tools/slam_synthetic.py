@@ -152,9 +152,10 @@ class SyntheticSequence:
 class ProductOps:
     """nice_slam_amd on an AMD GPU: channels-last grids, NICE decoders (random init), HIP renderer, fused grid Adam."""
 
-    def __init__(self, seq: SyntheticSequence, device, seed=0):
+    def __init__(self, seq: SyntheticSequence, device, seed=0, fused=False):
         import types
         import nice_slam_amd as nsa
+        self.fused = fused           # mapping iterations through nice_slam_amd.mapping_loss, replayed from hipGraphs
         from nice_slam_amd.common import set_decoder_bounds
         self.nsa, self.device = nsa, torch.device(device)
         cfg = {"scale": 1, "occupancy": True, "coarse": True, "mapping": {"bound": seq.bound_cfg},
@@ -313,6 +314,8 @@ class MiniSLAM:
         BA = len(self.keyframe_list) > 4 and mc["BA"]
 
         masks = ops.frustum_masks(cur_c2w, depth)                        # Mapper.py:315-318, once per call
+        if getattr(ops, "fused", False):
+            return self._optimize_map_fused(n_iters, lr_factor, color, depth, cur_c2w, frames, oldest, BA, pix, masks)
         opt_grid = ops.grid_optimizer(masks)
         dec_params = ops.color_decoder_params()
         groups = [{"params": dec_params, "lr": 0.0}]
@@ -378,6 +381,75 @@ class MiniSLAM:
                 else:
                     cur_c2w = to44(get_camera_from_tensor(cams[-1].detach())).clone()
             return cur_c2w
+        return None
+
+    # -- the same call on the fused path: every iteration is ONE autograd node (nice_slam_amd.mapping_loss: window sampling +
+    # render + loss) followed by capturable optimisers; per stage, the first iteration runs eagerly, is then recorded into a
+    # hipGraph, and the remaining iterations of the stage are replays (no host work, no host-side scalars).
+    def _optimize_map_fused(self, n_iters, lr_factor, color, depth, cur_c2w, frames, oldest, BA, pix, masks):
+        mc, ops, nsa = self.cfg["mapping"], self.ops, self.ops.nsa
+        keys = ("grid_middle", "grid_fine", "grid_color")
+        gopt = nsa.MaskedGridAdam({k: ops.c[k] for k in keys}, masks, capturable=True)
+        groups = [{"params": ops.color_decoder_params(), "lr": 0.0}]
+        cams, cam_of = [], {}
+        if BA:
+            for f in frames:
+                if f != oldest:
+                    c2w = self.keyframe_dict[f]["est_c2w"] if f != -1 else cur_c2w
+                    cam_of[f] = len(cams)
+                    cams.append(get_tensor_from_camera(c2w.to(self.device)).requires_grad_(True))
+            groups.append({"params": cams, "lr": 0.0})
+        opt = torch.optim.Adam(groups, capturable=True, foreach=True)
+        data = []
+        for f in frames:
+            if f != -1:
+                kf = self.keyframe_dict[f]
+                data.append((f, kf["depth"].to(self.device), kf["color"].to(self.device), kf["est_c2w"].to(self.device).float()))
+            else:
+                data.append((f, depth, color, cur_c2w.float()))
+        loss_buf = torch.zeros(1, dtype=torch.float64, device=self.device)
+
+        def iteration(stage):
+            opt.zero_grad(set_to_none=True)
+            ops.zero_grads()
+            fr = [(get_camera_from_tensor(cams[cam_of[f]]) if f in cam_of else c2w, d, c) for f, d, c, c2w in data]
+            loss = nsa.mapping_loss(ops.renderer, ops.c, ops.decoders, fr, pix, stage, w_color=mc["w_color_loss"])
+            loss.backward()
+            opt.step()
+            st = mc["stage"][stage]
+            with torch.no_grad():
+                gopt.step({"grid_middle": st["middle_lr"] * lr_factor, "grid_fine": st["fine_lr"] * lr_factor,
+                           "grid_color": st["color_lr"] * lr_factor})
+            loss_buf.copy_(loss.detach().reshape(1))
+
+        n_mid = min(n_iters, int(n_iters * mc["middle_iter_ratio"]) + 1)
+        n_fine = max(0, min(n_iters, int(n_iters * mc["fine_iter_ratio"]) + 1) - n_mid)
+        for stage, cnt in (("middle", n_mid), ("fine", n_fine), ("color", n_iters - n_mid - n_fine)):
+            if cnt <= 0:
+                continue
+            opt.param_groups[0]["lr"] = mc["stage"][stage]["decoders_lr"] * lr_factor
+            if BA and stage == "color":
+                opt.param_groups[1]["lr"] = mc["BA_cam_lr"]
+            iteration(stage)                                              # eager: also initialises optimiser state
+            if cnt > 3:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    iteration(stage)
+                for _ in range(cnt - 1):
+                    graph.replay()
+                del graph
+            else:
+                for _ in range(cnt - 1):
+                    iteration(stage)
+            self.counters["mapping_iters"] += cnt
+            self.counters["mapping_rays"] += cnt * pix * len(frames)
+        self.last_map_loss = float(loss_buf.item())                      # the only host read of the call
+        if BA:                                                             # Mapper.py:527-541
+            for f in frames:
+                if f in cam_of and f != -1:
+                    self.keyframe_dict[f]["est_c2w"] = to44(get_camera_from_tensor(cams[cam_of[f]].detach())).clone()
+            return to44(get_camera_from_tensor(cams[cam_of[-1]].detach())).clone()
         return None
 
     # -- Tracker.run + Mapper.run, strict synchronisation (Tracker.py:150-260, Mapper.py:547-657)
@@ -452,6 +524,8 @@ def main():
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--gt-mapping-pose", action="store_true", help="diagnostic: mapper uses ground-truth poses")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="mapping through get_samples / render_batch_ray / torch losses, eagerly (default: "
+                                                            "nice_slam_amd.mapping_loss + capturable optimisers, replayed from hipGraphs)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     import copy
@@ -462,7 +536,7 @@ def main():
     cfg["tracking"]["iters"] = args.track_iters
     torch.manual_seed(args.seed)
     seq = SyntheticSequence(args.frames, args.height, args.width, device=dev, step_deg=args.step_deg, seed=args.seed)
-    ops = ProductOps(seq, dev, seed=args.seed)
+    ops = ProductOps(seq, dev, seed=args.seed, fused=not args.unfused)
     slam = MiniSLAM(ops, seq, cfg, seed=args.seed, verbose=args.verbose, gt_mapping_pose=args.gt_mapping_pose)
     t0 = time.perf_counter()
     res = slam.run()
@@ -470,8 +544,10 @@ def main():
     res["wall_s"] = round(time.perf_counter() - t0, 2)
     res["config"] = {"frames": args.frames, "image": [args.height, args.width], "keyframe_every": args.keyframe_every,
                      "iters_first": args.iters_first, "map_iters": args.map_iters, "track_iters": args.track_iters,
-                     "every_frame": args.every_frame, "BA": not args.no_ba, "step_deg": args.step_deg, "decoders": "random init (no pretrained weights in this environment)",
+                     "every_frame": args.every_frame, "BA": not args.no_ba, "mapping_path": "unfused, eager" if args.unfused else "fused + hipGraph replay", "step_deg": args.step_deg, "decoders": "random init (no pretrained weights in this environment)",
                      "grids": {k: list(v.shape[2:]) for k, v in ops.c.items()}}
+    res["mapping_ms_per_iter"] = round(1e3 * res["mapping_s"] / max(1, res["mapping_iters"]), 4)
+    res["tracking_ms_per_iter"] = round(1e3 * res["tracking_s"] / max(1, res["tracking_iters"]), 4)
     res["metric"] = "ATE RMSE [cm] on a synthetic RGB-D sequence"
     res["value"] = res["ate"]["rmse"] * 100
     print(json.dumps(res))
