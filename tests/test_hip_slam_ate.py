@@ -1,0 +1,39 @@
+"""GPU: ATE of a short synthetic RGB-D sequence, product vs the reference's operator sequence (BASELINE.json north_star:
+"ATE within 0.5 cm of reference").  tools/slam_synthetic.MiniSLAM (the reference's tracker + mapper loops, strict sync) runs
+twice from identical grids / decoders: on nice_slam_amd (fused mapping iterations replayed from hipGraphs, HIP kernels) and on
+the oracle functions executed on the same GPU (stock ATen / rocBLAS kernels, the reference's ops).  ATE = the reference's
+Horn alignment + translational RMSE (tools/ate.py, pinned to src/tools/eval_ate.py by tests/golden/ate_golden.npz)."""
+import copy
+import os
+import sys
+import types
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ate_product_within_half_a_cm_of_the_reference_ops():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "perf"))
+    import slam_synthetic as ss
+    import ate_compare as ac
+    dev = torch.device("cuda", 0)
+    args = types.SimpleNamespace(seed=0)
+    cfg = copy.deepcopy(ss.DEFAULT_CFG)
+    cfg["mapping"].update({"iters": 100, "every_frame": 2, "iters_first": 400, "keyframe_every": 4})
+    seq = ss.SyntheticSequence(14, 120, 160, device=dev, seed=0)
+    torch.manual_seed(0)
+    p0 = ss.ProductOps(seq, dev, seed=0)
+    init = {"grids": {k: v.detach().cpu().contiguous().clone() for k, v in p0.c.items()},
+            "params": {k: v.detach().cpu().clone() for k, v in p0.decoders.state_dict().items()}}
+    del p0
+    res = {k: ac.run(k, args, seq, cfg, init) for k in ("fused", "aten")}
+    ate = {k: r["ate"]["rmse"] * 100 for k, r in res.items()}
+    print("ATE [cm]:", ate, "mapping iters", res["fused"]["mapping_iters"], "tracking iters", res["fused"]["tracking_iters"])
+    assert res["fused"]["mapping_iters"] == res["aten"]["mapping_iters"] and res["fused"]["tracking_iters"] == res["aten"]["tracking_iters"]
+    assert ate["aten"] < 3.0, ate                       # the reference path itself holds the trajectory on this sequence
+    assert abs(ate["fused"] - ate["aten"]) < 0.5, ate
