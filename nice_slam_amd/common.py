@@ -7,7 +7,10 @@ from __future__ import annotations
 
 from typing import Dict, Optional, Tuple
 
+import warnings
+
 import numpy as np
+
 import torch
 
 from . import _capi
@@ -65,6 +68,20 @@ def grid_shapes(cfg: dict, bound: torch.Tensor) -> Dict[str, Tuple[int, int, int
     return out
 
 
+_WARNED_NCDHW = False
+
+
+def warn_ncdhw_once(grid: torch.Tensor, what: str):
+    """A grid handed to a per-iteration entry point in NCDHW order is re-laid out (a full copy forward, a permuted
+    gradient backward) on EVERY call: legal, slow, and said once."""
+    global _WARNED_NCDHW
+    if not _WARNED_NCDHW and not grid.is_contiguous(memory_format=torch.channels_last_3d):
+        _WARNED_NCDHW = True
+        warnings.warn(f"nice_slam_amd: {what} is not in torch.channels_last_3d memory order; it is copied into that order on "
+                      "every call.  Allocate grids with grid_init() / to_channels_last() once (INTEGRATION.md section 2).",
+                      RuntimeWarning, stacklevel=4)
+
+
 def to_channels_last(grid: torch.Tensor) -> torch.Tensor:
     """Logical [1,C,Z,Y,X] tensor whose memory is [Z][Y][X][C] (what the kernels read).  No-op if it already is."""
     return grid.contiguous(memory_format=torch.channels_last_3d)
@@ -78,7 +95,7 @@ def grid_init(cfg: dict, bound: torch.Tensor, device="cpu") -> Dict[str, torch.T
     for key, zyx in grid_shapes(cfg, bound).items():
         std = 1e-4 if key == "grid_fine" else 1e-2
         val = torch.zeros((1, c_dim) + tuple(zyx)).normal_(mean=0, std=std)
-        out[key] = to_channels_last(val.to(device))
+        out[key] = val.to(device).contiguous(memory_format=torch.channels_last_3d)
     return out
 
 

@@ -2,7 +2,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
+#include <utility>
 
 #include "nsr_rt.h"
 #include "nsr_kernels.h"
@@ -45,6 +48,50 @@ int max_param_count(int stage) {
 int bwd_blocks(long long n_groups, int max_blocks) {
     long long cap = max_blocks > 0 ? max_blocks : kDefaultBwdBlocks;
     return (int)(n_groups < cap ? n_groups : cap);
+}
+
+// Share the blocks of one backward launch among the decoder passes of the stage.  A block serves ONE pass (that decoder's
+// operand stream sits in its LDS, its parameter-gradient accumulators in its registers) and one block fits a CU, so the
+// launch is sized to one block per CU and the passes must finish together: pass p with n_p blocks takes
+// ceil(G / n_p) * w_p + f_p (w: one ray group's tiles, f: the block's fixed costs -- operand stream into LDS, first
+// touches, accumulator flush).  Greedy: every pass starts with one block; the pass that would finish last gets the next.
+// w, f in kilo-cycles measured with tests/perf/ts_probe.py on MI355X (profiles/r02_ts/); passes without parameter
+// gradients run the lighter specialisation.  `max_blocks` > 0 (tests): at most that many blocks per pass.
+void bwd_partition(const nsr::RenderParams &P, int max_blocks, int first[4]) {
+    static const double kW[4] = {60.0, 100.0, 255.0, 141.0}, kF[4] = {30.0, 45.0, 60.0, 53.0};     // coarse, middle, fine, colour
+    static double w_env[4], f_env[4];
+    static const bool have_env = [] {
+        const char *e = getenv("NSR_BWD_COST");             // tuning aid: "w_coarse,w_middle,w_fine,w_color,f_coarse,...,f_color"
+        if (!e) return false;
+        double v[8];
+        if (sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf,%lf,%lf", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7) != 8) return false;
+        for (int i = 0; i < 4; ++i) { w_env[i] = v[i]; f_env[i] = v[4 + i]; }
+        return true;
+    }();
+    const long long G = P.n_groups;
+    int slots[3], n[3] = {0, 0, 0}, np = 0;
+    if (P.stage == NSR_STAGE_COARSE) slots[np++] = NSR_COARSE;
+    else for (int s = NSR_MIDDLE; s <= P.stage; ++s) slots[np++] = s;
+    double w[3], f[3];
+    for (int i = 0; i < np; ++i) {
+        const bool params = P.dec[slots[i]].dparams != nullptr;
+        w[i] = (have_env ? w_env : kW)[slots[i]] * (params ? 1.0 : 0.65);
+        f[i] = (have_env ? f_env : kF)[slots[i]] * (params ? 1.0 : 0.5);
+        n[i] = 1;
+    }
+    const long long per_pass = max_blocks > 0 ? max_blocks : kDefaultBwdBlocks;
+    const long long cap = G < per_pass ? G : per_pass;                    // a pass never gets more blocks than groups
+    long long budget = (max_blocks > 0 ? (long long)np * max_blocks : kDefaultBwdBlocks) - np;
+    auto cost = [&](int i) { return (double)((G + n[i] - 1) / n[i]) * w[i] + f[i]; };
+    for (; budget > 0; --budget) {                     // (ceil(G/n) is a step function: the same pass may be chosen several times
+        int worst = -1;                                // in a row before its cost drops)
+        for (int i = 0; i < np; ++i)
+            if (n[i] < cap && (worst < 0 || cost(i) > cost(worst))) worst = i;
+        if (worst < 0) break;
+        ++n[worst];
+    }
+    first[0] = 0;
+    for (int i = 0; i < 3; ++i) first[i + 1] = first[i] + (i < np ? n[i] : 0);
 }
 
 // validate + translate the public argument block
@@ -105,15 +152,21 @@ int finish(const char *what) {
     return 0;
 }
 
-// raise the dynamic-LDS limit of a kernel once per process and size (not a stream operation, but kept out of the
-// steady state so that a captured hipGraph contains kernel launches only)
+// raise the dynamic-LDS limit of a kernel once per (kernel, device, size): not a stream operation, but kept out of the
+// steady state so that a captured hipGraph contains kernel launches only.  Keyed by the kernel's ADDRESS (all render
+// kernels share one function-pointer type) and the current device.
 template <typename K>
 int launch_cfg(K kernel, int lds_bytes, const char *what) {
     if (lds_bytes > kLdsLimit) return fail(std::string(what) + ": LDS budget exceeded");
-    static thread_local int granted = 0;         // one instance per kernel type K
-    if (lds_bytes > 48 * 1024 && lds_bytes > granted) {
+    if (lds_bytes <= 48 * 1024) return 0;
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, int> granted;
+    const std::pair<const void *, int> key(reinterpret_cast<const void *>(kernel), nsr::rt_current_device());
+    std::lock_guard<std::mutex> lock(mu);
+    int &g = granted[key];
+    if (lds_bytes > g) {
         if (const char *e = nsr::rt_allow_lds(kernel, lds_bytes)) return fail(std::string(what) + ": " + e);
-        granted = lds_bytes;
+        g = lds_bytes;
     }
     return 0;
 }
@@ -200,20 +253,20 @@ int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream
 #ifdef NSR_TS
     if (const char *e = getenv("NSR_DBG_PTR")) P.dbg = reinterpret_cast<long long *>(strtoull(e, nullptr, 16));
 #endif
-    const int passes = stage_passes(P.stage);
-    const int nblk = bwd_blocks(P.n_groups, b->max_blocks);
+    bwd_partition(P, b->max_blocks, P.pass_first);
+    const int nblk = P.pass_first[3];
     bool any_params = false;
     for (int s = 0; s < 4; ++s) any_params |= P.dec[s].dparams != nullptr;
     P.partial_stride = max_param_count(P.stage);
     if (any_params) {
-        const long long need = (long long)passes * nblk * P.partial_stride;
+        const long long need = (long long)nblk * P.partial_stride;
         if (!b->workspace || b->workspace_floats < need) return fail("nsr_render_bwd: workspace too small");
         P.partials = b->workspace;
     }
     const int npts = P.rays_per_block * P.S;
     const int waves = kBwdWaves;
     const int lds = bwd_lds_bytes(P.stage, npts, P.rays_per_block, waves);
-    const dim3 grid(nblk, passes), block(64 * waves);
+    const dim3 grid(nblk), block(64 * waves);
 #define NSR_BWD(ST)                                                                              \
     case ST:                                                                                     \
         if (int rc = launch_cfg(nsr::render_bwd_kernel<ST>, lds, "nsr_render_bwd")) return rc;    \
@@ -228,18 +281,19 @@ int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream
         const int first = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE;
         const int last = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : P.stage;
         nsr::ReduceParams R;
-        R.nblocks = nblk; R.stride = P.partial_stride; R.overwrite = b->overwrite_dparams ? 1 : 0;
+        R.stride = P.partial_stride; R.overwrite = b->overwrite_dparams ? 1 : 0;
         int rows = 0, nmax = 0;
         for (int s = first; s <= last; ++s) {
             if (!P.dec[s].dparams) continue;
             const int pass = P.stage == NSR_STAGE_COARSE ? 0 : s - NSR_MIDDLE;
-            R.job[rows].partials = P.partials + (long long)pass * nblk * P.partial_stride;
+            R.job[rows].partials = P.partials + (long long)P.pass_first[pass] * P.partial_stride;
+            R.job[rows].nblocks = P.pass_first[pass + 1] - P.pass_first[pass];
             R.job[rows].dparams = P.dec[s].dparams;
             R.job[rows].n = nsr::param_total(s);
             nmax = nmax > R.job[rows].n ? nmax : R.job[rows].n;
             ++rows;
         }
-        for (int r = rows; r < 3; ++r) R.job[r] = nsr::ReduceJob{nullptr, nullptr, 0};
+        for (int r = rows; r < 3; ++r) R.job[r] = nsr::ReduceJob{nullptr, nullptr, 0, 0};
         const int tb = 1024;                                      // 64 parameters x 16 slices of the partial list
         NSR_LAUNCH(nsr::reduce_partials_kernel, dim3((nmax + 63) / 64, rows), dim3(tb), tb * 4, stream, R);
         if (int rc = finish("nsr_render_bwd(reduce)")) return rc;

@@ -610,8 +610,10 @@ struct TileCtx {
     Lvl L;
 };
 
+// `blk` / `nblk`: this block's index among the `nblk` blocks of the pass (it takes the ray groups blk, blk + nblk, ...);
+// `gblk`: its index in the launch (partial image, profiling slot).
 template <int KIND, bool PARAMS>
-NSR_DEV void bwd_pass(const RenderParams &P) {
+NSR_DEV void bwd_pass(const RenderParams &P, const int blk, const int nblk, const int gblk) {
     char *lds = lds_base();
     const int npts = P.rays_per_block * P.S, S = P.S;
     const int lane = tid() & 63, wave = tid() >> 6, nwaves = nthreads() >> 6;
@@ -635,8 +637,10 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
     F.rays = P.d_rays_o != nullptr;
     if (!F.grid && !F.params && !F.rays) return;
 
-    const Dbg dbg{P.dbg ? P.dbg + (((long long)bid_y() * nblk_x() + bid_x()) * kBwdWaves + wave) * 64 : nullptr};
+    const Dbg dbg{P.dbg ? P.dbg + ((long long)gblk * kBwdWaves + wave) * 64 : nullptr};
     dbg.stamp(0);
+    dbg.note(61, KIND + 1);                                  // the probe's key: which pass this block served, how many blocks it had
+    dbg.note(62, nblk);
     typename AccOf<KIND>::type A;
     if (PARAMS) {
         acc_zero(A);
@@ -659,7 +663,7 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
         return make_level(P.grid[KIND == NSR_FINE ? NSR_MIDDLE : KIND], px, py, pz);     // fine: the cell of the middle grid too
     };
 
-    for (long long grp = bid_x(); grp < P.n_groups; grp += nblk_x()) {
+    for (long long grp = blk; grp < P.n_groups; grp += nblk) {
         loop_fence();
         const long long ray0 = grp * P.rays_per_block;
         // Every independent global load of the group is issued before anything waits (a short-lived block pays a TLB miss
@@ -694,7 +698,7 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
         if (c_act) draw[lane] = F4{c_rw.x + (float)c_gD, c_rw.y + (float)c_gV, c_rw.z + c_gr + c_gg + c_gb, c_rw.w + (float)c_dep};
         dbg.stamp(60);
 #endif
-        if (grp == (long long)bid_x()) {
+        if (grp == (long long)blk) {
             copy_f4<(AUX_FLOATS + packed_total(KIND)) / 4>(aux, D.packed);      // visible after the barrier below
             dbg.stamp(1);
         }
@@ -835,7 +839,7 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
         }
     }
     if (PARAMS) {
-        float *img = P.partials + ((long long)bid_y() * nblk_x() + bid_x()) * P.partial_stride;
+        float *img = P.partials + (long long)gblk * P.partial_stride;
         if constexpr (KIND != NSR_COARSE) {                      // LDS-resident accumulator tiles join the others
 #pragma unroll
             for (int Tk = 0; Tk < lds_acc_ktiles(KIND); ++Tk) {
@@ -848,18 +852,23 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
     dbg.stamp(7);
 }
 
+// grid = one row of blocks; the launch gives every decoder pass its own contiguous share of them (pass_first), sized by the
+// host so that the passes finish together: a block pays its fixed costs (operand stream into LDS, accumulator flush) once
+// and then takes several ray groups of ITS pass, instead of one short-lived block per (group, pass).
 template <int STAGE>
 NSR_KERNEL NSR_BOUNDS(64 * kBwdWaves) void render_bwd_kernel(const RenderParams P) {
+    const int b = bid_x();
     if (STAGE == NSR_STAGE_COARSE) {
-        if (P.dec[NSR_COARSE].dparams) bwd_pass<NSR_COARSE, true>(P); else bwd_pass<NSR_COARSE, false>(P);
+        if (P.dec[NSR_COARSE].dparams) bwd_pass<NSR_COARSE, true>(P, b, nblk_x(), b); else bwd_pass<NSR_COARSE, false>(P, b, nblk_x(), b);
     } else {
-        const int pass = bid_y();
+        const int pass = (b >= P.pass_first[1]) + (b >= P.pass_first[2]);
+        const int blk = b - P.pass_first[pass], nblk = P.pass_first[pass + 1] - P.pass_first[pass];
         if (pass == 0) {
-            if (P.dec[NSR_MIDDLE].dparams) bwd_pass<NSR_MIDDLE, true>(P); else bwd_pass<NSR_MIDDLE, false>(P);
+            if (P.dec[NSR_MIDDLE].dparams) bwd_pass<NSR_MIDDLE, true>(P, blk, nblk, b); else bwd_pass<NSR_MIDDLE, false>(P, blk, nblk, b);
         } else if (pass == 1) {
-            if (STAGE >= NSR_STAGE_FINE) { if (P.dec[NSR_FINE].dparams) bwd_pass<NSR_FINE, true>(P); else bwd_pass<NSR_FINE, false>(P); }
+            if (STAGE >= NSR_STAGE_FINE) { if (P.dec[NSR_FINE].dparams) bwd_pass<NSR_FINE, true>(P, blk, nblk, b); else bwd_pass<NSR_FINE, false>(P, blk, nblk, b); }
         } else {
-            if (STAGE == NSR_STAGE_COLOR) { if (P.dec[NSR_COLOR].dparams) bwd_pass<NSR_COLOR, true>(P); else bwd_pass<NSR_COLOR, false>(P); }
+            if (STAGE == NSR_STAGE_COLOR) { if (P.dec[NSR_COLOR].dparams) bwd_pass<NSR_COLOR, true>(P, blk, nblk, b); else bwd_pass<NSR_COLOR, false>(P, blk, nblk, b); }
         }
     }
 }

@@ -78,6 +78,13 @@ struct Dbg {
         (void)slot;
 #endif
     }
+    NSR_DEV void note(int slot, long long v) const {
+#ifdef NSR_TS
+        if (p && (threadIdx.x & 63) == 0) p[slot] = v;
+#else
+        (void)slot; (void)v;
+#endif
+    }
 };
 
 NSR_DEV void atomic_add_global(float *p, float v) { unsafeAtomicAdd(p, v); }

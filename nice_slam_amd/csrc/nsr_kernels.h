@@ -73,8 +73,9 @@ struct RenderParams {
     const double *d_depth, *d_var, *g_depth;
     const float *d_rgb;
     float *d_rays_o, *d_rays_d;
-    float *partials;          // [3 passes][gridDim.x][max param count]
+    float *partials;          // [block of the launch][max param count]
     int partial_stride;       // floats between two blocks' partial images
+    int pass_first[4];        // backward launch: blocks [pass_first[p], pass_first[p+1]) work on decoder pass p (nsr_api.cpp: bwd_partition)
     // fused mapping loss (Mapper.py:487-493), optional
     const float *loss_depth;  // [N] sensor depth of the loss (also set where the SAMPLING is unguided: coarse mapper, Mapper.py:484-489)
     const float *gt_color;    // [N][3]
@@ -872,10 +873,11 @@ struct ReduceJob {
     const float *partials;   // [nblocks][stride] of this pass
     float *dparams;          // flat gradient blob of the decoder (accumulated into)
     int n;                   // its parameter count (0: nothing to do for this row)
+    int nblocks;             // blocks that worked on this pass
 };
 struct ReduceParams {
     ReduceJob job[3];
-    int nblocks, stride;
+    int stride;
     int overwrite;           // 1: dparams = sum (no caller-side zero fill needed), 0: dparams += sum
 };
 NSR_KERNEL void reduce_partials_kernel(const ReduceParams R) {
@@ -886,7 +888,7 @@ NSR_KERNEL void reduce_partials_kernel(const ReduceParams R) {
     if (bid_x() * 64 >= J.n) return;                     // whole block beyond this decoder's blob (uniform)
     float s = 0.f;
     if (t < J.n)
-        for (int b = slice; b < R.nblocks; b += nslice) s += J.partials[(long long)b * R.stride + t];
+        for (int b = slice; b < J.nblocks; b += nslice) s += J.partials[(long long)b * R.stride + t];
     red[tid()] = s;
     block_sync();
     if (slice == 0 && t < J.n) {

@@ -8,6 +8,7 @@ inline const char *rt_check_last() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? nullptr : hipGetErrorString(e);
 }
+inline int rt_current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 inline void rt_record(void *event, void *stream) { (void)hipEventRecord((hipEvent_t)event, (hipStream_t)stream); }
 template <typename K>
 inline const char *rt_allow_lds(K kernel, int bytes) {

@@ -12,7 +12,7 @@ from typing import Dict, Optional
 import torch
 
 from . import _capi
-from .common import _as_f32c, _require_cuda, _stream, get_rays, to_channels_last
+from .common import _as_f32c, _require_cuda, _stream, get_rays, to_channels_last, warn_ncdhw_once
 from .layout import param_count, stage_slots
 
 _SLOT_IDX = {s: i for i, s in enumerate(_capi.SLOT_NAMES)}
@@ -65,6 +65,7 @@ def _prep_grids(c: Dict[str, torch.Tensor], stage: str, device) -> Dict[str, tor
             g = g.to(device)
         if g.dtype != torch.float32 or g.dim() != 5 or g.shape[0] != 1 or g.shape[1] != 32:
             raise _capi.NsrError(f"grid_{s}: expected fp32 [1,32,Z,Y,X], got {g.dtype} {tuple(g.shape)}")
+        warn_ncdhw_once(g, f"grid_{s}")
         out[s] = to_channels_last(g)           # differentiable; no copy when the grid already is channels-last
     return out
 

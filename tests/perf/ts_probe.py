@@ -34,19 +34,21 @@ for it in range(3):
         depth, unc, col = renderer.render_batch_ray(grids, dec, d, o, dev, stage, gt_depth=gd)
         ((gd - depth).abs().sum() + 0.2 * (gc - col).abs().sum()).backward()
     torch.cuda.synchronize()
-nblk = min(256, (n_rays + 3) // 4)
-t = buf.cpu().numpy()[:3 * nblk * NW * NSLOT].reshape(3, nblk, NW, NSLOT)
+t_all = buf.cpu().numpy().reshape(3 * NBX, NW, NSLOT)            # one row per block of the launch; slot 61 = decoder pass + 1, 62 = its block count
+_ok = (t_all[:, :, 0] > 0) & (t_all[:, :, 7] > 0)
+print(f"kernel span (first entry -> last exit over all blocks): {t_all[:, :, 7][_ok].max() - t_all[:, :, 0][_ok].min()} cycles (s_memtime, 100 MHz ticks x ?: see block lifetimes)")
 blockn = {0: "entry", 1: "aux + packed weights copy issued", 2: "z loaded (barrier)", 3: "tile-0 setup + compositor", 4: "barrier wait (d raw)",
           5: "all tiles", 6: "barrier wait (tiles)", 7: "ray reduce + flush"}
 tilen = ["start (setup / gather wait)", "forward re-run", "output layer", "layer 4", "layer 3", "layer 2", "layer 1", "layer 0 (+W0/W3e)",
          "embedding stage", "dB", "coord grad + scatter"]
 for p_, nm in enumerate(("middle", "fine", "color")[:{"middle": 1, "fine": 2, "color": 3}[stage]]):
-    blk = t[p_]
+    blk = t_all[t_all[:, 0, 61] == p_ + 2]
     ok = (blk[:, :, 0] > 0) & (blk[:, :, 7] > 0)
     if not ok.any():
         continue
     tot = (blk[:, :, 7] - blk[:, :, 0])[ok]
-    print(f"pass {nm}: waves with data {ok.sum()}, block lifetime mean {tot.mean():.0f} cycles (p90 {np.percentile(tot, 90):.0f})")
+    print(f"pass {nm}: {blk.shape[0]} blocks (partition: {int(blk[0, 0, 62])}), block lifetime mean {tot.mean():.0f} cycles (p90 {np.percentile(tot, 90):.0f}, "
+          f"max {tot.max():.0f}); per-group stamps below are those of each block's LAST ray group")
     for s_ in range(1, 8):
         dlt = (blk[:, :, s_] - blk[:, :, s_ - 1])[ok]
         print("   %-36s mean %8.0f  p10 %8.0f  p90 %8.0f   %5.1f %%" % (blockn[s_], dlt.mean(), np.percentile(dlt, 10), np.percentile(dlt, 90), 100 * dlt.mean() / tot.mean()))

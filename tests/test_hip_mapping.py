@@ -55,7 +55,7 @@ def test_window_sampling_is_the_per_frame_loop():
         assert rel_err(got[k], frames[k][0].grad) < 1e-5, k
 
 
-@pytest.mark.parametrize("stage", ["middle", "fine", "color"])
+@pytest.mark.parametrize("stage", ["coarse", "middle", "fine", "color"])
 def test_fused_mapping_loss_equals_unfused_path(stage):
     import nice_slam_amd as nsa
     sc = make_scene(seed=82, n_rays=8, small=True)
@@ -70,11 +70,12 @@ def test_fused_mapping_loss_equals_unfused_path(stage):
         for p in dec.parameters():
             p.requires_grad_(True); p.grad = None
         if fused:
-            loss = nsa.mapping_loss(renderer, c, dec, frames, n, stage, w_color=0.2, indices=idx)
+            loss = nsa.mapping_loss(renderer, c, dec, frames, n, stage, w_color=0.2, indices=idx, coarse_mapper=stage == "coarse")
         else:
             w = nsa.get_samples_window(0, H, 0, W, n, H, W, fx, fy, cx, cy, [f[0] for f in frames], [f[1] for f in frames],
                                        [f[2] for f in frames], sc["bound"], DEV, indices=idx)
-            depth, _, color = renderer.render_batch_ray(c, dec, w.rays_d, w.rays_o, DEV, stage, gt_depth=w.gt_depth, gt_max=w.kept_max)
+            depth, _, color = renderer.render_batch_ray(c, dec, w.rays_d, w.rays_o, DEV, stage, gt_max=w.kept_max,
+                                                        gt_depth=None if stage == "coarse" else w.gt_depth)      # Mapper.py:484
             loss = (torch.abs(w.gt_depth - depth) * (w.keep & (w.gt_depth > 0))).sum()          # Mapper.py:487-493, mask form
             if stage == "color":
                 loss = loss + 0.2 * (torch.abs(w.gt_color - color) * w.keep[:, None]).sum()
@@ -86,7 +87,7 @@ def test_fused_mapping_loss_equals_unfused_path(stage):
     l1, g1, p1, c1 = run(True)
     # (the colour term of the unfused path is an fp32 torch.sum, Mapper.py:491: 1e-7 of summation noise)
     assert abs(l0 - l1) <= (1e-6 if stage == "color" else 1e-9) * abs(l0), (l0, l1)
-    assert set(g0) == set(g1) and set(p0) == set(p1) and len(g0) == {"middle": 1, "fine": 2, "color": 3}[stage]
+    assert set(g0) == set(g1) and set(p0) == set(p1) and len(g0) == {"coarse": 1, "middle": 1, "fine": 2, "color": 3}[stage]
     for k in g0:
         assert rel_err(g1[k], g0[k]) < 1e-5, k
     for k in p0:

@@ -6,8 +6,10 @@ smooth camera path gives depth / colour / ground-truth poses.  The tracker and t
 loops -- Tracker.run / optimize_cam_in_batch (src/Tracker.py:71-128,150-260) and Mapper.run / optimize_map /
 keyframe_selection_overlap (src/Mapper.py:166-228,230-545,547-657), strict synchronisation, single process -- on top of
 the product: get_samples, Renderer.render_batch_ray, NICE decoders, FrustumSelector and MaskedGridAdam.  The coarse-level
-mapper (a separate process in the reference, not read by the tracker's 'color' stage), meshing, visualisation and the
-final colour refinement are not part of this loop.  Decoders are random-init (the reference loads pretrained
+mapper (a separate process in the reference, src/NICE_SLAM.py:288-305; its grid is not read by the tracker's 'color' stage)
+runs after each mapping call when ``coarse_mapper=True`` (the command line's default): 'global' keyframe selection,
+stage 'coarse' throughout, no depth-guided samples, every coarse voxel optimised (Mapper.py:79-80,305-306,403-404,484).
+Meshing, visualisation and the final colour refinement are not part of this loop.  Decoders are random-init (the reference loads pretrained
 middle/fine decoders), so the absolute ATE is not comparable with published numbers; what it shows is that the hot path
 carries a complete tracking + mapping run.
 
@@ -45,7 +47,8 @@ DEFAULT_CFG = {
     "mapping": {"middle_iter_ratio": 0.4, "fine_iter_ratio": 0.6, "every_frame": 5, "BA": True, "BA_cam_lr": 0.001,
                 "keyframe_every": 50, "mapping_window_size": 5, "w_color_loss": 0.2, "lr_first_factor": 5, "lr_factor": 1,
                 "pixels": 1000, "iters_first": 1500, "iters": 60,
-                "stage": {"middle": {"decoders_lr": 0.0, "middle_lr": 0.1, "fine_lr": 0.0, "color_lr": 0.0},
+                "stage": {"coarse": {"decoders_lr": 0.0, "coarse_lr": 0.001},
+                          "middle": {"decoders_lr": 0.0, "middle_lr": 0.1, "fine_lr": 0.0, "color_lr": 0.0},
                           "fine": {"decoders_lr": 0.0, "middle_lr": 0.005, "fine_lr": 0.005, "color_lr": 0.0},
                           "color": {"decoders_lr": 0.005, "middle_lr": 0.005, "fine_lr": 0.005, "color_lr": 0.005}}},
 }
@@ -209,8 +212,11 @@ class ProductOps:
 # tracker + mapper
 # --------------------------------------------------------------------------------------------------------------------
 class MiniSLAM:
-    def __init__(self, ops, seq: SyntheticSequence, cfg=None, seed=0, verbose=False, gt_mapping_pose=False):
+    def __init__(self, ops, seq: SyntheticSequence, cfg=None, seed=0, verbose=False, gt_mapping_pose=False, coarse_mapper=False):
         self.ops, self.seq, self.cfg, self.verbose = ops, seq, cfg or DEFAULT_CFG, verbose
+        self.coarse_mapper = coarse_mapper and getattr(ops, "fused", False)
+        self.coarse_rng = np.random.RandomState(seed + 1)   # its own stream: the coarse mapper is its own process in the reference
+        self.coarse_losses = []
         self.gt_mapping_pose = gt_mapping_pose          # diagnostic: the mapper sees ground-truth poses (isolates tracking)
         self.device = ops.device
         self.H, self.W = seq.H, seq.W
@@ -218,8 +224,8 @@ class MiniSLAM:
         self.gt = [None] * seq.n
         self.keyframe_list, self.keyframe_dict = [], []
         self.np_rng = np.random.RandomState(seed)
-        self.counters = {"tracking_iters": 0, "mapping_iters": 0, "tracking_rays": 0, "mapping_rays": 0}
-        self.timers = {"tracking_s": 0.0, "mapping_s": 0.0}
+        self.counters = {"tracking_iters": 0, "mapping_iters": 0, "tracking_rays": 0, "mapping_rays": 0, "coarse_iters": 0}
+        self.timers = {"tracking_s": 0.0, "mapping_s": 0.0, "coarse_s": 0.0}
 
     # The reference drops the rays whose depth lies outside the bound by boolean-mask compaction (Tracker.py:95-104,
     # Mapper.py:471-481) and indexes its loss terms with further masks -- a host synchronisation each.  Here the batch
@@ -452,6 +458,53 @@ class MiniSLAM:
             return to44(get_camera_from_tensor(cams[cam_of[-1]].detach())).clone()
         return None
 
+    # -- the coarse mapper's optimize_map (Mapper.py:230-545 with coarse_mapper=True): 'global' keyframe selection (:79-80,
+    # 258-260), stage 'coarse' in every iteration (:403-404), no BA (:602-603), rendering without gt_depth (:484), the whole
+    # coarse grid optimised at coarse_lr (:305-306,413).  Same execution scheme as _optimize_map_fused.
+    def optimize_coarse(self, n_iters, lr_factor, color, depth, cur_c2w):
+        mc, ops, nsa = self.cfg["mapping"], self.ops, self.ops.nsa
+        frames = []
+        if len(self.keyframe_dict) > 0:
+            n_old = len(self.keyframe_dict) - 1
+            frames = [int(v) for v in self.coarse_rng.permutation(n_old)[:mc["mapping_window_size"] - 2]]
+            frames = frames + [len(self.keyframe_list) - 1]
+        frames = frames + [-1]
+        pix = mc["pixels"] // len(frames)
+        fr = []
+        for f in frames:
+            if f != -1:
+                kf = self.keyframe_dict[f]
+                fr.append((kf["est_c2w"].to(self.device).float(), kf["depth"].to(self.device), kf["color"].to(self.device)))
+            else:
+                fr.append((cur_c2w.float(), depth, color))
+        gopt = nsa.MaskedGridAdam({"grid_coarse": ops.c["grid_coarse"]}, None, capturable=True)
+        lr = mc["stage"]["coarse"]["coarse_lr"] * lr_factor
+        loss_buf = torch.zeros(2, dtype=torch.float64, device=self.device)
+
+        def iteration(slot):
+            ops.zero_grads()
+            loss = nsa.mapping_loss(ops.renderer, ops.c, ops.decoders, fr, pix, "coarse", w_color=mc["w_color_loss"], coarse_mapper=True)
+            loss.backward()
+            with torch.no_grad():
+                gopt.step({"grid_coarse": lr})
+            loss_buf[slot:slot + 1].copy_(loss.detach().reshape(1))
+
+        iteration(0)
+        if n_iters > 3:
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                iteration(1)
+            for _ in range(n_iters - 1):
+                graph.replay()
+            del graph
+        else:
+            for _ in range(n_iters - 1):
+                iteration(1)
+        self.counters["coarse_iters"] += n_iters
+        first, last = (float(v) for v in loss_buf.tolist())
+        self.coarse_losses.append((first, last))
+
     # -- Tracker.run + Mapper.run, strict synchronisation (Tracker.py:150-260, Mapper.py:547-657)
     def run(self):
         mc = self.cfg["mapping"]
@@ -482,13 +535,19 @@ class MiniSLAM:
                                         mc["lr_first_factor"] if first else mc["lr_factor"], idx, color, depth, cur)
                 if new is not None:
                     self.est[idx] = new.detach()
+                if self.device.type == "cuda":
+                    torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                self.timers["mapping_s"] += t2 - t1
+                if self.coarse_mapper:                       # sees the same keyframe list the mapper just used
+                    self.optimize_coarse(mc["iters_first"] if first else mc["iters"],
+                                         mc["lr_first_factor"] if first else mc["lr_factor"], color, depth, self.est[idx].to(self.device))
+                    torch.cuda.synchronize()
+                    self.timers["coarse_s"] += time.perf_counter() - t2
                 if (idx % mc["keyframe_every"] == 0 or idx == n - 2) and idx not in self.keyframe_list:
                     self.keyframe_list.append(idx)
                     self.keyframe_dict.append({"idx": idx, "color": color, "depth": depth, "gt_c2w": gt_c2w.cpu(),
                                                "est_c2w": self.est[idx].clone()})
-                if self.device.type == "cuda":
-                    torch.cuda.synchronize()
-                self.timers["mapping_s"] += time.perf_counter() - t1
                 if self.verbose:
                     e = float((self.est[idx][:3, 3].cpu() - self.gt[idx][:3, 3]).norm())
                     print(f"[map] frame {idx:4d} loss {self.last_map_loss:9.3f} pose err {e*100:6.2f} cm", file=sys.stderr)
@@ -504,6 +563,9 @@ class MiniSLAM:
         res["path_length_m"] = float(sum(np.linalg.norm(gt[i + 1][:3, 3] - gt[i][:3, 3]) for i in range(len(gt) - 1)))
         res.update(self.counters)
         res.update({k: round(v, 3) for k, v in self.timers.items()})
+        if self.coarse_losses:
+            res["coarse_loss_first_call"] = [round(v, 3) for v in self.coarse_losses[0]]
+            res["coarse_loss_last_call"] = [round(v, 3) for v in self.coarse_losses[-1]]
         return res
 
 
@@ -522,6 +584,7 @@ def main():
     ap.add_argument("--every-frame", type=int, default=2, help="map every n-th frame (reference: 5)")
     ap.add_argument("--step-deg", type=float, default=0.9, help="camera rotation per frame")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--no-coarse", action="store_true", help="skip the coarse-level mapper (fused path only)")
     ap.add_argument("--gt-mapping-pose", action="store_true", help="diagnostic: mapper uses ground-truth poses")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="mapping through get_samples / render_batch_ray / torch losses, eagerly (default: "
@@ -537,7 +600,8 @@ def main():
     torch.manual_seed(args.seed)
     seq = SyntheticSequence(args.frames, args.height, args.width, device=dev, step_deg=args.step_deg, seed=args.seed)
     ops = ProductOps(seq, dev, seed=args.seed, fused=not args.unfused)
-    slam = MiniSLAM(ops, seq, cfg, seed=args.seed, verbose=args.verbose, gt_mapping_pose=args.gt_mapping_pose)
+    slam = MiniSLAM(ops, seq, cfg, seed=args.seed, verbose=args.verbose, gt_mapping_pose=args.gt_mapping_pose,
+                    coarse_mapper=not args.no_coarse)
     t0 = time.perf_counter()
     res = slam.run()
     torch.cuda.synchronize()
@@ -548,6 +612,7 @@ def main():
                      "grids": {k: list(v.shape[2:]) for k, v in ops.c.items()}}
     res["mapping_ms_per_iter"] = round(1e3 * res["mapping_s"] / max(1, res["mapping_iters"]), 4)
     res["tracking_ms_per_iter"] = round(1e3 * res["tracking_s"] / max(1, res["tracking_iters"]), 4)
+    res["coarse_ms_per_iter"] = round(1e3 * res["coarse_s"] / max(1, res["coarse_iters"]), 4)
     res["metric"] = "ATE RMSE [cm] on a synthetic RGB-D sequence"
     res["value"] = res["ate"]["rmse"] * 100
     print(json.dumps(res))
