@@ -50,49 +50,13 @@ int bwd_blocks(long long n_groups, int max_blocks) {
     return (int)(n_groups < cap ? n_groups : cap);
 }
 
-// Share the blocks of one backward launch among the decoder passes of the stage.  A block serves ONE pass (that decoder's
-// operand stream sits in its LDS, its parameter-gradient accumulators in its registers) and one block fits a CU, so the
-// launch is sized to one block per CU and the passes must finish together: pass p with n_p blocks takes
-// ceil(G / n_p) * w_p + f_p (w: one ray group's tiles, f: the block's fixed costs -- operand stream into LDS, first
-// touches, accumulator flush).  Greedy: every pass starts with one block; the pass that would finish last gets the next.
-// w, f in kilo-cycles measured with tests/perf/ts_probe.py on MI355X (profiles/r02_ts/); passes without parameter
-// gradients run the lighter specialisation.  `max_blocks` > 0 (tests): at most that many blocks per pass.
-void bwd_partition(const nsr::RenderParams &P, int max_blocks, int first[4]) {
-    static const double kW[4] = {60.0, 100.0, 255.0, 141.0}, kF[4] = {30.0, 45.0, 60.0, 53.0};     // coarse, middle, fine, colour
-    static double w_env[4], f_env[4];
-    static const bool have_env = [] {
-        const char *e = getenv("NSR_BWD_COST");             // tuning aid: "w_coarse,w_middle,w_fine,w_color,f_coarse,...,f_color"
-        if (!e) return false;
-        double v[8];
-        if (sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf,%lf,%lf", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7) != 8) return false;
-        for (int i = 0; i < 4; ++i) { w_env[i] = v[i]; f_env[i] = v[4 + i]; }
-        return true;
-    }();
-    const long long G = P.n_groups;
-    int slots[3], n[3] = {0, 0, 0}, np = 0;
-    if (P.stage == NSR_STAGE_COARSE) slots[np++] = NSR_COARSE;
-    else for (int s = NSR_MIDDLE; s <= P.stage; ++s) slots[np++] = s;
-    double w[3], f[3];
-    for (int i = 0; i < np; ++i) {
-        const bool params = P.dec[slots[i]].dparams != nullptr;
-        w[i] = (have_env ? w_env : kW)[slots[i]] * (params ? 1.0 : 0.65);
-        f[i] = (have_env ? f_env : kF)[slots[i]] * (params ? 1.0 : 0.5);
-        n[i] = 1;
-    }
-    const long long per_pass = max_blocks > 0 ? max_blocks : kDefaultBwdBlocks;
-    const long long cap = G < per_pass ? G : per_pass;                    // a pass never gets more blocks than groups
-    long long budget = (max_blocks > 0 ? (long long)np * max_blocks : kDefaultBwdBlocks) - np;
-    auto cost = [&](int i) { return (double)((G + n[i] - 1) / n[i]) * w[i] + f[i]; };
-    for (; budget > 0; --budget) {                     // (ceil(G/n) is a step function: the same pass may be chosen several times
-        int worst = -1;                                // in a row before its cost drops)
-        for (int i = 0; i < np; ++i)
-            if (n[i] < cap && (worst < 0 || cost(i) > cost(worst))) worst = i;
-        if (worst < 0) break;
-        ++n[worst];
-    }
-    first[0] = 0;
-    for (int i = 0; i < 3; ++i) first[i + 1] = first[i] + (i < np ? n[i] : 0);
-}
+// Decoder passes of one backward launch (grid.y): a block serves ONE pass -- that decoder's operand stream sits in its LDS,
+// its parameter-gradient accumulators in its registers -- and one block fits a CU, so the passes run as successive rounds
+// over the chip.  (Measured alternative, profiles/r02_ts/r02n_partition.txt: ONE round of 256 blocks shared among the
+// passes by a cost model, so that a block pays its fixed costs once: at 1000 rays the 4-ray group granularity (250 groups
+// per pass) leaves the best such partition no better than the rounds, at >= 5000 rays it gains < 3 %, and it depends on
+// per-scene cost weights.)
+int bwd_passes(int stage) { return stage == NSR_STAGE_COARSE ? 1 : stage; }     // middle 1, fine 2, colour 3
 
 // validate + translate the public argument block
 int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays, bool bwd = false) {
@@ -253,20 +217,20 @@ int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream
 #ifdef NSR_TS
     if (const char *e = getenv("NSR_DBG_PTR")) P.dbg = reinterpret_cast<long long *>(strtoull(e, nullptr, 16));
 #endif
-    bwd_partition(P, b->max_blocks, P.pass_first);
-    const int nblk = P.pass_first[3];
+    const int passes = bwd_passes(P.stage);
+    const int nblk = bwd_blocks(P.n_groups, b->max_blocks);
     bool any_params = false;
     for (int s = 0; s < 4; ++s) any_params |= P.dec[s].dparams != nullptr;
     P.partial_stride = max_param_count(P.stage);
     if (any_params) {
-        const long long need = (long long)nblk * P.partial_stride;
+        const long long need = (long long)passes * nblk * P.partial_stride;
         if (!b->workspace || b->workspace_floats < need) return fail("nsr_render_bwd: workspace too small");
         P.partials = b->workspace;
     }
     const int npts = P.rays_per_block * P.S;
     const int waves = kBwdWaves;
     const int lds = bwd_lds_bytes(P.stage, npts, P.rays_per_block, waves);
-    const dim3 grid(nblk), block(64 * waves);
+    const dim3 grid(nblk, passes), block(64 * waves);
 #define NSR_BWD(ST)                                                                              \
     case ST:                                                                                     \
         if (int rc = launch_cfg(nsr::render_bwd_kernel<ST>, lds, "nsr_render_bwd")) return rc;    \
@@ -286,8 +250,8 @@ int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream
         for (int s = first; s <= last; ++s) {
             if (!P.dec[s].dparams) continue;
             const int pass = P.stage == NSR_STAGE_COARSE ? 0 : s - NSR_MIDDLE;
-            R.job[rows].partials = P.partials + (long long)P.pass_first[pass] * P.partial_stride;
-            R.job[rows].nblocks = P.pass_first[pass + 1] - P.pass_first[pass];
+            R.job[rows].partials = P.partials + (long long)pass * nblk * P.partial_stride;
+            R.job[rows].nblocks = nblk;
             R.job[rows].dparams = P.dec[s].dparams;
             R.job[rows].n = nsr::param_total(s);
             nmax = nmax > R.job[rows].n ? nmax : R.job[rows].n;

@@ -610,10 +610,8 @@ struct TileCtx {
     Lvl L;
 };
 
-// `blk` / `nblk`: this block's index among the `nblk` blocks of the pass (it takes the ray groups blk, blk + nblk, ...);
-// `gblk`: its index in the launch (partial image, profiling slot).
 template <int KIND, bool PARAMS>
-NSR_DEV void bwd_pass(const RenderParams &P, const int blk, const int nblk, const int gblk) {
+NSR_DEV void bwd_pass(const RenderParams &P) {
     char *lds = lds_base();
     const int npts = P.rays_per_block * P.S, S = P.S;
     const int lane = tid() & 63, wave = tid() >> 6, nwaves = nthreads() >> 6;
@@ -637,10 +635,12 @@ NSR_DEV void bwd_pass(const RenderParams &P, const int blk, const int nblk, cons
     F.rays = P.d_rays_o != nullptr;
     if (!F.grid && !F.params && !F.rays) return;
 
-    const Dbg dbg{P.dbg ? P.dbg + ((long long)gblk * kBwdWaves + wave) * 64 : nullptr};
+    const Dbg dbg{P.dbg ? P.dbg + (((long long)bid_y() * nblk_x() + bid_x()) * kBwdWaves + wave) * 64 : nullptr};
     dbg.stamp(0);
+#ifdef NSR_TS
     dbg.note(61, KIND + 1);                                  // the probe's key: which pass this block served, how many blocks it had
-    dbg.note(62, nblk);
+    dbg.note(62, nblk_x());
+#endif
     typename AccOf<KIND>::type A;
     if (PARAMS) {
         acc_zero(A);
@@ -663,7 +663,7 @@ NSR_DEV void bwd_pass(const RenderParams &P, const int blk, const int nblk, cons
         return make_level(P.grid[KIND == NSR_FINE ? NSR_MIDDLE : KIND], px, py, pz);     // fine: the cell of the middle grid too
     };
 
-    for (long long grp = blk; grp < P.n_groups; grp += nblk) {
+    for (long long grp = bid_x(); grp < P.n_groups; grp += nblk_x()) {
         loop_fence();
         const long long ray0 = grp * P.rays_per_block;
         // Every independent global load of the group is issued before anything waits (a short-lived block pays a TLB miss
@@ -698,7 +698,7 @@ NSR_DEV void bwd_pass(const RenderParams &P, const int blk, const int nblk, cons
         if (c_act) draw[lane] = F4{c_rw.x + (float)c_gD, c_rw.y + (float)c_gV, c_rw.z + c_gr + c_gg + c_gb, c_rw.w + (float)c_dep};
         dbg.stamp(60);
 #endif
-        if (grp == (long long)blk) {
+        if (grp == (long long)bid_x()) {
             copy_f4<(AUX_FLOATS + packed_total(KIND)) / 4>(aux, D.packed);      // visible after the barrier below
             dbg.stamp(1);
         }
@@ -839,7 +839,7 @@ NSR_DEV void bwd_pass(const RenderParams &P, const int blk, const int nblk, cons
         }
     }
     if (PARAMS) {
-        float *img = P.partials + (long long)gblk * P.partial_stride;
+        float *img = P.partials + ((long long)bid_y() * nblk_x() + bid_x()) * P.partial_stride;
         if constexpr (KIND != NSR_COARSE) {                      // LDS-resident accumulator tiles join the others
 #pragma unroll
             for (int Tk = 0; Tk < lds_acc_ktiles(KIND); ++Tk) {
@@ -852,23 +852,19 @@ NSR_DEV void bwd_pass(const RenderParams &P, const int blk, const int nblk, cons
     dbg.stamp(7);
 }
 
-// grid = one row of blocks; the launch gives every decoder pass its own contiguous share of them (pass_first), sized by the
-// host so that the passes finish together: a block pays its fixed costs (operand stream into LDS, accumulator flush) once
-// and then takes several ray groups of ITS pass, instead of one short-lived block per (group, pass).
+// grid = (blocks per pass, decoder passes of the stage): block (x, p) takes the ray groups x, x + gridDim.x, ... of pass p.
 template <int STAGE>
 NSR_KERNEL NSR_BOUNDS(64 * kBwdWaves) void render_bwd_kernel(const RenderParams P) {
-    const int b = bid_x();
     if (STAGE == NSR_STAGE_COARSE) {
-        if (P.dec[NSR_COARSE].dparams) bwd_pass<NSR_COARSE, true>(P, b, nblk_x(), b); else bwd_pass<NSR_COARSE, false>(P, b, nblk_x(), b);
+        if (P.dec[NSR_COARSE].dparams) bwd_pass<NSR_COARSE, true>(P); else bwd_pass<NSR_COARSE, false>(P);
     } else {
-        const int pass = (b >= P.pass_first[1]) + (b >= P.pass_first[2]);
-        const int blk = b - P.pass_first[pass], nblk = P.pass_first[pass + 1] - P.pass_first[pass];
+        const int pass = bid_y();
         if (pass == 0) {
-            if (P.dec[NSR_MIDDLE].dparams) bwd_pass<NSR_MIDDLE, true>(P, blk, nblk, b); else bwd_pass<NSR_MIDDLE, false>(P, blk, nblk, b);
+            if (P.dec[NSR_MIDDLE].dparams) bwd_pass<NSR_MIDDLE, true>(P); else bwd_pass<NSR_MIDDLE, false>(P);
         } else if (pass == 1) {
-            if (STAGE >= NSR_STAGE_FINE) { if (P.dec[NSR_FINE].dparams) bwd_pass<NSR_FINE, true>(P, blk, nblk, b); else bwd_pass<NSR_FINE, false>(P, blk, nblk, b); }
+            if (STAGE >= NSR_STAGE_FINE) { if (P.dec[NSR_FINE].dparams) bwd_pass<NSR_FINE, true>(P); else bwd_pass<NSR_FINE, false>(P); }
         } else {
-            if (STAGE == NSR_STAGE_COLOR) { if (P.dec[NSR_COLOR].dparams) bwd_pass<NSR_COLOR, true>(P, blk, nblk, b); else bwd_pass<NSR_COLOR, false>(P, blk, nblk, b); }
+            if (STAGE == NSR_STAGE_COLOR) { if (P.dec[NSR_COLOR].dparams) bwd_pass<NSR_COLOR, true>(P); else bwd_pass<NSR_COLOR, false>(P); }
         }
     }
 }

@@ -29,6 +29,7 @@ NSR_DEV int f2i_rn(float x) { return __float2int_rn(x); }      // round half to 
 // (no wait states inserted, stale accumulators read).
 NSR_DEV float relu1(float x) { const int b = __builtin_bit_cast(int, x); return __builtin_bit_cast(float, b > 0 ? b : 0); }
 NSR_DEV int bid_y() { return (int)blockIdx.y; }
+NSR_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }      // pin a wave-uniform value to an SGPR
 NSR_DEV int nblk_x() { return (int)gridDim.x; }
 
 NSR_DEV float shfl(float v, int src) { return __shfl(v, src, 64); }

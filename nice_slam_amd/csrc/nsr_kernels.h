@@ -73,9 +73,8 @@ struct RenderParams {
     const double *d_depth, *d_var, *g_depth;
     const float *d_rgb;
     float *d_rays_o, *d_rays_d;
-    float *partials;          // [block of the launch][max param count]
+    float *partials;          // [passes][gridDim.x][max param count]
     int partial_stride;       // floats between two blocks' partial images
-    int pass_first[4];        // backward launch: blocks [pass_first[p], pass_first[p+1]) work on decoder pass p (nsr_api.cpp: bwd_partition)
     // fused mapping loss (Mapper.py:487-493), optional
     const float *loss_depth;  // [N] sensor depth of the loss (also set where the SAMPLING is unguided: coarse mapper, Mapper.py:484-489)
     const float *gt_color;    // [N][3]

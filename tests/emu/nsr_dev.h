@@ -134,6 +134,7 @@ NSR_DEV int bid_x() { return (int)emu::B->bid.x; }
 NSR_DEV int f2i_rn(float x) { return (int)lrintf(x); }
 NSR_DEV float relu1(float x) { const int b = __builtin_bit_cast(int, x); return __builtin_bit_cast(float, b > 0 ? b : 0); }
 NSR_DEV int bid_y() { return (int)emu::B->bid.y; }
+NSR_DEV int uniform(int v) { return v; }
 NSR_DEV int nblk_x() { return (int)emu::B->gdim.x; }
 
 template <typename T>
