@@ -134,7 +134,7 @@ def build_scene(cfg_id, dev, seed=0):
             "intr": (H, W, fx, fy, cx, cy)}
 
 
-def cpu_baseline(sc, n_rays, stages, weights):
+def cpu_baseline(sc, n_rays, stages, weights, track_crop=None):
     """The CPU oracle (a torch restatement of the reference path, kind='port') on this box's host cores, in the mode that
     calls ATen's grid_sampler_3d exactly like the reference (decoder.py:173; its backward is 59 % of the reference's CPU time),
     fed with the SAME grids / decoder parameters / frames as the GPU run: one forward+backward per stage on a bounded ray
@@ -150,6 +150,32 @@ def cpu_baseline(sc, n_rays, stages, weights):
     n = min(n_rays, 1000)                                       # bounded sample: ~10-20 s of CPU work
     idx = torch.randint(H * W, (n,), generator=torch.Generator().manual_seed(5))
     rays_o, rays_d, gt_depth, gt_color = orc.pixel_rays(idx, 0, H, 0, W, fx, fy, cx, cy, c2w, depth_img, color_img)
+
+    def once_track(m):                                          # Tracker.optimize_cam_in_batch (Tracker.py:86-125): gradient to the pose only
+        pose = c2w[:3].clone().requires_grad_(True)
+        e = track_crop
+        ti = torch.randint((H - 2 * e) * (W - 2 * e), (m,), generator=torch.Generator().manual_seed(6))
+        o, d, gd, gc = orc.pixel_rays(ti, e, H - e, e, W - e, fx, fy, cx, cy, pose, depth_img, color_img)
+        with torch.no_grad():
+            tt = (sc["bound"].unsqueeze(0) - o.detach().unsqueeze(-1)) / d.detach().unsqueeze(-1)
+            inside = torch.min(torch.max(tt, dim=2)[0], dim=1)[0] >= gd
+        o, d, gd, gc = o[inside], d[inside], gd[inside], gc[inside]
+        depth, unc, col = orc.render_batch_ray(grids, params, d, o, "color", gd, sc["bound"])
+        unc = unc.detach()
+        tmp = torch.abs(gd - depth) / torch.sqrt(unc + 1e-10)
+        mask = (tmp < 10 * tmp.median()) & (gd > 0)
+        (tmp[mask].sum() + 0.5 * torch.abs(gc - col)[mask].sum()).backward()
+
+    if track_crop is not None:
+        once_track(64)
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            once_track(n)
+        dt = (time.perf_counter() - t0) / reps
+        return {"value": n / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+                "sample": "oracle (grid_sampler_3d mode) tracking iteration (sampling, pre-filter, colour-stage render, loss, backward to the "
+                          "pose), %d rays, mean of %d iterations (%.0f ms each)" % (n, reps, dt * 1e3)}
 
     def once(stage, m):
         G = {k: v.clone().requires_grad_(True) for k, v in grids.items()}
@@ -284,7 +310,11 @@ def main():
             p.grad = None
         if not timed:
             renderer.profile_events = None
-        if tracking:                                              # Tracker.optimize_cam_in_batch (Tracker.py:87-125), sync-free form
+        if tracking and not args.unfused:                         # Tracker.optimize_cam_in_batch (Tracker.py:87-125) as one autograd node
+            cam.grad = None
+            loss = nsa.tracking_loss(renderer, grids, dec, cam, frames[0][1], frames[0][2], rays_rank, crop, crop, w_color=0.5)
+            loss.backward()
+        elif tracking:                                            # the same through the drop-in surface, sync-free form
             cam.grad = None
             o, d, gd, gc = nsa.get_samples(crop, H - crop, crop, W - crop, rays_rank, H, W, fx, fy, cx, cy, cam, frames[0][1], frames[0][2], dev)
             keep, kmax = nsa.aabb_keep(o, d, gd, sc["bound"])
@@ -398,8 +428,10 @@ def main():
                                    f", 32 ch fp32, random-init decoders, {H}x{W} synthetic RGB-D, {K}x{per_frame} pixels/iter/GPU, S=32+16",
                        "rays_per_gpu": rays_rank, "rays_per_iteration": rays_iter,
                        "stage_mix": {s: stages.count(s) for s in sorted(set(stages))},
-                       "timed_region": ("get_samples (crop) + bounding-box mask + render_batch_ray(color) + tracking loss + backward to the pose"
-                                        if tracking else
+                       "timed_region": (("get_samples (crop) + bounding-box mask + render_batch_ray(color) + tracking loss (torch) + backward to the pose"
+                                         if args.unfused else
+                                         "index draw + window kernel (crop, bounding-box mask) + render forward (colour stage) + tracking loss kernel "
+                                         "(median mask) + render backward + pose gradient") if tracking else
                                         ("get_samples x window + cat + render_batch_ray + torch loss + backward" if args.unfused else
                                          "index draw + window sampling kernel + render forward (with the mapping loss) + render backward") +
                                         " (all grid + all decoder grads, like the reference autograd), no optimiser"),
@@ -431,8 +463,8 @@ def main():
         if shard is not None:
             res["config"]["grad_exchange_MB_last_iter"] = round(shard.last_exchange_floats * 4 / 1e6, 2)
         res["kernel_ms"] = {f"render_bwd<{s}>": round(v[0], 4) for s, v in ksum.items()}
-        if not args.no_cpu_baseline and world == 1 and not tracking:
-            res["cpu_baseline"] = cpu_baseline(sc, rays_rank, stages_cfg, mix)
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(sc, rays_rank, stages_cfg, mix, crop if tracking else None)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     if sharded:

@@ -217,6 +217,25 @@ typedef struct nsr_span {
 int nsr_pack_rows(const nsr_rows *grids, int32_t n_grids, const nsr_span *spans, int32_t n_spans, float *packed,
                   int32_t unpack, void *stream);
 
+/* The tracker's loss on rendered outputs -- src/Tracker.py:108-124 (Tracker.optimize_cam_in_batch): with
+ * tmp = |gt_depth - depth| / sqrt(var + 1e-10) (fp64, `var` detached), mask = keep & (gt_depth > 0) and, when
+ * handle_dynamic, & (tmp < 10 * median(tmp over the kept rays)) (torch.median: the lower middle element; NaN if any
+ * element is NaN),
+ *     *loss += sum_mask tmp  [+ w_color * sum_mask |gt_color - rgb|   when use_color]
+ * and dl_depth [n] / dl_rgb [n][3] receive d loss / d depth and d loss / d rgb -- what autograd would hand to the backward
+ * of render_batch_ray (feed them to nsr_render_bwd as d_depth / d_rgb).  `keep` (or NULL) is the bounding-box pre-filter
+ * of :92-104 as a byte mask (nsr_aabb_keep / nsr_get_samples_window): the reference compacts the batch instead, so its
+ * median runs over exactly the kept rays.  One launch, no host synchronisation, any n. */
+int nsr_tracking_loss(int64_t n_rays, const float *gt_depth, const float *gt_color, const uint8_t *keep,
+                      const double *depth, const double *var, const float *rgb,
+                      int32_t handle_dynamic, int32_t use_color, float w_color,
+                      double *loss, double *dl_depth, float *dl_rgb, void *stream);
+
+/* get_camera_from_tensor / quad2rotation -- src/common.py:137-176: n camera tensors [quaternion (w,x,y,z) | translation]
+ * (7 floats each) -> n 3x4 matrices [R | T] in `rt` (d_rt == NULL), or -- d_rt != NULL -- the backward: d_cam [n][7] from
+ * d_rt [n][3][4].  The pose parametrisation of the tracker and of local BA (Tracker.py:87, Mapper.py:447-451). */
+int nsr_camera_from_tensor(const float *cam, int64_t n, float *rt, const float *d_rt, float *d_cam, void *stream);
+
 /* --- frustum feature selection ---------------------------------------------------------------------
  * Replaces Mapper.get_mask_from_c2w (src/Mapper.py:93-164) for one non-coarse feature grid: every voxel centre (xs[ix],
  * ys[iy], zs[iz]: the per-axis torch.linspace over the scene bound, :111-113, device arrays) is projected with

@@ -93,6 +93,9 @@ SYMBOLS = (
     ("nsr_masked_adam_multi", C.c_int, [C.POINTER(NsrAdamGrid), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32,
                                         C.c_void_p, C.c_void_p]),
     ("nsr_pack_rows", C.c_int, [C.POINTER(NsrRows), C.c_int32, C.POINTER(NsrSpan), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    ("nsr_tracking_loss", C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("nsr_camera_from_tensor", C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("nsr_aabb_keep", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.c_void_p, C.c_void_p, C.c_void_p]),
     ("nsr_frustum_workspace_floats", C.c_int64, [C.c_int64]),

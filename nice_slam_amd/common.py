@@ -188,6 +188,39 @@ def aabb_keep(rays_o: torch.Tensor, rays_d: torch.Tensor, gt_depth: torch.Tensor
     return keep.bool(), kmax
 
 
+class _CameraFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cam):
+        lib = _capi.get_lib()
+        c = cam.detach().reshape(-1, 7).to(torch.float32).contiguous()
+        rt = torch.empty((c.shape[0], 3, 4), dtype=torch.float32, device=c.device)
+        lib.check(lib.nsr_camera_from_tensor(c.data_ptr(), c.shape[0], rt.data_ptr(), None, None, _stream(c.device)), "nsr_camera_from_tensor")
+        ctx.save_for_backward(c)
+        ctx.meta = (cam.shape, cam.dtype)
+        return rt[0] if cam.dim() == 1 else rt
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        lib = _capi.get_lib()
+        (c,) = ctx.saved_tensors
+        g = g.reshape(-1, 3, 4).to(torch.float32).contiguous()
+        d = torch.empty_like(c)
+        lib.check(lib.nsr_camera_from_tensor(c.data_ptr(), c.shape[0], None, g.data_ptr(), d.data_ptr(), _stream(c.device)), "nsr_camera_from_tensor")
+        shape, dtype = ctx.meta
+        return d.reshape(shape).to(dtype)
+
+
+def get_camera_from_tensor(inputs: torch.Tensor) -> torch.Tensor:
+    """src/common.py:163-176 (with quad2rotation, :137-160): ``[quaternion (w,x,y,z), translation]`` (7,) or (B,7) -> the 3x4
+    (or B x 3 x 4) matrix ``[R | T]``; one launch forward, one backward (the reference spends ~25 + ~45 ATen launches per
+    tracking / BA iteration here)."""
+    _require_cuda(inputs, "get_camera_from_tensor: inputs")
+    if inputs.shape[-1] != 7 or inputs.dim() not in (1, 2):
+        raise _capi.NsrError(f"get_camera_from_tensor: expected (7,) or (B,7), got {tuple(inputs.shape)}")
+    return _CameraFn.apply(inputs)
+
+
 def get_rays(H, W, fx, fy, cx, cy, c2w, device):
     """src/common.py:248-266: rays for a whole image (used by render_img, forward only)."""
     if isinstance(c2w, np.ndarray):

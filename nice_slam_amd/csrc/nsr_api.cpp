@@ -452,4 +452,33 @@ int nsr_aabb_keep(const float *rays_o, const float *rays_d, const float *gt_dept
     return finish("nsr_aabb_keep");
 }
 
+int nsr_tracking_loss(int64_t n_rays, const float *gt_depth, const float *gt_color, const uint8_t *keep,
+                      const double *depth, const double *var, const float *rgb,
+                      int32_t handle_dynamic, int32_t use_color, float w_color,
+                      double *loss, double *dl_depth, float *dl_rgb, void *stream) {
+    if (n_rays < 0) return fail("nsr_tracking_loss: negative ray count");
+    if (n_rays == 0) return 0;
+    if (!gt_depth || !depth || !var || !loss || !dl_depth) return fail("nsr_tracking_loss: null pointer");
+    if (use_color && (!gt_color || !rgb || !dl_rgb)) return fail("nsr_tracking_loss: the colour term needs gt_color, rgb and dl_rgb");
+    nsr::TrackLossParams P;
+    P.n = n_rays; P.gt_depth = gt_depth; P.gt_color = gt_color; P.rgb = rgb; P.keep = keep; P.depth = depth; P.var = var;
+    P.handle_dynamic = handle_dynamic ? 1 : 0; P.use_color = use_color ? 1 : 0; P.w_color = w_color;
+    P.loss = loss; P.dl_depth = dl_depth; P.dl_rgb = dl_rgb;
+    const int tb = n_rays <= 256 ? 256 : 1024;                       // one block: the median is a property of the whole batch
+    const int key_cap = (handle_dynamic && n_rays <= 4096) ? (int)n_rays : 0;      // tmp bit patterns cached in LDS (<= 32 KB), else recomputed
+    NSR_LAUNCH(nsr::tracking_loss_kernel, dim3(1), dim3(tb), 1024 + 32 + tb * 8 + key_cap * 8, stream, P, key_cap);
+    return finish("nsr_tracking_loss");
+}
+
+int nsr_camera_from_tensor(const float *cam, int64_t n, float *rt, const float *d_rt, float *d_cam, void *stream) {
+    if (n < 0) return fail("nsr_camera_from_tensor: negative count");
+    if (n == 0) return 0;
+    if (!cam || (!d_rt && !rt) || (d_rt && !d_cam)) return fail("nsr_camera_from_tensor: null pointer");
+    nsr::CamParams P;
+    P.cam = cam; P.n = n; P.rt = rt; P.d_rt = d_rt; P.d_cam = d_cam;
+    const int tb = 64;
+    NSR_LAUNCH(nsr::camera_from_tensor_kernel, dim3((unsigned)((n + tb - 1) / tb)), dim3(tb), 0, stream, P);
+    return finish("nsr_camera_from_tensor");
+}
+
 }  // extern "C"

@@ -1271,6 +1271,202 @@ NSR_KERNEL void frustum_mask_kernel(const FrustumParams P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The tracker's loss on rendered outputs (Tracker.optimize_cam_in_batch, src/Tracker.py:108-124), one block:
+//   tmp_i  = |gt_i - depth_i| / sqrt(var_i + 1e-10)                 (fp64; var is detached, :109)
+//   mask_i = keep_i & (gt_i > 0) [& (tmp_i < 10 * median(tmp over the kept rays))   -- handle_dynamic, :110-112]
+//   loss  += sum_mask tmp_i [+ w_color * sum_mask |gt_rgb_i - rgb_i|                -- use_color_in_tracking, :119-122]
+// plus d loss / d depth and d loss / d rgb per ray, i.e. what autograd hands render_batch_ray's backward.  `keep` is the
+// bounding-box pre-filter as a mask (the reference compacts the batch, :92-104; the median runs over the compacted batch,
+// zero-depth rays included).  torch.median: the LOWER middle element, NaN if any element is NaN -- found here by an 8-pass
+// radix select over the bit patterns of the non-negative doubles (they order like unsigned integers), no sort, any N.
+// ------------------------------------------------------------------------------------------------
+struct TrackLossParams {
+    long long n;
+    const float *gt_depth, *gt_color, *rgb;
+    const unsigned char *keep;       // or NULL: every ray counts
+    const double *depth, *var;
+    int handle_dynamic, use_color;
+    float w_color;
+    double *loss;                    // += the loss
+    double *dl_depth;                // [n]
+    float *dl_rgb;                   // [n][3] (written when use_color)
+};
+
+NSR_DEV double track_tmp(const TrackLossParams &P, long long i) {
+    return fabs((double)P.gt_depth[i] - P.depth[i]) / sqrt(P.var[i] + 1e-10);
+}
+
+// LDS: hist int[256] | ctl int[4] | pre u64[2] | red f64[nthreads] | keys u64[key_cap]   (key_cap >= n: the kept rays' tmp bit
+// patterns are computed once and cached; key_cap == 0: recomputed in every pass)
+NSR_KERNEL void tracking_loss_kernel(const TrackLossParams P, const int key_cap) {
+    int *hist = reinterpret_cast<int *>(lds_base());
+    int *ctl = hist + 256;                                        // n_kept, n_nan, k, pad
+    unsigned long long *pre = reinterpret_cast<unsigned long long *>(ctl + 4);
+    double *red = reinterpret_cast<double *>(pre + 2);            // [nthreads] loss partials
+    const int t = tid(), nt = nthreads();
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(red + nt);
+    const bool cached = key_cap > 0;
+    constexpr unsigned long long kSkip = ~0ull;                    // not kept: above every finite / inf / NaN pattern of a non-negative double
+    double thr = 0.0;
+    bool use_thr = false;
+    if (P.handle_dynamic) {
+        if (t < 4) ctl[t] = 0;
+        if (t == 0) { pre[0] = 0ull; pre[1] = 0ull; }
+        block_sync();
+        int kept = 0, nan = 0;
+        for (long long i = t; i < P.n; i += nt) {
+            const bool k = !P.keep || P.keep[i];
+            const double v = k ? track_tmp(P, i) : 0.0;
+            if (cached) keys[i] = k ? __builtin_bit_cast(unsigned long long, v) : kSkip;
+            kept += k ? 1 : 0;
+            nan += (k && v != v) ? 1 : 0;
+        }
+        if (kept) atomic_add_lds_i(ctl + 0, kept);
+        if (nan) atomic_add_lds_i(ctl + 1, nan);
+        block_sync();
+        const int n_kept = ctl[0], n_nan = ctl[1];
+        use_thr = true;
+        thr = __builtin_nan("");                                   // NaN median (or an empty batch): nothing passes `tmp < 10 * median`
+        if (n_kept > 0 && n_nan == 0) {
+            const int kth = (n_kept - 1) / 2;                      // torch.median: the lower middle element (0-based rank)
+            if (cached && P.n <= 1024) {
+                // small batch: every thread ranks its own key against all others (ties broken by index)
+                for (long long i = t; i < P.n; i += nt) {
+                    const unsigned long long ki = keys[i];
+                    if (ki == kSkip) continue;
+                    int rank = 0;
+                    for (int j = 0; j < (int)P.n; ++j) {
+                        const unsigned long long kj = keys[j];
+                        rank += (kj < ki || (kj == ki && j < (int)i)) ? 1 : 0;
+                    }
+                    if (rank == kth) pre[0] = ki;
+                }
+                block_sync();
+            } else {
+                // radix select, 8 bits per pass from the top: histogram of the digit among the keys matching the prefix so far
+                if (t == 0) ctl[2] = kth;
+                for (int pass = 0; pass < 8; ++pass) {
+                    const int shift = 56 - 8 * pass;
+                    for (int b = t; b < 256; b += nt) hist[b] = 0;
+                    block_sync();
+                    const unsigned long long prefix = pre[0], pmask = pre[1];
+                    const int k = ctl[2];
+                    for (long long i = t; i < P.n; i += nt) {
+                        unsigned long long key;
+                        if (cached) { key = keys[i]; if (key == kSkip) continue; }
+                        else { if (P.keep && !P.keep[i]) continue; key = __builtin_bit_cast(unsigned long long, track_tmp(P, i)); }
+                        if ((key & pmask) == prefix) atomic_add_lds_i(hist + (int)((key >> shift) & 255ull), 1);
+                    }
+                    block_sync();
+                    if (t < 256) {                                 // the digit whose bin holds rank k: bins below sum to <= k < including it
+                        int below = 0;
+                        for (int j = 0; j < t; ++j) below += hist[j];
+                        const int mine = hist[t];
+                        if (below <= k && k < below + mine) {
+                            ctl[2] = k - below;
+                            pre[0] = prefix | ((unsigned long long)t << shift);
+                            pre[1] = pmask | (255ull << shift);
+                        }
+                    }
+                    block_sync();
+                }
+            }
+            thr = 10.0 * __builtin_bit_cast(double, pre[0]);
+        }
+    }
+    double part = 0.0, cpart = 0.0;
+    for (long long i = t; i < P.n; i += nt) {
+        const float gd = P.gt_depth[i];
+        const double diff = (double)gd - P.depth[i], rs = sqrt(P.var[i] + 1e-10), v = fabs(diff) / rs;
+        bool m = (!P.keep || P.keep[i]) && gd > 0.f;
+        if (use_thr) m = m && (v < thr);
+        // d |x| = sign(x) with sign(0) = 0 (torch.abs backward)
+        P.dl_depth[i] = m ? (diff > 0.0 ? -1.0 : (diff < 0.0 ? 1.0 : 0.0)) / rs : 0.0;
+        if (m) part += v;
+        if (P.use_color) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float dc = P.gt_color[i * 3 + a] - P.rgb[i * 3 + a];
+                P.dl_rgb[i * 3 + a] = m ? (dc > 0.f ? -P.w_color : (dc < 0.f ? P.w_color : 0.f)) : 0.f;
+                if (m) cpart += (double)fabsf(dc);
+            }
+        }
+    }
+    red[t] = part + (double)P.w_color * cpart;
+    block_sync();
+    for (int s = nt >> 1; s > 0; s >>= 1) {
+        if (t < s) red[t] += red[t + s];
+        block_sync();
+    }
+    if (t == 0) atomic_add_global_d(P.loss, red[0]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// get_camera_from_tensor / quad2rotation (src/common.py:137-176): [quaternion (w, x, y, z) | translation] -> 3x4 [R | T],
+// R = I - two_s * (...) with two_s = 2 / |q|^2 (no normalisation of q: the optimiser moves all four components).  One
+// thread per camera; `d_rt` != NULL: the backward (d cam from d [R | T]) instead.  Replaces ~25 ATen launches forward and
+// ~45 backward per tracking / BA iteration (Tracker.py:87, Mapper.py:447-451).
+// ------------------------------------------------------------------------------------------------
+struct CamParams {
+    const float *cam;     // [B][7]
+    long long n;
+    float *rt;            // forward:  [B][3][4]
+    const float *d_rt;    // backward: [B][3][4]
+    float *d_cam;         // backward: [B][7]
+};
+NSR_KERNEL void camera_from_tensor_kernel(const CamParams P) {
+    const long long b = (long long)bid_x() * nthreads() + tid();
+    if (b >= P.n) return;
+    const float *c = P.cam + b * 7;
+    const float qr = c[0], qi = c[1], qj = c[2], qk = c[3];
+    const float nn = ((qr * qr + qi * qi) + qj * qj) + qk * qk;
+    const float s = 2.0f / nn;
+    // R = [[1 - s*a00, s*a01, s*a02], ...] with the bracket terms of common.py:152-160
+    const float a[9] = {qj * qj + qk * qk, qi * qj - qk * qr, qi * qk + qj * qr,
+                        qi * qj + qk * qr, qi * qi + qk * qk, qj * qk - qi * qr,
+                        qi * qk - qj * qr, qj * qk + qi * qr, qi * qi + qj * qj};
+    if (!P.d_rt) {
+        float *o = P.rt + b * 12;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o[r * 4 + k] = (r == k) ? 1.0f - s * a[r * 3 + k] : s * a[r * 3 + k];
+            o[r * 4 + 3] = c[4 + r];
+        }
+        return;
+    }
+    const float *g = P.d_rt + b * 12;
+    // d R_rk = sgn_rk * (ds * a_rk + s * da_rk),  sgn = -1 on the diagonal, +1 off it;  ds/dq_m = -s^2 q_m / ... = -(s*s/2)*2 q_m / 2
+    float ga[9], gs = 0.f;                                       // gradient w.r.t. the bracket terms and w.r.t. s
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float sg = (r == k) ? -g[r * 4 + k] : g[r * 4 + k];
+            ga[r * 3 + k] = sg * s;
+            gs += sg * a[r * 3 + k];
+        }
+    // s = 2 / nn  ->  ds/dq_m = -2 / nn^2 * 2 q_m = -(s / nn) * 2 q_m
+    const float gn = -gs * s / nn;                               // gradient w.r.t. nn
+    float dqr = gn * 2.f * qr, dqi = gn * 2.f * qi, dqj = gn * 2.f * qj, dqk = gn * 2.f * qk;
+    // a00 = qj^2 + qk^2
+    dqj += ga[0] * 2.f * qj; dqk += ga[0] * 2.f * qk;
+    // a01 = qi qj - qk qr ; a10 = qi qj + qk qr
+    dqi += (ga[1] + ga[3]) * qj; dqj += (ga[1] + ga[3]) * qi; dqk += (ga[3] - ga[1]) * qr; dqr += (ga[3] - ga[1]) * qk;
+    // a02 = qi qk + qj qr ; a20 = qi qk - qj qr
+    dqi += (ga[2] + ga[6]) * qk; dqk += (ga[2] + ga[6]) * qi; dqj += (ga[2] - ga[6]) * qr; dqr += (ga[2] - ga[6]) * qj;
+    // a11 = qi^2 + qk^2
+    dqi += ga[4] * 2.f * qi; dqk += ga[4] * 2.f * qk;
+    // a12 = qj qk - qi qr ; a21 = qj qk + qi qr
+    dqj += (ga[5] + ga[7]) * qk; dqk += (ga[5] + ga[7]) * qj; dqi += (ga[7] - ga[5]) * qr; dqr += (ga[7] - ga[5]) * qi;
+    // a22 = qi^2 + qj^2
+    dqi += ga[8] * 2.f * qi; dqj += ga[8] * 2.f * qj;
+    float *o = P.d_cam + b * 7;
+    o[0] = dqr; o[1] = dqi; o[2] = dqj; o[3] = dqk;
+    o[4] = g[3]; o[5] = g[7]; o[6] = g[11];
+}
+
 }  // namespace nsr
 
 #include "nsr_bwd.h"

@@ -124,7 +124,11 @@ class _FlatDecoder(nn.Module):
         # whose writes never touch THIS process's version counters: re-pack on every call (one small kernel)
         if self._packed is None or self._packed[0] != key or self._cross_process:
             slot = _capi.SLOT_NAMES.index(self.slot)
-            pk = torch.empty(lib.nsr_packed_count(slot), dtype=torch.float32, device=f.device)
+            # re-pack INTO the buffer of the last pack when there is one: a captured hipGraph keeps reading that address
+            # (the pack launch is then either part of the graph -- parameters stepped inside it -- or issued by the caller
+            # between replays: NICE.repack())
+            pk = self._packed[1] if (self._packed is not None and self._packed[1].device == f.device) else \
+                torch.empty(lib.nsr_packed_count(slot), dtype=torch.float32, device=f.device)
             lib.check(lib.nsr_pack_params(slot, f.data_ptr(), pk.data_ptr(), stream), "nsr_pack_params")
             self._packed = (key, pk)
         return self._packed[1]
@@ -258,6 +262,16 @@ class NICE(nn.Module):
 
     def sub(self, slot: str) -> _FlatDecoder:
         return getattr(self, slot + "_decoder")
+
+    def repack(self):
+        """Refresh the packed operand streams after the parameters were written by something the version counters of this
+        process do not see, or between replays of a captured graph that does not contain the pack launch (a tracker-side
+        copy refreshed from the mapper's decoders, src/Tracker.py:130-142).  In place: captured graphs stay valid."""
+        from .common import _stream
+        lib = _capi.get_lib()
+        for m in self.children():
+            if isinstance(m, _FlatDecoder) and m.flat_params().is_cuda:
+                m.packed_params(lib, _stream(m.flat_params().device))
 
     def share_memory(self):                                  # src/NICE_SLAM.py:88-90
         for m in self.children():

@@ -1,4 +1,4 @@
-"""The mapper's iteration as three launches (src/Mapper.py:437-503).
+"""The mapper's iteration as three launches (src/Mapper.py:437-503), and the tracker's (src/Tracker.py:86-125).
 
 The reference's mapping iteration is: ``get_samples`` per keyframe of the window + ``torch.cat`` (Mapper.py:437-468), the
 bounding-box pre-filter (:471-481), ``render_batch_ray`` (:482), the L1 losses (:487-493) and ``loss.backward()`` (:503) --
@@ -132,7 +132,7 @@ class _MappingLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, meta, *tensors):
-        renderer, decoders, stage, wmeta, w_color, sharder, out = meta
+        renderer, decoders, stage, wmeta, w_color, sharder, out, track = meta      # track: None | (handle_dynamic, use_color)
         indices, K, n, crop, intr, depths, colors, bound, dev = wmeta
         lib = _capi.get_lib()
         slots = stage_slots(stage)
@@ -178,9 +178,14 @@ class _MappingLossFn(torch.autograd.Function):
         if not guided:
             a.n_surface = 0
         a.depth, a.var, a.rgb, a.raw, a.zvals = depth.data_ptr(), var.data_ptr(), rgb.data_ptr(), raw.data_ptr(), zvals.data_ptr()
-        a.gt_color, a.keep, a.loss, a.w_color = gt_color.data_ptr(), keep.data_ptr(), loss.data_ptr(), float(w_color)
-        a.dl_depth, a.dl_rgb = dl_depth.data_ptr(), dl_rgb.data_ptr()
+        if track is None:                                       # the mapper's L1 loss is accumulated by the forward kernel itself
+            a.gt_color, a.keep, a.loss, a.w_color = gt_color.data_ptr(), keep.data_ptr(), loss.data_ptr(), float(w_color)
+            a.dl_depth, a.dl_rgb = dl_depth.data_ptr(), dl_rgb.data_ptr()
         lib.check(lib.nsr_render_fwd(C.byref(a), stream), "nsr_render_fwd")
+        if track is not None:                                   # the tracker's loss needs the batch median of the rendered outputs
+            lib.check(lib.nsr_tracking_loss(N, gt_depth.data_ptr(), gt_color.data_ptr(), keep.data_ptr(), depth.data_ptr(), var.data_ptr(),
+                                            rgb.data_ptr(), int(track[0]), int(track[1]), float(w_color), loss.data_ptr(),
+                                            dl_depth.data_ptr(), dl_rgb.data_ptr(), stream), "nsr_tracking_loss")
         if out is not None:
             out.update(rays_o=rays_o, rays_d=rays_d, gt_depth=gt_depth, gt_color=gt_color, keep=keep, kept_max=kmax, depth=depth,
                        uncertainty=var, color=rgb, indices=indices)
@@ -188,7 +193,8 @@ class _MappingLossFn(torch.autograd.Function):
             ctx.sharder, ctx.loss32 = sharder, Z[3:4]
             ctx.state = (a, (renderer, decoders, stage, S, None if sharder is None else sharder.collect),
                          ([kmax, F, sbuf, Z, hold], rays_o, rays_d, gt_depth, grids, flats, packed, raw, depth),
-                         (need_pose, need_grid, need_par), dl_depth, dl_rgb if stage == "color" else None, Z[4:],
+                         (need_pose, need_grid, need_par), dl_depth,
+                         dl_rgb if (stage == "color" and (track is None or track[1])) else None, Z[4:],
                          (indices, K, n, crop, intr, [tuple(c.shape) for c in c2ws], [c.dtype for c in c2ws], [c.device for c in c2ws]))
         return loss[0]
 
@@ -235,5 +241,27 @@ def mapping_loss(renderer, c, decoders, frames: Sequence[Tuple[torch.Tensor, tor
     grids = _prep_grids(c, stage, dev)
     gates = [_gate(dev, torch.is_grad_enabled() and decoders.sub(s).wants_grad() and
                    (renderer.decoder_grads is None or s in renderer.decoder_grads)) for s in slots]
-    meta = (renderer, decoders, stage, wmeta, w_color, sharder, out)
+    meta = (renderer, decoders, stage, wmeta, w_color, sharder, out, None)
+    return _MappingLossFn.apply(meta, *c2ws, *[grids[s] for s in slots], *gates)
+
+
+def tracking_loss(renderer, c, decoders, c2w: torch.Tensor, depth: torch.Tensor, color: torch.Tensor, n_pixels: int,
+                  ignore_edge_H: int = 0, ignore_edge_W: int = 0, w_color: float = 0.5, handle_dynamic: bool = True,
+                  use_color: bool = True, device=None, indices: Optional[torch.Tensor] = None, out: Optional[dict] = None) -> torch.Tensor:
+    """One tracking iteration's loss (Tracker.optimize_cam_in_batch, src/Tracker.py:86-124) as a single autograd node:
+    ``n_pixels`` samples from the frame's ``[ignore_edge_H, H - ignore_edge_H) x [ignore_edge_W, W - ignore_edge_W)`` crop
+    under the pose ``c2w`` (3x4 or 4x4; gets its gradient), the bounding-box pre-filter as a mask, the colour-stage render with
+    depth-guided samples, and ``sum_mask |gt - depth| / sqrt(var + 1e-10) (+ w_color * sum_mask |gt_rgb - rgb|)`` with
+    ``mask = kept & (gt > 0) (& tmp < 10 * median(tmp))`` -- five launches (index draw, one zero-fill, window kernel, render
+    forward, ``nsr_tracking_loss``) and three in the backward (render backward, pose gradient, + the partial sum only if a
+    decoder wants parameter gradients) instead of ~80.  Returns an fp64 scalar; call ``.backward()`` on it directly."""
+    dev = torch.device(device) if device is not None else depth.device
+    H0, H1, W0, W1 = int(ignore_edge_H), renderer.H - int(ignore_edge_H), int(ignore_edge_W), renderer.W - int(ignore_edge_W)
+    wmeta, c2ws = _window_meta(H0, H1, W0, W1, n_pixels, renderer.W, renderer.fx, renderer.fy, renderer.cx, renderer.cy,
+                               [c2w], [depth], [color], renderer.bound, dev, indices)
+    slots = stage_slots("color")
+    grids = _prep_grids(c, "color", dev)
+    gates = [_gate(dev, torch.is_grad_enabled() and decoders.sub(s).wants_grad() and
+                   (renderer.decoder_grads is None or s in renderer.decoder_grads)) for s in slots]
+    meta = (renderer, decoders, "color", wmeta, w_color, None, out, (bool(handle_dynamic), bool(use_color)))
     return _MappingLossFn.apply(meta, *c2ws, *[grids[s] for s in slots], *gates)

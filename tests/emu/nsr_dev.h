@@ -177,6 +177,7 @@ NSR_DEV void atomic_add_global(float *p, float v) {
     } while (!__atomic_compare_exchange_n(u, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
 }
 NSR_DEV void atomic_add_lds(float *p, float v) { *p += v; }
+NSR_DEV void atomic_add_lds_i(int *p, int v) { *p += v; }
 NSR_DEV void atomic_add_global_d(double *p, double v) { *p += v; }
 NSR_DEV void atomic_max_pos(float *p, float v) {
     uint32_t *u = reinterpret_cast<uint32_t *>(p);

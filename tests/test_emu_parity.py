@@ -486,3 +486,90 @@ def test_masked_adam_multi_and_pack_rows(emu):
         sel = masks[i].astype(bool)
         assert np.array_equal(P[i][sel], 2 * before[i][sel]) and np.array_equal(P[i][~sel], before[i][~sel])
     assert np.array_equal(flat * 0.5 * 2, flat) and np.array_equal(pose, want[-48:] * 2)
+
+
+@pytest.mark.parametrize("n,dyn,col", [(203, True, True), (1, True, True), (2, True, False), (1500, True, True), (5000, True, True), (64, False, True),
+                                       (300, False, False)])       # <= 1024: rank by counting; <= 4096: radix select on cached keys; above: recomputed
+def test_tracking_loss_matches_the_reference_expression(emu, n, dyn, col):
+    """nsr_tracking_loss vs Tracker.optimize_cam_in_batch's loss (src/Tracker.py:108-124) on the COMPACTED batch, with autograd
+    for d loss / d depth and d loss / d rgb: the median of `tmp` (lower middle element) is found without a sort."""
+    from emu_harness import ptr
+    g = torch.Generator().manual_seed(100 + n)
+    gd = (torch.rand((n,), generator=g) * 4 + 0.5).float()
+    gd[torch.rand((n,), generator=g) < 0.1] = 0.0
+    depth = (gd.double() + torch.randn((n,), generator=g).double() * 0.3)
+    depth[torch.rand((n,), generator=g) < 0.05] *= 3.0                    # outliers: the dynamic-object mask must cut some rays
+    if n > 10:
+        depth[5] = gd[5].double()                                          # |0|: zero gradient
+    var = torch.rand((n,), generator=g).double() * 0.2
+    rgb, gc = torch.rand((n, 3), generator=g), torch.rand((n, 3), generator=g)
+    if n > 10:
+        rgb[7, 1] = gc[7, 1]
+    keep = torch.rand((n,), generator=g) < 0.85
+    if n <= 2:
+        keep[:] = True
+    w = 0.5
+    # reference, on the compacted batch
+    d_l, r_l = depth[keep].clone().requires_grad_(True), rgb[keep].clone().requires_grad_(True)
+    g_k, c_k, v_k = gd[keep], gc[keep], var[keep]
+    tmp = torch.abs(g_k - d_l) / torch.sqrt(v_k + 1e-10)
+    mask = ((tmp < 10 * tmp.median()) & (g_k > 0)) if dyn else (g_k > 0)
+    ref = tmp[mask].sum()
+    if col:
+        ref = ref + w * torch.abs(c_k - r_l)[mask].sum()
+    ref.backward()
+    want_d = torch.zeros(n, dtype=torch.float64); want_d[keep] = d_l.grad
+    want_r = torch.zeros((n, 3)); want_r[keep] = r_l.grad if r_l.grad is not None else torch.zeros_like(r_l)
+    if dyn and n > 100:
+        assert int(mask.sum()) < int((g_k > 0).sum())                      # the median test really removes rays in this case
+    loss = np.zeros(1)
+    dld, dlr = np.full(n, np.nan), np.full((n, 3), np.nan, np.float32)
+    a = [np.ascontiguousarray(x) for x in (gd.numpy(), gc.numpy(), keep.numpy().astype(np.uint8), depth.numpy(), var.numpy(), rgb.numpy())]
+    emu.check(emu.nsr_tracking_loss(n, ptr(a[0]), ptr(a[1]), ptr(a[2]), ptr(a[3]), ptr(a[4]), ptr(a[5]), int(dyn), int(col), w,
+                                    ptr(loss), ptr(dld), ptr(dlr) if col else None, None))
+    assert abs(loss[0] - float(ref.detach())) <= 1e-6 * abs(float(ref.detach())) + 1e-12, (loss[0], float(ref.detach()))
+    # (torch's CPU sqrt for doubles is not correctly rounded -- 1 ulp off IEEE on ~1 % of the inputs -- so 1/sqrt agrees to 1e-15, not bitwise)
+    assert np.array_equal(dld == 0, want_d.numpy() == 0) and np.allclose(dld, want_d.numpy(), rtol=1e-14, atol=0)
+    if col:
+        assert np.array_equal(dlr, want_r.numpy())
+    # keep = NULL: every ray counts
+    loss2, dld2 = np.zeros(1), np.full(n, np.nan)
+    emu.check(emu.nsr_tracking_loss(n, ptr(a[0]), ptr(a[1]), None, ptr(a[3]), ptr(a[4]), ptr(a[5]), int(dyn), 0, w, ptr(loss2), ptr(dld2), None, None))
+    tmp = torch.abs(gd - depth) / torch.sqrt(var + 1e-10)
+    mask = ((tmp < 10 * tmp.median()) & (gd > 0)) if dyn else (gd > 0)
+    assert abs(loss2[0] - float(tmp[mask].sum())) <= 1e-9 * float(tmp[mask].sum()) + 1e-12
+    assert np.array_equal(dld2 != 0, (mask & (gd.double() != depth)).numpy())
+
+
+def test_camera_from_tensor_forward_and_backward(emu):
+    """nsr_camera_from_tensor vs quad2rotation / get_camera_from_tensor (src/common.py:137-176, restated with torch ops) and
+    autograd through them; quaternions are NOT normalised (the optimiser moves all four components)."""
+    from emu_harness import ptr
+    g = torch.Generator().manual_seed(9)
+    B = 5
+    cam = torch.randn((B, 7), generator=g)
+    cam[:, :4] += torch.tensor([1.0, 0.0, 0.0, 0.0])
+    cam[0, :4] = torch.tensor([1.0, 0.0, 0.0, 0.0])                      # identity rotation
+    cam[1, :4] *= 1.7                                                    # far from unit norm
+
+    def ref(t):
+        qr, qi, qj, qk = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
+        two_s = 2.0 / (t[:, :4] * t[:, :4]).sum(-1)
+        R = torch.stack([1 - two_s * (qj ** 2 + qk ** 2), two_s * (qi * qj - qk * qr), two_s * (qi * qk + qj * qr),
+                         two_s * (qi * qj + qk * qr), 1 - two_s * (qi ** 2 + qk ** 2), two_s * (qj * qk - qi * qr),
+                         two_s * (qi * qk - qj * qr), two_s * (qj * qk + qi * qr), 1 - two_s * (qi ** 2 + qj ** 2)], -1).reshape(-1, 3, 3)
+        return torch.cat([R, t[:, 4:, None]], 2)
+
+    t = cam.clone().requires_grad_(True)
+    want = ref(t)
+    w = torch.randn((B, 3, 4), generator=g)
+    (want * w).sum().backward()
+    c_np = np.ascontiguousarray(cam.numpy())
+    rt = np.full((B, 3, 4), np.nan, np.float32)
+    emu.check(emu.nsr_camera_from_tensor(ptr(c_np), B, ptr(rt), None, None, None))
+    assert np.allclose(rt, want.detach().numpy(), rtol=0, atol=2e-6)
+    assert np.array_equal(rt[0, :, :3], np.eye(3, dtype=np.float32))
+    d = np.full((B, 7), np.nan, np.float32)
+    w_np = np.ascontiguousarray(w.numpy())
+    emu.check(emu.nsr_camera_from_tensor(ptr(c_np), B, None, ptr(w_np), ptr(d), None))
+    assert np.allclose(d, t.grad.numpy(), rtol=1e-5, atol=1e-5 * float(t.grad.abs().max()))

@@ -96,6 +96,86 @@ def test_fused_mapping_loss_equals_unfused_path(stage):
         assert rel_err(c1[k], c0[k]) < 1e-4, (k, c1[k], c0[k])
 
 
+@pytest.mark.parametrize("dyn,col,dec_grads", [(True, True, False), (True, True, True), (False, True, False), (True, False, False)])
+def test_fused_tracking_loss_equals_unfused_path(dyn, col, dec_grads):
+    """nice_slam_amd.tracking_loss (window kernel + render + nsr_tracking_loss + backward to the pose) against the same
+    iteration spelled with get_samples_window / render_batch_ray / the torch loss of Tracker.py:108-124 on the compacted batch."""
+    import nice_slam_amd as nsa
+    sc = make_scene(seed=85, n_rays=8, small=True)
+    H, W, fx, fy, cx, cy = sc["intr"]
+    renderer, dec, grids_dev = build_product(sc, DEV)
+    n, eh, ew = 300, 3, 5
+    idx = torch.randint((H - 2 * eh) * (W - 2 * ew), (n,), generator=torch.Generator().manual_seed(6))
+    depth_img = sc["depth_img"].clone()
+    depth_img[::7, ::5] *= 3.0                                   # "dynamic objects": depth the map does not explain
+    depth_img, color_img = depth_img.to(DEV), torch.rand((H, W, 3), generator=torch.Generator().manual_seed(7)).to(DEV)
+    for p in dec.parameters():
+        p.requires_grad_(dec_grads)
+
+    def run(fused):
+        c2w = sc["c2w"].clone().to(DEV).requires_grad_(True)
+        for p in dec.parameters():
+            p.grad = None
+        out = {}
+        if fused:
+            loss = nsa.tracking_loss(renderer, grids_dev, dec, c2w, depth_img, color_img, n, eh, ew, w_color=0.5, handle_dynamic=dyn,
+                                     use_color=col, indices=idx, out=out)
+        else:
+            w = nsa.get_samples_window(eh, H - eh, ew, W - ew, n, H, W, fx, fy, cx, cy, [c2w], [depth_img], [color_img], sc["bound"], DEV,
+                                       indices=idx)
+            depth, unc, color = renderer.render_batch_ray(grids_dev, dec, w.rays_d, w.rays_o, DEV, "color", gt_depth=w.gt_depth,
+                                                          gt_max=w.kept_max)
+            k = w.keep
+            gd, dep, unc, colr, gc = w.gt_depth[k], depth[k], unc[k].detach(), color[k], w.gt_color[k]
+            tmp = torch.abs(gd - dep) / torch.sqrt(unc + 1e-10)
+            mask = ((tmp < 10 * tmp.median()) & (gd > 0)) if dyn else (gd > 0)
+            loss = tmp[mask].sum()
+            if col:
+                loss = loss + 0.5 * torch.abs(gc - colr)[mask].sum()
+            out["n_mask"], out["n_pos"] = int(mask.sum()), int((gd > 0).sum())
+        loss.backward()
+        return float(loss.detach()), c2w.grad.clone(), {k_: p.grad.clone() for k_, p in dec.named_parameters() if p.grad is not None}, out
+
+    l0, g0, p0, o0 = run(False)
+    l1, g1, p1, o1 = run(True)
+    # (whether the median test removes rays depends on the random-init map; tests/test_emu_parity.py pins a case where it does)
+    assert 0.3 < float(o1["keep"].float().mean()) < 1.0
+    assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)
+    assert rel_err(g1, g0) < 1e-5
+    assert set(p0) == set(p1) and (len(p0) > 0) == dec_grads
+    for k_ in p0:
+        assert rel_err(p1[k_], p0[k_]) < 2e-5, k_
+    assert all(v.grad is None for v in grids_dev.values())
+
+
+def test_get_camera_from_tensor_drop_in():
+    """nice_slam_amd.get_camera_from_tensor vs src/common.py:137-176 restated with torch ops, (7,) and (B,7), with gradients."""
+    import nice_slam_amd as nsa
+    g = torch.Generator().manual_seed(11)
+    cam = torch.randn((4, 7), generator=g)
+    cam[:, 0] += 1.5
+
+    def ref(t):
+        qr, qi, qj, qk = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
+        two_s = 2.0 / (t[:, :4] * t[:, :4]).sum(-1)
+        R = torch.stack([1 - two_s * (qj ** 2 + qk ** 2), two_s * (qi * qj - qk * qr), two_s * (qi * qk + qj * qr),
+                         two_s * (qi * qj + qk * qr), 1 - two_s * (qi ** 2 + qk ** 2), two_s * (qj * qk - qi * qr),
+                         two_s * (qi * qk - qj * qr), two_s * (qj * qk + qi * qr), 1 - two_s * (qi ** 2 + qj ** 2)], -1).reshape(-1, 3, 3)
+        return torch.cat([R, t[:, 4:, None]], 2)
+
+    w = torch.randn((4, 3, 4), generator=g)
+    t0 = cam.clone().requires_grad_(True)
+    (ref(t0) * w).sum().backward()
+    t1 = cam.clone().to(DEV).requires_grad_(True)
+    got = nsa.get_camera_from_tensor(t1)
+    (got * w.to(DEV)).sum().backward()
+    assert got.shape == (4, 3, 4) and rel_err(got, ref(cam)) < 1e-6 and rel_err(t1.grad, t0.grad) < 1e-5
+    t2 = cam[2].clone().to(DEV).requires_grad_(True)
+    one = nsa.get_camera_from_tensor(t2)
+    (one * w[2].to(DEV)).sum().backward()
+    assert one.shape == (3, 4) and torch.equal(one, got[2].detach()) and rel_err(t2.grad, t0.grad[2]) < 1e-5
+
+
 def test_masked_adam_multi_equals_per_grid_steps():
     import nice_slam_amd as nsa
     sc = make_scene(seed=83, n_rays=8, small=True)

@@ -173,6 +173,21 @@ def test_replica_tracking_config():
     for a, b, nm in ((depth, depth2, "depth"), (unc, unc2, "var"), (col, col2, "rgb"), (c2w.grad, c2.grad, "d_c2w")):
         assert rel_err(a, b) < TOL, (nm, rel_err(a, b))
     assert all(p.grad is None for p in dec.parameters()) and all(v.grad is None for v in grids.values())
+    # the same iteration as ONE autograd node (nice_slam_amd.tracking_loss: window kernel + render + nsr_tracking_loss)
+    c3 = sc["c2w"][:3].clone().to(dev).requires_grad_(True)
+    l3 = nsa.tracking_loss(renderer, grids, dec, c3, sc["depth_img"].to(dev), sc["color_img"].to(dev), 200, 100, 100, w_color=0.5,
+                           indices=idx)
+    l3.backward()
+    c4 = sc["c2w"][:3].clone().requires_grad_(True)              # oracle with the bounding-box pre-filter of Tracker.py:92-104 (compaction)
+    o4, d4, gd4, gc4 = orc.pixel_rays(idx, 100, H - 100, 100, W - 100, fx, fy, cx, cy, c4, sc["depth_img"], sc["color_img"])
+    with torch.no_grad():
+        t = (sc["bound"].unsqueeze(0) - o4.detach().unsqueeze(-1)) / d4.detach().unsqueeze(-1)
+        inside = torch.min(torch.max(t, dim=2)[0], dim=1)[0] >= gd4
+    depth4, unc4, col4 = orc.render_batch_ray(sc["grids"], sc["params"], d4[inside], o4[inside], "color", gd4[inside], sc["bound"])
+    l4 = loss_fn(depth4, unc4, col4, gd4[inside], gc4[inside])
+    l4.backward()
+    assert abs(float(l3.detach()) - float(l4.detach())) < TOL * abs(float(l4.detach())), (float(l3.detach()), float(l4.detach()), int(inside.sum()))
+    assert rel_err(c3.grad, c4.grad) < TOL, rel_err(c3.grad, c4.grad)
 
 
 def test_edge_cases():

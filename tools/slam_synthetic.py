@@ -177,6 +177,24 @@ class ProductOps:
         self.bound_dev = self.bound.to(self.device)
         self._params = list(self.decoders.parameters())
 
+    def update_tracker_copy(self):
+        """The tracker renders from its OWN copy of the map, refreshed from the shared one before a frame is tracked
+        (Tracker.update_para_from_mapping, src/Tracker.py:130-142: deepcopy of the decoders, clone of every grid).  Static
+        buffers here, so that the captured tracking iteration keeps reading the same addresses."""
+        if not hasattr(self, "c_track"):
+            import copy
+            self.c_track = {k: v.detach().clone(memory_format=torch.preserve_format) for k, v in self.c.items()}
+            self.decoders_track = copy.deepcopy(self.decoders)
+            for p in self.decoders_track.parameters():
+                p.requires_grad_(False)                         # nothing steps them; the reference leaves requires_grad on and discards the grads
+            return
+        with torch.no_grad():
+            for k, v in self.c.items():
+                self.c_track[k].copy_(v)
+            for m_t, m_m in zip(self.decoders_track.children(), self.decoders.children()):
+                m_t.flat_params().copy_(m_m.flat_params())      # one copy per decoder (every Parameter is a view of the flat blob)
+        self.decoders_track.repack()                            # same packed buffers: the captured iteration reads the new weights
+
     def get_samples(self, H0, H1, W0, W1, n, c2w, depth, color):
         return self.nsa.get_samples(H0, H1, W0, W1, n, self.H, self.W, self.fx, self.fy, self.cx, self.cy, c2w, depth, color, self.device)
 
@@ -259,6 +277,55 @@ class MiniSLAM:
         self.counters["tracking_rays"] += int(o.shape[0])
         return loss.detach()
 
+    # -- the same iteration on the fused path: nice_slam_amd.tracking_loss (one autograd node) + capturable Adam, recorded ONCE
+    # into a hipGraph; every later iteration of every frame is a replay (the frame, the pose and the optimiser state live in
+    # static buffers that are refilled / zeroed per frame; per-iteration losses and poses go to device-side history slots).
+    def _track_fused(self, init_cam, color, depth):
+        tc, ops, nsa = self.cfg["tracking"], self.ops, self.ops.nsa
+        n_it = tc["iters"]
+        ft = getattr(self, "_ft", None)
+        if ft is None:
+            ft = self._ft = {"cam": init_cam.clone().requires_grad_(True), "depth": depth.clone(), "color": color.clone(),
+                             "i": torch.zeros(1, dtype=torch.long, device=self.device),
+                             "loss": torch.zeros(n_it, dtype=torch.float64, device=self.device),
+                             "cams": torch.zeros((n_it, init_cam.numel()), dtype=torch.float32, device=self.device), "graph": None}
+            ft["opt"] = torch.optim.Adam([ft["cam"]], lr=tc["lr"], capturable=True)
+        cam, opt = ft["cam"], ft["opt"]
+        with torch.no_grad():
+            cam.copy_(init_cam); ft["depth"].copy_(depth); ft["color"].copy_(color); ft["i"].zero_()
+            for st in opt.state.values():                       # a fresh optimiser per frame (Tracker.py:214-222)
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+
+        def iteration():
+            opt.zero_grad(set_to_none=True)
+            c2w = nsa.get_camera_from_tensor(cam)                # one launch each way (src/common.py:137-176)
+            loss = nsa.tracking_loss(ops.renderer, ops.c_track, ops.decoders_track, c2w, ft["depth"], ft["color"], tc["pixels"],
+                                     tc["ignore_edge_H"], tc["ignore_edge_W"], w_color=tc["w_color_loss"],
+                                     handle_dynamic=tc["handle_dynamic"], use_color=tc["use_color_in_tracking"])
+            loss.backward()
+            opt.step()
+            with torch.no_grad():
+                ft["loss"].index_copy_(0, ft["i"], loss.detach().reshape(1))
+                ft["cams"].index_copy_(0, ft["i"], cam.detach().reshape(1, -1))
+                ft["i"] += 1
+
+        done = 0
+        if ft["graph"] is None:
+            iteration(); done = 1                               # eager once: optimiser state, code load
+            if n_it > 1:
+                torch.cuda.synchronize()
+                ft["graph"] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ft["graph"]):
+                    iteration()
+        for _ in range(n_it - done):
+            ft["graph"].replay()
+        self.counters["tracking_iters"] += n_it
+        self.counters["tracking_rays"] += n_it * tc["pixels"]
+        k = int(torch.argmin(ft["loss"]))                       # Tracker.py:236-246, the one host read of the frame
+        return ft["cams"][k].clone(), float(ft["loss"][k])
+
     # -- Tracker.run, one frame (Tracker.py:176-256)
     def track(self, idx, color, depth):
         tc = self.cfg["tracking"]
@@ -268,6 +335,10 @@ class MiniSLAM:
             init = delta @ pre
         else:
             init = pre
+        if getattr(self.ops, "fused", False) and tc["iters"] > 0:
+            self.ops.update_tracker_copy()                       # Tracker.update_para_from_mapping (Tracker.py:130-142)
+            best, self.last_track_loss = self._track_fused(get_tensor_from_camera(init.detach()).to(self.device), color, depth)
+            return to44(get_camera_from_tensor(best)), init
         cam = get_tensor_from_camera(init.detach()).to(self.device).requires_grad_(True)
         opt = torch.optim.Adam([cam], lr=tc["lr"])
         best, self.last_track_loss = cam.clone().detach(), float("nan")          # iters == 0: the motion-model prediction alone
@@ -397,14 +468,16 @@ class MiniSLAM:
         keys = ("grid_middle", "grid_fine", "grid_color")
         gopt = nsa.MaskedGridAdam({k: ops.c[k] for k in keys}, masks, capturable=True)
         groups = [{"params": ops.color_decoder_params(), "lr": 0.0}]
-        cams, cam_of = [], {}
-        if BA:
+        cam_all, cam_of = None, {}
+        if BA:                                                           # every optimised pose is a row of ONE [n,7] parameter (Adam is
+            rows = []                                                    # elementwise: same update as the reference's per-tensor list)
             for f in frames:
                 if f != oldest:
                     c2w = self.keyframe_dict[f]["est_c2w"] if f != -1 else cur_c2w
-                    cam_of[f] = len(cams)
-                    cams.append(get_tensor_from_camera(c2w.to(self.device)).requires_grad_(True))
-            groups.append({"params": cams, "lr": 0.0})
+                    cam_of[f] = len(rows)
+                    rows.append(get_tensor_from_camera(c2w.to(self.device)))
+            cam_all = torch.stack(rows).requires_grad_(True)
+            groups.append({"params": [cam_all], "lr": 0.0})
         opt = torch.optim.Adam(groups, capturable=True, foreach=True)
         data = []
         for f in frames:
@@ -418,7 +491,8 @@ class MiniSLAM:
         def iteration(stage):
             opt.zero_grad(set_to_none=True)
             ops.zero_grads()
-            fr = [(get_camera_from_tensor(cams[cam_of[f]]) if f in cam_of else c2w, d, c) for f, d, c, c2w in data]
+            poses = nsa.get_camera_from_tensor(cam_all).unbind(0) if BA else ()     # one launch each way for the whole window
+            fr = [(poses[cam_of[f]] if f in cam_of else c2w, d, c) for f, d, c, c2w in data]
             loss = nsa.mapping_loss(ops.renderer, ops.c, ops.decoders, fr, pix, stage, w_color=mc["w_color_loss"])
             loss.backward()
             opt.step()
@@ -454,8 +528,8 @@ class MiniSLAM:
         if BA:                                                             # Mapper.py:527-541
             for f in frames:
                 if f in cam_of and f != -1:
-                    self.keyframe_dict[f]["est_c2w"] = to44(get_camera_from_tensor(cams[cam_of[f]].detach())).clone()
-            return to44(get_camera_from_tensor(cams[cam_of[-1]].detach())).clone()
+                    self.keyframe_dict[f]["est_c2w"] = to44(get_camera_from_tensor(cam_all[cam_of[f]].detach())).clone()
+            return to44(get_camera_from_tensor(cam_all[cam_of[-1]].detach())).clone()
         return None
 
     # -- the coarse mapper's optimize_map (Mapper.py:230-545 with coarse_mapper=True): 'global' keyframe selection (:79-80,
