@@ -699,7 +699,8 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
         dbg.stamp(60);
 #endif
         if (grp == (long long)bid_x()) {
-            copy_f4<(AUX_FLOATS + packed_total(KIND)) / 4>(aux, D.packed);      // visible after the barrier below
+            copy_f4<(AUX_FLOATS + packed_total(KIND)) / 4>(aux, D.packed);      // visible after the barrier below (8 or 11 loads in
+                                                                                 // flight per thread instead of 4: measured, no gain)
             dbg.stamp(1);
         }
         if (has_ray) rayb[t0] = ray_v;
@@ -770,13 +771,33 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
             const bool has_next = tile + nwaves < tile_end;
             TileCtx nx;
             Lvl Lm_next;
-            constexpr bool kWarm = KIND != NSR_FINE;            // (the fine pass has no registers to spare for it)
-            float warm[8];
-            auto mid = [&]() {                                  // next tile: set up, pull its voxel lines towards the L2
-                if (kWarm && has_next) {
-                    Lm_next = setup(nx, tile + nwaves);
+            // Next tile: set up, and pull its voxel lines towards L1 / L2 while the embedding stage runs.
+            // Big grids (fine, colour pass): through LDS-sink loads, no destination register -- plain loads get spilled there and
+            // every spill waits for its load (measured: -7 % / -5 % kernel time against them); every lane touches its own 16 bytes
+            // of all 8 voxels (measured best among 2 / 4 / 8 requests per lane).  The middle / coarse passes have registers to
+            // spare: lane group g loads one word of each half of voxels 2g, 2g+1 and keeps them alive until the gather (5 %
+            // faster there than the sink, or than no prefetch).
+#ifndef NSR_PF_MODE
+#define NSR_PF_MODE 0
+#endif
+            constexpr int kPfMode = NSR_PF_MODE ? NSR_PF_MODE : ((KIND == NSR_FINE || KIND == NSR_COLOR) ? 1 : 2);
+            float warm[4] = {0.f, 0.f, 0.f, 0.f};
+            auto touch = [&](const GridDev &GG, const Lvl &LL) {
+                if (kPfMode == 1) {
+                    float *sink = reinterpret_cast<float *>(ztmp);      // (scratch of the sample placement: dead during the tiles)
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) warm[k] = G.feat[(long long)corner_vox(nx.L, k) * kC + 4 * g];
+                    for (int k = 0; k < 8; ++k) prefetch_line(GG.feat + (long long)corner_vox(LL, k) * kC + 4 * g, sink);
+                } else {
+                    const int v0 = LL.vox + ((g & 1) ? LL.sy : 0) + ((g & 2) ? LL.sz : 0);
+                    const float *p0 = GG.feat + (long long)v0 * kC, *p1 = p0 + (long long)LL.sx * kC;
+                    warm[0] = p0[0]; warm[1] = p0[16]; warm[2] = p1[0]; warm[3] = p1[16];
+                }
+            };
+            auto mid = [&]() {
+                if (has_next) {
+                    Lm_next = setup(nx, tile + nwaves);
+                    touch(G, nx.L);
+                    if constexpr (KIND == NSR_FINE) touch(P.grid[NSR_MIDDLE], Lm_next);
                 }
             };
             F4 dr = cur.active ? draw[cur.pidx] : F4{0.f, 0.f, 0.f, 0.f};
@@ -795,15 +816,14 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
             // every load of the next tile is consumed before this tile's atomics are issued (see the header)
             Act<2> c_next, cm_next;
             if (has_next) {
-                if (!kWarm) Lm_next = setup(nx, tile + nwaves);
                 GatherRaw rawm;
                 gather_issue(raw, G, nx.L, g);
                 if (KIND == NSR_FINE) gather_issue(rawm, P.grid[NSR_MIDDLE], Lm_next, g);
                 c_next = gather_finish(raw, nx.L);
                 if (KIND == NSR_FINE) cm_next = gather_finish(rawm, Lm_next);
-                if (kWarm) {
+                if (kPfMode == 2) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) keep_alive(warm[k]);
+                    for (int k = 0; k < 4; ++k) keep_alive(warm[k]);
                 }
             }
             float dux = 0.f, duy = 0.f, duz = 0.f;

@@ -88,6 +88,14 @@ struct Dbg {
     }
 };
 
+// Pull the 64-byte line of `p` towards the L2 without a destination register: a global -> LDS load (gfx950
+// global_load_lds_dword) into a sink region nobody reads.  A plain load kept alive in a VGPR gets spilled by the register
+// allocator of the backward kernel -- `s_waitcnt vmcnt(0)` + scratch store right behind every such load, i.e. the full memory
+// latency eight times in a row (measured: 6.7k cycles per tile).
+NSR_DEV void prefetch_line(const float *p, float *lds_sink) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
+                                     (__attribute__((address_space(3))) void *)lds_sink, 4, 0, 0);
+}
 NSR_DEV void atomic_add_global(float *p, float v) { unsafeAtomicAdd(p, v); }
 NSR_DEV void atomic_add_lds(float *p, float v) { atomicAdd(p, v); }
 NSR_DEV void atomic_add_lds_i(int *p, int v) { atomicAdd(p, v); }

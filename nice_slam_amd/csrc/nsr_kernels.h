@@ -138,14 +138,18 @@ NSR_KERNEL void pack_kernel(const float *__restrict__ flat, float *__restrict__ 
     packed[gidx] = v;
 }
 
-// cooperative global -> LDS copy of NF4 16-byte words; four loads in flight per thread before the first store
-template <int NF4>
+// cooperative global -> LDS copy of NF4 16-byte words; B loads in flight per thread before the first store (a fresh block's
+// first loads take several thousand cycles: the fewer dependent rounds, the shorter its prologue)
+template <int NF4, int B = 4>
 NSR_DEV void copy_f4(float *dst, const float *__restrict__ src) {
     const int nt = nthreads();
     int t = tid();
-    for (; t + 3 * nt < NF4; t += 4 * nt) {
-        const F4 a = ld4(src + 4 * t), b = ld4(src + 4 * (t + nt)), c = ld4(src + 4 * (t + 2 * nt)), d = ld4(src + 4 * (t + 3 * nt));
-        st4(dst + 4 * t, a); st4(dst + 4 * (t + nt), b); st4(dst + 4 * (t + 2 * nt), c); st4(dst + 4 * (t + 3 * nt), d);
+    for (; t + (B - 1) * nt < NF4; t += B * nt) {
+        F4 v[B];
+#pragma unroll
+        for (int k = 0; k < B; ++k) v[k] = ld4(src + 4 * (t + k * nt));
+#pragma unroll
+        for (int k = 0; k < B; ++k) st4(dst + 4 * (t + k * nt), v[k]);
     }
     for (; t < NF4; t += nt) st4(dst + 4 * t, ld4(src + 4 * t));
 }

@@ -165,6 +165,7 @@ NSR_DEV void keep_alive(float) {}
 NSR_DEV void loop_fence() {}
 NSR_DEV void block_sync() { emu::block_sync_impl(); }
 
+NSR_DEV void prefetch_line(const float *, float *) {}
 NSR_DEV void atomic_add_global(float *p, float v) {
     // blocks may run on different OS threads: real atomic read-modify-write
     uint32_t *u = reinterpret_cast<uint32_t *>(p);

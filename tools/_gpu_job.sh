@@ -1,7 +1,9 @@
-mkdir -p gpurun_out/r02s
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r02s/smoke.log 2>&1; tail -4 gpurun_out/r02s/smoke.log
-timeout 300 python bench.py --no-cpu-baseline --windows 1 2>/dev/null | cut -c1-200
-sh tools/pmc_bench.sh r02 > gpurun_out/r02s/pmc.log 2>&1; tail -3 gpurun_out/r02s/pmc.log | cut -c1-400
-for c in 1 0 2 3 tracking 4; do
-  sh tools/profile_bench.sh r02c_c$c --config $c > gpurun_out/r02s/c$c.log 2>&1; tail -1 gpurun_out/r02s/c$c.log | cut -c1-230
+for i in 1 2; do
+for v in pf8 pfh cb8 cb11; do
+NSR_LIB_PATH=$PWD/nice_slam_amd/_ab/libnsr_$v.so timeout 300 python bench.py --no-cpu-baseline --windows 3 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('$v', round(r['value']), round(r['ms_per_step'],4), r['kernel_ms'])"
+done
+done
+for v in pf8 pfh cb11; do
+NSR_LIB_PATH=$PWD/nice_slam_amd/_ab/libnsr_$v.so timeout 300 python bench.py --config 2 --no-cpu-baseline --windows 1 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('$v c2', round(r['value']), round(r['ms_per_step'],4), r['kernel_ms'])"
+NSR_LIB_PATH=$PWD/nice_slam_amd/_ab/libnsr_$v.so timeout 300 python bench.py --config tracking --no-cpu-baseline --windows 1 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print('$v trk', round(r['value']), round(r['ms_per_step'],4), r['kernel_ms'])"
 done
