@@ -156,7 +156,11 @@ class _FlatDecoder(nn.Module):
     #     ACCUMULATES into the blob -- autograd's semantics -- and nothing is assigned;
     #   * anything else (foreign .grad tensors): the caller falls back to a temporary blob + publish_grads().
     def grad_target(self):
-        """-> (flat gradient buffer, mode) with mode in {"overwrite", "accumulate"}, or (None, None) for the fallback."""
+        """-> (flat gradient buffer, mode) with mode in {"overwrite", "accumulate"}, or (None, None) for the fallback.
+        ``self.persistent_grads = False`` (default True) always takes the fallback: fresh gradient tensors per backward, like
+        stock autograd -- for callers that keep references to ``.grad`` tensors across ``zero_grad(set_to_none=True)``."""
+        if not getattr(self, "persistent_grads", True):
+            return None, None
         f = self.flat_params()
         if self._grad_flat is None or self._grad_flat.device != f.device:
             self._grad_flat = torch.zeros_like(f)

@@ -201,6 +201,9 @@ class _MappingLossFn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_loss):
+        if ctx.state is None:
+            raise RuntimeError("nice_slam_amd: backward through mapping_loss / tracking_loss a second time is not supported (the "
+                               "saved buffers are released after the first backward)")
         a, meta, kept, (need_pose, need_grid, need_par), dl_depth, dl_rgb, zero_buf, wm = ctx.state
         # the loss is the root of the caller's graph (loss.backward(), Mapper.py:503): its incoming gradient is 1
         d_o, d_d, d_grids = render_backward(a, meta, kept, (need_pose, need_pose, need_grid, need_par), dl_depth, None, dl_rgb,

@@ -142,7 +142,9 @@ class _RenderFn(torch.autograd.Function):
         keep.append(zsave)
         lib.check(lib.nsr_render_fwd(C.byref(a), stream), "nsr_render_fwd")
         if need_bwd:
-            ctx.args, ctx.keep = a, (keep, rays_o, rays_d, gt_depth, grids, flats, packed, raw, depth)
+            # `depth` is an OUTPUT: kept as a detached alias (same storage, different tensor object), so that no reference
+            # cycle output -> grad_fn -> ctx -> output forms (a forward whose backward never runs is then freed normally)
+            ctx.args, ctx.keep = a, (keep, rays_o, rays_d, gt_depth, grids, flats, packed, raw, depth.detach())
             ctx.meta = (renderer, decoders, stage, S, reduce_hook)
         return depth, var, rgb
 
@@ -152,6 +154,9 @@ class _RenderFn(torch.autograd.Function):
         slots = stage_slots(ctx.meta[2])
         need = (ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3:3 + len(slots)],
                 ctx.needs_input_grad[3 + len(slots):3 + 2 * len(slots)])
+        if ctx.keep is None:
+            raise RuntimeError("nice_slam_amd: backward through render_batch_ray a second time is not supported (the saved "
+                               "buffers are released after the first backward; render again instead of retain_graph=True)")
         g_depth = g_depth.to(torch.float64).contiguous()
         g_var = g_var.to(torch.float64).contiguous()
         g_rgb = g_rgb.to(torch.float32).contiguous()
