@@ -77,6 +77,17 @@ int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays,
         if (a->n_rays > 0 && (!a->rays_o || !a->rays_d)) return fail("nsr: null ray pointers");
     }
     P.rays_per_block = bwd ? rays_per_block_bwd(P.S) : rays_per_block(P.S);
+    if (!bwd) {
+        // Small batches (the tracker's 200 rays): a forward block runs its decoders one after the other, so with few blocks the
+        // launch takes one block's serial chain while most CUs idle.  Fewer rays per block -> one block per CU as long as
+        // the batch allows (NSR_FWD_SMALL=0: always full 12-tile blocks).
+        static const bool small_ok = [] { const char *e = getenv("NSR_FWD_SMALL"); return !(e && e[0] == '0'); }();
+        if (small_ok) {
+            long long want = (P.n_rays + kDefaultBwdBlocks - 1) / kDefaultBwdBlocks;
+            if (want < 1) want = 1;
+            if (want < P.rays_per_block) P.rays_per_block = (int)want;
+        }
+    }
     P.tiles_per_block = (P.rays_per_block * P.S + nsr::kTile - 1) / nsr::kTile;
     P.n_groups = (P.n_rays + P.rays_per_block - 1) / P.rays_per_block;
     P.rays_o = a->rays_o;

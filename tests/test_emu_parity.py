@@ -1,6 +1,7 @@
 """CPU: the kernel SOURCES (nice_slam_amd/csrc, compiled for the host against the fiber shim in tests/emu)
 against the reference goldens and the oracle.  This exercises every index, layout and reduction of the HIP
 kernels without a GPU; the GPU run (test_hip_parity.py) then only has to confirm the hardware primitives."""
+import os
 import shutil
 
 import numpy as np
@@ -573,3 +574,17 @@ def test_camera_from_tensor_forward_and_backward(emu):
     w_np = np.ascontiguousarray(w.numpy())
     emu.check(emu.nsr_camera_from_tensor(ptr(c_np), B, None, ptr(w_np), ptr(d), None))
     assert np.allclose(d, t.grad.numpy(), rtol=1e-5, atol=1e-5 * float(t.grad.abs().max()))
+
+
+def test_full_size_forward_blocks_in_a_subprocess():
+    """nsr_render_fwd shrinks its blocks for small batches (one block per CU); NSR_FWD_SMALL=0 keeps the 12-tile blocks the
+    large batches use, so that the small CPU scenes cover that shape too (the switch is read once per process)."""
+    import subprocess, sys
+    if os.environ.get("NSR_FWD_SMALL") == "0":
+        pytest.skip("already the inner run")
+    env = dict(os.environ, NSR_FWD_SMALL="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k",
+                        "golden_forward or random_scene or fused_mapping_loss or other_sample_counts"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
