@@ -30,7 +30,9 @@ HBM_PEAK = 8.0e12
 # necessary / executed MAC per sample point, SURVEY §8(d)
 FWD_MAC = {"coarse": 6176, "middle": 15479, "fine": 36078, "color": 51653}
 NEC_MAC = {"coarse": 12352, "middle": 24727, "fine": 59694, "color": 106140}          # fwd + bwd, what the optimiser needs
-EXEC_BWD_MAC = {k: 2 * v for k, v in FWD_MAC.items()}                                     # + dW of every decoder: 3x fwd in total
+# MACs per sample point the backward kernel actually issues (forward re-run + dX + dW of every decoder): counted by
+# SQ_INSTS_VALU_MFMA_MOPS_F32 (x 512 FLOP) in profiles/r02_pmc_bench_kernels.txt; coarse: 3 x forward (not measured)
+EXEC_BWD_MAC = {"coarse": 3 * 6176, "middle": 46080, "fine": 102400, "color": 148480}
 
 # ---- BASELINE.json configs ------------------------------------------------------------------------
 GRID_LEN = {"coarse": 2, "middle": 0.32, "fine": 0.16, "color": 0.16, "bound_divisible": 0.32}

@@ -1382,7 +1382,8 @@ NSR_KERNEL void tracking_loss_kernel(const TrackLossParams P, const int key_cap)
     double part = 0.0, cpart = 0.0;
     for (long long i = t; i < P.n; i += nt) {
         const float gd = P.gt_depth[i];
-        const double diff = (double)gd - P.depth[i], rs = sqrt(P.var[i] + 1e-10), v = fabs(diff) / rs;
+        const double diff = (double)gd - P.depth[i], rs = sqrt(P.var[i] + 1e-10);
+        const double v = (cached && i < key_cap && (!P.keep || P.keep[i])) ? __builtin_bit_cast(double, keys[i]) : fabs(diff) / rs;
         bool m = (!P.keep || P.keep[i]) && gd > 0.f;
         if (use_thr) m = m && (v < thr);
         // d |x| = sign(x) with sign(0) = 0 (torch.abs backward)
@@ -1397,13 +1398,14 @@ NSR_KERNEL void tracking_loss_kernel(const TrackLossParams P, const int key_cap)
             }
         }
     }
-    red[t] = part + (double)P.w_color * cpart;
+    const double mine = wave_sum_d(part + (double)P.w_color * cpart);      // wave sums, then one LDS round over the waves
+    if ((t & 63) == 0) red[t >> 6] = mine;
     block_sync();
-    for (int s = nt >> 1; s > 0; s >>= 1) {
-        if (t < s) red[t] += red[t + s];
-        block_sync();
+    if (t == 0) {
+        double s = 0.0;
+        for (int w = 0; w < (nt >> 6); ++w) s += red[w];
+        atomic_add_global_d(P.loss, s);
     }
-    if (t == 0) atomic_add_global_d(P.loss, red[0]);
 }
 
 // ------------------------------------------------------------------------------------------------
