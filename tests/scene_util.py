@@ -93,22 +93,46 @@ def oracle_render(sc, stage, backward=False, with_depth=True, rays=None, lo=torc
     return out
 
 
-def oracle_render_chunked(sc, stage, chunk=10000, lo=torch.float32):
+def _chunk_job(args):
+    """worker of oracle_render_chunked (module level: runs in a spawned process; CPU only)"""
+    sub, stage, lo_name, threads = args
+    torch.set_num_threads(threads)
+    r = oracle_render(sub, stage, backward=True, lo=getattr(torch, lo_name))
+    return {k: v for k, v in r.items()}
+
+
+def oracle_render_chunked(sc, stage, chunk=10000, lo=torch.float32, workers=None):
     """``oracle_render(..., backward=True)`` over a batch too large to hold the oracle's autograd graph at once (100k rays
     = 4.8 M points): rays are independent once the batch-global ``max(gt_depth)`` (Renderer.py:109,144) is shared, so
     every chunk gets the maximum-depth ray appended with zero loss weight; outputs are concatenated, the additive grid /
-    parameter gradients summed."""
+    parameter gradients summed in chunk order.  ``workers`` > 1 (or NSR_ORACLE_WORKERS) runs the chunks in spawned processes
+    -- worth it only on hosts with many more cores than torch's small-channel CPU kernels can use (default: serial)."""
+    import multiprocessing as mp
+    import os
     n = sc["rays_o"].shape[0]
     j = int(torch.argmax(sc["gt_depth"]))
-    out, acc = {}, {}
-    parts = {k: [] for k in ("depth", "var", "rgb", "d_rays_o", "d_rays_d")}
+    jobs = []
+    lo_name = str(lo).split(".")[-1]
+    ncpu = os.cpu_count() or 8
+    if workers is None:
+        workers = int(os.environ.get("NSR_ORACLE_WORKERS", "1"))
+    threads = max(1, min(8, ncpu // max(1, workers)))
+    keep = ("grids", "params", "bound", "intr")
     for lo_i in range(0, n, chunk):
         sl = slice(lo_i, min(n, lo_i + chunk))
-        sub = dict(sc)
+        sub = {k: sc[k] for k in keep if k in sc}
         for k in ("rays_o", "rays_d", "gt_depth"):
             sub[k] = torch.cat([sc[k][sl], sc[k][j:j + 1]])
         sub["w"] = {k: torch.cat([v[sl], torch.zeros_like(v[:1])]) for k, v in sc["w"].items()}
-        r = oracle_render(sub, stage, backward=True, lo=lo)
+        jobs.append((sub, stage, lo_name, threads))
+    if workers > 1 and len(jobs) > 1:
+        with mp.get_context("spawn").Pool(min(workers, len(jobs))) as pool:
+            results = pool.map(_chunk_job, jobs, chunksize=1)
+    else:
+        results = [_chunk_job(jb) for jb in jobs]
+    out, acc = {}, {}
+    parts = {k: [] for k in ("depth", "var", "rgb", "d_rays_o", "d_rays_d")}
+    for r in results:
         for k in parts:
             parts[k].append(r[k][:-1])
         for k, v in r.items():

@@ -260,3 +260,54 @@ def test_captured_fused_iteration_replays_like_eager():
         assert float((c_g[k] - grids_dev[k]).abs().max()) > 1e-3, k
     for (n_, p), q in zip(dec_g.color_decoder.named_parameters(), dec_e.color_decoder.parameters()):
         assert rel_err(p, q) < 1e-4, n_
+
+
+def test_captured_tracking_iteration_follows_repacked_decoders():
+    """The tracker's iteration (get_camera_from_tensor + tracking_loss + capturable Adam on the 7-vector) recorded once; the
+    tracker-side decoder copy is then refreshed like Tracker.update_para_from_mapping (src/Tracker.py:130-142) -- flat copy +
+    NICE.repack(), in place -- and the SAME graph must render with the new weights: replay == eager on the new weights."""
+    import copy
+    import nice_slam_amd as nsa
+    sc = make_scene(seed=86, n_rays=8, small=True)
+    H, W, fx, fy, cx, cy = sc["intr"]
+    renderer, dec_map, grids_dev = build_product(sc, DEV)
+    depth_img, color_img = sc["depth_img"].to(DEV), torch.rand((H, W, 3), generator=torch.Generator().manual_seed(9)).to(DEV)
+    cam0 = torch.tensor([1.0, 0.02, -0.01, 0.03, 0.0, 0.0, 0.0]) + torch.cat([torch.zeros(4), sc["c2w"][:3, 3]])
+    idx = torch.randint((H - 4) * (W - 4), (150,), generator=torch.Generator().manual_seed(10)).to(DEV)
+    new_flat = {s: dec_map.sub(s).flat_params().clone() * 1.03 for s in ("coarse", "middle", "fine", "color")}
+
+    def build():
+        dec = copy.deepcopy(dec_map)
+        for p in dec.parameters():
+            p.requires_grad_(False)
+        cam = cam0.clone().to(DEV).requires_grad_(True)
+        opt = torch.optim.Adam([cam], lr=torch.tensor(1e-3, device=DEV), capturable=True)
+        loss_out = torch.zeros(1, dtype=torch.float64, device=DEV)
+
+        def it():
+            opt.zero_grad(set_to_none=True)
+            loss = nsa.tracking_loss(renderer, grids_dev, dec, nsa.get_camera_from_tensor(cam), depth_img, color_img, 150, 2, 2,
+                                     indices=idx)
+            loss.backward()
+            opt.step()
+            loss_out.copy_(loss.detach().reshape(1))
+        return dec, cam, loss_out, it
+
+    def refresh(dec):
+        with torch.no_grad():
+            for s, f in new_flat.items():
+                dec.sub(s).flat_params().copy_(f)
+        dec.repack()
+
+    dec_g, cam_g, loss_g, it_g = build()
+    step = nsa.graphs.CapturedStep(it_g, warmup=1)              # executes one iteration, then records one (recording runs nothing)
+    dec_e, cam_e, loss_e, it_e = build()
+    it_e()
+    step(); it_e()
+    assert rel_err(cam_g, cam_e) < 1e-6 and abs(float(loss_g) - float(loss_e)) < 1e-7 * abs(float(loss_e))
+    before = float(loss_g)
+    refresh(dec_g); refresh(dec_e)
+    step(); it_e()
+    assert abs(float(loss_g) - float(loss_e)) < 1e-7 * abs(float(loss_e)), (float(loss_g), float(loss_e))
+    assert abs(float(loss_g) - before) > 1e-6 * abs(before)     # ... and the new weights really changed the render
+    assert rel_err(cam_g, cam_e) < 1e-6

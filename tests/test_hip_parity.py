@@ -108,35 +108,38 @@ def test_synthetic_stress_full_size_vs_oracle():
     got = hip_render(sc, "color", backward=True)
     ref = oracle_render_chunked(sc, "color")
     assert set(ref) <= set(got)
-    bad = parity_failures(got, sc, "color", tol=TOL, ref=ref, truth_fn=lambda: oracle_render_chunked(sc, "color", lo=torch.float64))
-    # Per-ray gradients at this size: among 4.8 M samples a handful sit so close to a discontinuity of the path (the
-    # out-of-bound override, a relu kink) that two fp32 evaluations land on different sides; the reference's own fp32 vs
-    # fp64 evaluations show such isolated rays too (one ray in 30 000 at 4e-5).  For these two tensors the max-norm gate is
-    # therefore applied to all but at most 1 ray in 10 000, and no ray may be grossly off.
-    # The same discontinuities reach the parameter gradients: a relu whose pre-activation is within rounding of zero at ONE of
-    # the 4.8 M points switches dY_i[j] of that point on or off, which moves row j of dW_i and b_i[j] by that point's whole
-    # contribution (~1/sqrt(N) of a sum of N zero-mean terms, i.e. 1e-4...5e-4 here) and everything else by far less.  A
-    # parameter tensor that misses the gate is therefore accepted only with that signature: at most ONE output row beyond
-    # the tolerance, and that row below 1e-3; a layout, indexing or accumulation error would not be confined to one row.
+    # Among 4.8 M samples a handful sit so close to a discontinuity of the path (the out-of-bound override, a relu kink) that
+    # two fp32 evaluations land on different sides; the reference's own fp32 vs fp64 evaluations show such isolated rays too
+    # (one ray in 30 000 at 4e-5).  Two explicitly bounded signatures are therefore accepted for a tensor that misses the gate:
+    #  * per-ray gradients: all but at most 1 ray in 10 000 inside the gate, and no ray grossly off (< 1e-2);
+    #  * parameter gradients: a relu whose pre-activation is within rounding of zero at ONE point switches dY_i[j] of that
+    #    point on or off, which moves row j of dW_i and b_i[j] by that point's whole contribution (~1/sqrt(N) of a sum of N
+    #    zero-mean terms, 1e-4...5e-4 here) and everything else by far less: at most ONE output row beyond the tolerance, and
+    #    that row below 1e-3 (a layout, indexing or accumulation error would not be confined to one row).
+    # Whatever is left goes through the usual secondary gate against an fp64 evaluation (another ~4 minutes of CPU time, only
+    # spent when needed).
     still = []
-    for item in bad:
-        k = item[0]
+    for k in ref:
+        if rel_err(got[k], ref[k]) < TOL:
+            continue
+        a, b = got[k].detach().cpu().double(), ref[k].double()
         if k in ("d_rays_o", "d_rays_d"):
-            a, b = got[k].detach().cpu().double(), ref[k].double()
             err = (a - b).abs().max(1)[0] / b.abs().max()
             n_out = int((err >= TOL).sum())
             print(f"{k}: {n_out} of {err.numel()} rays beyond {TOL}, max {float(err.max()):.2e}, median {float(err.median()):.2e}")
             if n_out <= err.numel() // 10_000 and float(err.max()) < 1e-2:
                 continue
         elif k.startswith("dparam/") and (k.endswith(".weight") or k.endswith(".bias")):
-            a, b = got[k].detach().cpu().double(), ref[k].double()
             err = ((a - b).abs() / b.abs().max()).reshape(a.shape[0], -1).max(1)[0]
             rows = [int(i) for i in torch.nonzero(err >= TOL).flatten()]
             print(f"{k}: output rows beyond {TOL}: {rows}, max {float(err.max()):.2e}, median row {float(err.median()):.2e}")
             if len(rows) <= 1 and float(err.max()) < 1e-3:
                 continue
-        still.append(item)
-    assert not still, still
+        still.append(k)
+    if still:
+        bad = parity_failures({k: got[k] for k in still}, sc, "color", tol=TOL, ref={k: ref[k] for k in still},
+                              truth_fn=lambda: oracle_render_chunked(sc, "color", lo=torch.float64))
+        assert not bad, bad
 
 
 def test_replica_tracking_config():
