@@ -170,6 +170,10 @@ class ProductOps:
         self.H, self.W, self.fx, self.fy, self.cx, self.cy = seq.H, seq.W, seq.fx, seq.fy, seq.cx, seq.cy
         slam = types.SimpleNamespace(nice=True, bound=self.bound, H=seq.H, W=seq.W, fx=seq.fx, fy=seq.fy, cx=seq.cx, cy=seq.cy)
         self.renderer = nsa.Renderer(cfg, None, slam)
+        # This mapper only ever steps the colour decoder (like the reference with fix_fine: True, Mapper.py:335-341); the
+        # reference's autograd nevertheless produces dW for the middle and fine decoders in every iteration and nobody reads
+        # them.  Tell the renderer which parameter gradients are consumed: the other passes skip their dW work.
+        self.renderer.decoder_grads = ("color",)
         self.decoders = nsa.NICE(coarse=True).to(self.device)
         set_decoder_bounds(self.decoders, self.bound, 2.0)
         self.c = {k: v.to(self.device).requires_grad_(True) for k, v in nsa.grid_init(cfg, self.bound).items()}
