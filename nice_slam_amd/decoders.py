@@ -7,13 +7,13 @@ The arithmetic lives in libnsr.so; these classes only own parameters.
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Optional
+from typing import List, Optional
 
 import torch
 import torch.nn as nn
 
 from . import _capi
-from .layout import param_spec, stage_slots
+from .layout import param_spec
 
 
 class _Holder(nn.Module):

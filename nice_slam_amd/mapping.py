@@ -24,7 +24,7 @@ import torch
 from . import _capi
 from .common import _as_f32c, _require_cuda, _stream
 from .layout import param_count, stage_slots
-from .renderer import _SLOT_IDX, _fill_common, _gate, _prep_grids, render_backward
+from .renderer import _fill_common, _gate, _prep_grids, render_backward
 
 
 class WindowSamples:

@@ -61,7 +61,6 @@ class MaskedGridAdam:
             self.masks[k] = m
 
     def _step_multi(self, lrs, grads, zero_grad):
-        import ctypes as C
         lib = _capi.get_lib()
         keys = list(self.grids)
         dev = self.grids[keys[0]].device
