@@ -17,6 +17,14 @@ from . import _capi
 
 
 def _stream(device) -> int:
+    """HIP stream handle for the next libnsr launch on `device`.  The library launches on the CURRENT device (its kernels
+    carry no device guard): a caller working on tensors of another GPU of the same process (the reference lets tracking and
+    mapping name different devices, configs/nice_slam.yaml:31,44) gets that device made current here, like every torch
+    operator does for the duration of its launch."""
+    device = torch.device(device)
+    idx = device.index
+    if idx is not None and idx != torch.cuda.current_device():
+        torch.cuda.set_device(idx)
     return torch.cuda.current_stream(device).cuda_stream
 
 
