@@ -216,6 +216,8 @@ def main():
                     help="parameter gradients only for the decoder the reference's optimiser steps (colour); default: all, like the reference autograd")
     ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
                     help="multi-GPU: weak = the configuration's rays per GPU, strong = in total (default: strong for config 3 / 4, else weak)")
+    ap.add_argument("--rerun-activations", action="store_true",
+                    help="backward re-runs the decoder forward instead of loading activations saved by the forward (Renderer.save_activations)")
     ap.add_argument("--dense-exchange", action="store_true",
                     help="multi-GPU: all-reduce the whole feature-grid gradients instead of the frustum-selected voxel rows")
     args = ap.parse_args()
@@ -264,6 +266,8 @@ def main():
         grids = {k: v.detach() for k, v in grids.items()}
     if args.stepped_grads_only:
         renderer.decoder_grads = ("color",)
+    if args.rerun_activations:
+        renderer.save_activations = False
     H, W, fx, fy, cx, cy = sc["intr"]
     frames = [(c.to(dev), d.to(dev), col.to(dev)) for c, d, col in sc["frames"]]
     K = len(frames)
@@ -439,6 +443,8 @@ def main():
                                         " (all grid + all decoder grads, like the reference autograd), no optimiser"),
                        "decoder_grads": "none (tracking)" if tracking else ("colour decoder only (what Mapper's optimiser steps)" if args.stepped_grads_only else "all decoders (reference autograd semantics)"),
                        "launch": "hipGraph replay (one captured graph per stage)" if use_graph else "eager",
+                       "activations": "saved by the forward (704 B per point and decoder), loaded by the backward"
+                                      if renderer.save_activations else "decoder forward re-run in the backward",
                        "timed_windows_ms": [round(w_ * 1e3, 3) for w_ in windows], "reported": "median window",
                        "parallelism": exchange},
         }

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define NSR_VERSION 2
+#define NSR_VERSION 3
 
 /* stages of NICE.forward (decoder.py:312-342) */
 enum { NSR_STAGE_COARSE = 0, NSR_STAGE_MIDDLE = 1, NSR_STAGE_FINE = 2, NSR_STAGE_COLOR = 3 };
@@ -102,6 +102,13 @@ typedef struct nsr_render_args {
     float *dl_rgb;            /* [N][3] out, optional */
     float w_color;            /* cfg mapping.w_color_loss */
     int32_t pad2_;
+    /* --- optional (ABI 3): saved decoder activations ---------------------------------------------------------------------
+     * NULL: nsr_render_bwd re-runs the forward of the decoder it differentiates (24 B/point of saved state).  Non-NULL
+     * (nsr_acts_floats(stage, n_rays, n_samples + n_surface) floats, device, uninitialised): nsr_render_fwd also writes the
+     * five hidden states and relu masks of every xyz decoder per sample point (704 B per point and decoder) and
+     * nsr_render_bwd, given the SAME pointer, loads them instead of re-running -- 288 GB of HBM traded for a quarter of the
+     * backward's work.  Ignored in the coarse stage. */
+    float *acts;
 } nsr_render_args;
 
 typedef struct nsr_bwd_args {
@@ -127,6 +134,9 @@ const char *nsr_last_error(void);
 int64_t nsr_param_count(int slot);
 /* number of floats of the packed operand stream for decoder slot `slot` */
 int64_t nsr_packed_count(int slot);
+/* size of nsr_render_args.acts in floats (0 for the coarse stage; -1 on bad arguments) */
+int64_t nsr_acts_floats(int stage, int64_t n_rays, int n_samples_total);
+
 /* floats of scratch nsr_render_bwd needs for (stage, n_rays, max_blocks) */
 int64_t nsr_bwd_workspace_floats(int stage, int64_t n_rays, int n_samples_total, int max_blocks);
 

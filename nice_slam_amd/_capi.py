@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401  -- must be loaded first: libnsr.so binds to the HIP runtime (libamdhip64.so.7) torch already mapped
 
 MAX_SAMPLES = 64
-ABI_VERSION = 2
+ABI_VERSION = 3
 STAGE_ID = {"coarse": 0, "middle": 1, "fine": 2, "color": 3}
 SLOT_NAMES = ("coarse", "middle", "fine", "color")
 
@@ -40,7 +40,7 @@ class NsrRenderArgs(C.Structure):
                 ("depth", C.c_void_p), ("var", C.c_void_p), ("rgb", C.c_void_p), ("raw", C.c_void_p),
                 ("zvals", C.c_void_p),
                 ("gt_color", C.c_void_p), ("keep", C.c_void_p), ("loss", C.c_void_p), ("dl_depth", C.c_void_p), ("dl_rgb", C.c_void_p),
-                ("w_color", C.c_float), ("pad2_", C.c_int32)]
+                ("w_color", C.c_float), ("pad2_", C.c_int32), ("acts", C.c_void_p)]
 
 
 class NsrBwdArgs(C.Structure):
@@ -74,6 +74,7 @@ SYMBOLS = (
     ("nsr_last_error", C.c_char_p, []),
     ("nsr_param_count", C.c_int64, [C.c_int]),
     ("nsr_packed_count", C.c_int64, [C.c_int]),
+    ("nsr_acts_floats", C.c_int64, [C.c_int, C.c_int64, C.c_int]),
     ("nsr_bwd_workspace_floats", C.c_int64, [C.c_int, C.c_int64, C.c_int, C.c_int]),
     ("nsr_pack_params", C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("nsr_render_fwd", C.c_int, [C.POINTER(NsrRenderArgs), C.c_void_p]),

@@ -92,6 +92,8 @@ int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays,
     P.n_groups = (P.n_rays + P.rays_per_block - 1) / P.rays_per_block;
     P.rays_o = a->rays_o;
     P.rays_d = a->rays_d;
+    P.acts = a->stage == NSR_STAGE_COARSE ? nullptr : a->acts;
+    P.n_points_total = (long long)P.n_rays * P.S;
     P.gt_depth = guided ? a->gt_depth : nullptr;
     P.gt_max = a->gt_max;
     for (int i = 0; i < 3; ++i) { P.blo[i] = a->bound_lo[i]; P.bhi[i] = a->bound_hi[i]; }
@@ -174,6 +176,12 @@ const char *nsr_last_error(void) { return g_err.c_str(); }
 int64_t nsr_param_count(int slot) { return (slot < 0 || slot > 3) ? -1 : nsr::param_total(slot); }
 int64_t nsr_packed_count(int slot) { return (slot < 0 || slot > 3) ? -1 : nsr::packed_buf_total(slot); }
 
+int64_t nsr_acts_floats(int stage, int64_t n_rays, int n_samples_total) {
+    if (stage < 0 || stage > 3 || n_rays < 0 || n_samples_total < 1 || n_samples_total > NSR_MAX_SAMPLES) return -1;
+    if (stage == NSR_STAGE_COARSE) return 0;
+    return (int64_t)stage * nsr::kActSlots * n_rays * n_samples_total * 16;      // passes x slots x points x 64 bytes
+}
+
 int64_t nsr_bwd_workspace_floats(int stage, int64_t n_rays, int n_samples_total, int max_blocks) {
     if (stage < 0 || stage > 3 || n_samples_total < 1 || n_samples_total > NSR_MAX_SAMPLES) return -1;
     const int rb = rays_per_block_bwd(n_samples_total);
@@ -204,12 +212,16 @@ int nsr_render_fwd(const nsr_render_args *a, void *stream) {
     const int npts = P.rays_per_block * P.S;
     const int lds = fwd_lds_bytes(P.stage, npts);
     const dim3 grid((unsigned)(P.n_groups < (1 << 20) ? P.n_groups : (1 << 20))), block(64 * P.tiles_per_block);
-#define NSR_FWD(ST)                                                                              \
-    case ST:                                                                                     \
-        if (int rc = launch_cfg(nsr::render_fwd_kernel<ST>, lds, "nsr_render_fwd")) return rc;    \
-        NSR_LAUNCH(nsr::render_fwd_kernel<ST>, grid, block, lds, stream, P);                      \
-        break;
-    switch (P.stage) { NSR_FWD(0) NSR_FWD(1) NSR_FWD(2) NSR_FWD(3) }
+#define NSR_FWD(ST, SV)                                                                               \
+    if (int rc = launch_cfg(nsr::render_fwd_kernel<ST, SV>, lds, "nsr_render_fwd")) return rc;         \
+    NSR_LAUNCH((nsr::render_fwd_kernel<ST, SV>), grid, block, lds, stream, P);
+    const bool save = P.acts != nullptr;           // the variant that also writes the activation slots (nsr_render_args.acts)
+    switch (P.stage) {
+        case 0: NSR_FWD(0, false) break;
+        case 1: if (save) { NSR_FWD(1, true) } else { NSR_FWD(1, false) } break;
+        case 2: if (save) { NSR_FWD(2, true) } else { NSR_FWD(2, false) } break;
+        default: if (save) { NSR_FWD(3, true) } else { NSR_FWD(3, false) } break;
+    }
 #undef NSR_FWD
     return finish("nsr_render_fwd");
 }
@@ -242,13 +254,17 @@ int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream
     const int waves = kBwdWaves;
     const int lds = bwd_lds_bytes(P.stage, npts, P.rays_per_block, waves);
     const dim3 grid(nblk, passes), block(64 * waves);
-#define NSR_BWD(ST)                                                                              \
-    case ST:                                                                                     \
-        if (int rc = launch_cfg(nsr::render_bwd_kernel<ST>, lds, "nsr_render_bwd")) return rc;    \
-        NSR_LAUNCH(nsr::render_bwd_kernel<ST>, grid, block, lds, stream, P);                      \
-        break;
+#define NSR_BWD(ST, SV)                                                                               \
+    if (int rc = launch_cfg(nsr::render_bwd_kernel<ST, SV>, lds, "nsr_render_bwd")) return rc;         \
+    NSR_LAUNCH((nsr::render_bwd_kernel<ST, SV>), grid, block, lds, stream, P);
+    const bool saved = P.acts != nullptr;          // the forward wrote the activation slots (nsr_render_args.acts)
     if (b->ev_start) nsr::rt_record(b->ev_start, stream);
-    switch (P.stage) { NSR_BWD(0) NSR_BWD(1) NSR_BWD(2) NSR_BWD(3) }
+    switch (P.stage) {
+        case 0: NSR_BWD(0, false) break;
+        case 1: if (saved) { NSR_BWD(1, true) } else { NSR_BWD(1, false) } break;
+        case 2: if (saved) { NSR_BWD(2, true) } else { NSR_BWD(2, false) } break;
+        default: if (saved) { NSR_BWD(3, true) } else { NSR_BWD(3, false) } break;
+    }
 #undef NSR_BWD
     if (b->ev_stop) nsr::rt_record(b->ev_stop, stream);
     if (int rc = finish("nsr_render_bwd")) return rc;

@@ -69,6 +69,8 @@ struct RenderParams {
     double *depth, *var;
     float *rgb, *raw;
     double *zvals;            // [N][S] saved sample depths (optional)
+    float *acts;              // saved decoder activations (optional, see ActSink): the backward then loads h_i / relu masks
+    long long n_points_total; // n_rays * S (slot stride of `acts`)
     // backward only
     const double *d_depth, *d_var, *g_depth;
     const float *d_rgb;
@@ -585,16 +587,37 @@ struct Kept {
     unsigned mask[5];
 };
 
+// Saved activations (288 GB of HBM buy the backward its forward re-run): per xyz decoder pass p (middle 0, fine 1, colour 2)
+// and sample point, the five hidden states h_i (what the next layer reads) and the five relu masks -- exactly the `Kept`
+// registers of the lane that computed them.  Slot j (16 bytes per lane) of lane (pt, g) working on global point gp:
+//     acts + (((p * kActSlots + j) * n_points_total + gp) * 4 + g) * 4          j = 2 i + T: h_i k-tile T;  j = 10: masks
+// i.e. a wave's 64 lanes write / read 1 KB contiguous per slot, whatever the tile / ray-group geometry of the kernel.
+constexpr int kActSlots = 11;
+struct ActSink {
+    float *p;                // slot 0 of this lane, NULL for a lane without a point
+    long long stride;        // floats between two slots (n_points_total * 16)
+};
+NSR_DEV ActSink act_sink(const RenderParams &P, int pass, long long gp, int g) {
+    ActSink a;
+    a.stride = P.n_points_total * 16;
+    a.p = (P.acts && gp >= 0) ? P.acts + (long long)pass * kActSlots * a.stride + (gp * 4 + g) * 4 : nullptr;
+    return a;
+}
+NSR_DEV int act_pass(int kind) { return kind - NSR_MIDDLE; }
+
 // MLP (decoder.py:177-203): h_i = relu(W_i x_i + b_i) + (U_i c + v_i), x_3 = [e | h_2]
-template <int KIND, bool KEEP>
+// `save` (forward kernel only): non-NULL = write h_i and the relu masks to the lane's activation slots
+template <int KIND, bool KEEP, bool SAVE = false>
 NSR_DEV void mlp_xyz_fwd(const float *pk, const float *aux, float px, float py, float pz,
-                         const Act<cdim_of(KIND) / 16> &c, int lane, float (&out)[nout_of(KIND)], Kept<KIND> *kept) {
+                         const Act<cdim_of(KIND) / 16> &c, int lane, float (&out)[nout_of(KIND)], Kept<KIND> *kept,
+                         const ActSink *save = nullptr) {
     constexpr int CD = cdim_of(KIND), NOUT = nout_of(KIND), NTC = CD / 16;
     const int g = lane >> 4;
     Act<kET> e;
     embed(e, aux, px, py, pz, g);
     Act<2> h;
     act_zero(h);
+    unsigned mpack0 = 0, mpack1 = 0;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         f32x4 acc[2];
@@ -609,14 +632,20 @@ NSR_DEV void mlp_xyz_fwd(const float *pk, const float *aux, float px, float py, 
             gemv_fwd<2>(acc, h, pk + xyz_mat(CD, i == 1 ? XW1 : (i == 2 ? XW2 : XW4)).pk, lane);
         }
         unsigned m = 0;
-        if (KEEP) m = relu_mask(acc); else relu_plain(acc);
+        if (KEEP || SAVE) m = relu_mask(acc); else relu_plain(acc);
         acc[0] += to_v(ld4(aux + AUX_V + i * 32 + 4 * g));
         acc[1] += to_v(ld4(aux + AUX_V + i * 32 + 16 + 4 * g));
         gemv_fwd<NTC>(acc, c, pk + xyz_mat(CD, i == 0 ? XU0 : (i == 1 ? XU1 : (i == 2 ? XU2 : (i == 3 ? XU3 : XU4)))).pk, lane);
         h.t[0] = acc[0];
         h.t[1] = acc[1];
         if (KEEP) { kept->h[i] = h; kept->mask[i] = m; }
+        if (SAVE) {
+            if (save->p) { st4(save->p + (2 * i) * save->stride, to_F4(h.t[0])); st4(save->p + (2 * i + 1) * save->stride, to_F4(h.t[1])); }
+            if (i < 4) mpack0 |= m << (8 * i); else mpack1 = m;
+        }
     }
+    if (SAVE && save->p)
+        st4(save->p + 10 * save->stride, F4{__builtin_bit_cast(float, mpack0), __builtin_bit_cast(float, mpack1), 0.f, 0.f});
 #pragma unroll
     for (int n = 0; n < NOUT; ++n) {
         const F4 w0 = ld4(aux + AUX_WO + n * 32 + 4 * g), w1 = ld4(aux + AUX_WO + n * 32 + 16 + 4 * g);
@@ -625,6 +654,27 @@ NSR_DEV void mlp_xyz_fwd(const float *pk, const float *aux, float px, float py, 
         s = fmaf(w1.x, h.t[1][0], s); s = fmaf(w1.y, h.t[1][1], s); s = fmaf(w1.z, h.t[1][2], s); s = fmaf(w1.w, h.t[1][3], s);
         out[n] = red_g(s) + aux[AUX_BO + n];
     }
+}
+
+// the backward's view of the same slots (zero for a lane without a point): the relu masks up front, one hidden state at a
+// time right where it is needed -- loading all 40 registers at the head of the tile gets them spilled, and every spill
+// waits for its load
+template <int KIND>
+NSR_DEV void load_masks(Kept<KIND> &K, const ActSink &a) {
+    unsigned m0 = 0u, m1 = 0u;
+    if (a.p) {
+        const F4 mm = ld4(a.p + 10 * a.stride);
+        m0 = __builtin_bit_cast(unsigned, mm.x); m1 = __builtin_bit_cast(unsigned, mm.y);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) K.mask[i] = (m0 >> (8 * i)) & 255u;
+    K.mask[4] = m1 & 255u;
+}
+NSR_DEV Act<2> load_hidden(const ActSink &a, int i) {
+    Act<2> h;
+    if (a.p) { h.t[0] = to_v(ld4(a.p + (2 * i) * a.stride)); h.t[1] = to_v(ld4(a.p + (2 * i + 1) * a.stride)); }
+    else { h.t[0] = f4zero(); h.t[1] = f4zero(); }
+    return h;
 }
 
 // MLP_no_xyz (decoder.py:262-274): h = c; h = relu(W_i h + b_i); after i == 2: h = [c | h]
@@ -703,8 +753,9 @@ NSR_DEV double wave_sum_d(double v) {
 // NICE.forward for the tile of this wave with the packed weights staged in LDS, one decoder after the other
 // (block-wide barriers inside: EVERY wave of the block must call it).  On entry `wl` holds the first decoder of the
 // stage (coarse or middle); on exit the last one.  Returns (r,g,b,occ) before the out-of-bound override.
-template <int STAGE>
-NSR_DEV F4 decode_tile_lds(const RenderParams &P, const float *aux, float *wl, double px, double py, double pz, int lane) {
+template <int STAGE, bool SAVE = false>
+NSR_DEV F4 decode_tile_lds(const RenderParams &P, const float *aux, float *wl, double px, double py, double pz, int lane,
+                           long long gp = -1) {      // gp: global index of the lane's sample point (saved activations), -1: none
     const int g = lane >> 4;
     F4 raw = F4{0.f, 0.f, 0.f, 0.f};
     if (STAGE == NSR_STAGE_COARSE) {
@@ -718,7 +769,8 @@ NSR_DEV F4 decode_tile_lds(const RenderParams &P, const float *aux, float *wl, d
         const Lvl Lm = make_level(P.grid[NSR_MIDDLE], px, py, pz);
         const Act<2> cm = gather_feat(P.grid[NSR_MIDDLE], Lm, g);
         float om[1];
-        mlp_xyz_fwd<NSR_MIDDLE, false>(wl, aux, fx, fy, fz, cm, lane, om, nullptr);
+        const ActSink sm = act_sink(P, 0, gp, g);
+        mlp_xyz_fwd<NSR_MIDDLE, false, SAVE>(wl, aux, fx, fy, fz, cm, lane, om, nullptr, &sm);
         float occ = om[0];
         if (STAGE >= NSR_STAGE_FINE) {
             const Lvl Lf = make_level(P.grid[NSR_FINE], px, py, pz);
@@ -729,7 +781,8 @@ NSR_DEV F4 decode_tile_lds(const RenderParams &P, const float *aux, float *wl, d
             Act<4> cc;
             cc.t[0] = cf.t[0]; cc.t[1] = cf.t[1]; cc.t[2] = cm.t[0]; cc.t[3] = cm.t[1];    // decoder.py:182-187
             float of[1];
-            mlp_xyz_fwd<NSR_FINE, false>(wl, aux + AUX_FLOATS, fx, fy, fz, cc, lane, of, nullptr);
+            const ActSink sf = act_sink(P, 1, gp, g);
+            mlp_xyz_fwd<NSR_FINE, false, SAVE>(wl, aux + AUX_FLOATS, fx, fy, fz, cc, lane, of, nullptr, &sf);
             occ = of[0] + om[0];                                                            // decoder.py:333,341
         }
         if (STAGE == NSR_STAGE_COLOR) {
@@ -739,7 +792,8 @@ NSR_DEV F4 decode_tile_lds(const RenderParams &P, const float *aux, float *wl, d
             load_packed<NSR_COLOR>(wl, P.dec[NSR_COLOR].packed);
             block_sync();
             float oc[4];
-            mlp_xyz_fwd<NSR_COLOR, false>(wl, aux + 2 * AUX_FLOATS, fx, fy, fz, ccol, lane, oc, nullptr);
+            const ActSink sc = act_sink(P, 2, gp, g);
+            mlp_xyz_fwd<NSR_COLOR, false, SAVE>(wl, aux + 2 * AUX_FLOATS, fx, fy, fz, ccol, lane, oc, nullptr, &sc);
             raw.x = oc[0]; raw.y = oc[1]; raw.z = oc[2];
         }
         raw.w = occ;
@@ -754,7 +808,7 @@ NSR_DEV F4 decode_tile_lds(const RenderParams &P, const float *aux, float *wl, d
 // decoder's packed operand stream (61-82 KB) in LDS so that every MFMA operand is an LDS read (~100 cycles)
 // instead of an L2 round trip.  The gathers of the next decoder's features are issued before the barrier.
 // ------------------------------------------------------------------------------------------------
-template <int STAGE>
+template <int STAGE, bool SAVE = false>
 NSR_KERNEL NSR_BOUNDS(768) void render_fwd_kernel(const RenderParams P) {
     char *lds = lds_base();
     const int npts = P.rays_per_block * P.S;
@@ -787,7 +841,7 @@ NSR_KERNEL NSR_BOUNDS(768) void render_fwd_kernel(const RenderParams P) {
         const double pz = (double)P.rays_o[rr * 3 + 2] + (double)P.rays_d[rr * 3 + 2] * z;
         const bool inside = (px > P.blo[0]) && (px < P.bhi[0]) && (py > P.blo[1]) && (py < P.bhi[1]) &&
                             (pz > P.blo[2]) && (pz < P.bhi[2]);
-        F4 raw = decode_tile_lds<STAGE>(P, aux, wl, px, py, pz, lane);
+        F4 raw = decode_tile_lds<STAGE, SAVE>(P, aux, wl, px, py, pz, lane, active ? ray * S + k : -1);
         if (!inside) raw.w = 100.f;                                         // Renderer.py:57
         if (active && g == 0) {
             rawbuf[pidx] = raw;

@@ -186,6 +186,7 @@ class _MappingLossFn(torch.autograd.Function):
         if track is None:                                       # the mapper's L1 loss is accumulated by the forward kernel itself
             a.gt_color, a.keep, a.loss, a.w_color = gt_color.data_ptr(), keep.data_ptr(), loss.data_ptr(), float(w_color)
             a.dl_depth, a.dl_rgb = dl_depth.data_ptr(), dl_rgb.data_ptr()
+        acts = renderer._attach_acts(a, stage, N, S, dev) if need_bwd else None
         lib.check(lib.nsr_render_fwd(C.byref(a), stream), "nsr_render_fwd")
         if track is not None:                                   # the tracker's loss needs the batch median of the rendered outputs
             lib.check(lib.nsr_tracking_loss(N, gt_depth.data_ptr(), gt_color.data_ptr(), keep.data_ptr(), depth.data_ptr(), var.data_ptr(),
@@ -197,7 +198,7 @@ class _MappingLossFn(torch.autograd.Function):
         if need_bwd:
             ctx.sharder, ctx.loss32 = sharder, Z[3:4]
             ctx.state = (a, (renderer, decoders, stage, S, None if sharder is None else sharder.collect),
-                         ([kmax, F, sbuf, Z, hold], rays_o, rays_d, gt_depth, grids, flats, packed, raw, depth),
+                         ([kmax, F, sbuf, Z, hold, acts], rays_o, rays_d, gt_depth, grids, flats, packed, raw, depth),
                          (need_pose, need_grid, need_par), dl_depth,
                          dl_rgb if (stage == "color" and (track is None or track[1])) else None, Z[4:],
                          (indices, K, n, crop, intr, [tuple(c.shape) for c in c2ws], [c.dtype for c in c2ws], [c.device for c in c2ws]))

@@ -140,6 +140,8 @@ class _RenderFn(torch.autograd.Function):
         zsave = torch.empty((n, S), dtype=torch.float64, device=dev) if need_bwd else None
         a.zvals = zsave.data_ptr() if zsave is not None else None
         keep.append(zsave)
+        if need_bwd:
+            keep.append(renderer._attach_acts(a, stage, n, S, dev))
         lib.check(lib.nsr_render_fwd(C.byref(a), stream), "nsr_render_fwd")
         if need_bwd:
             # `depth` is an OUTPUT: kept as a detached alias (same storage, different tensor object), so that no reference
@@ -300,6 +302,14 @@ class Renderer(object):
             tmpl.t_surface[i] = v
         self._arg_template = bytes(tmpl)
         self.bwd_max_blocks = 0                 # 0 = library default persistent-grid cap
+        # Saved activations: the forward of a call that will be differentiated also writes the decoders' hidden states and
+        # relu masks (704 B per sample point and decoder: 101 MB per 1000 colour-stage rays) and the backward loads them
+        # instead of re-running the decoder forward.  Measured on MI355X: backward -9 % at 1000 rays with parameter gradients,
+        # -36 % for the tracker's 200 rays (only the masks are read there); the forward's extra stores cancel the gain from
+        # ~5000 rays on, so batches whose buffer would exceed `max_saved_activation_bytes` (256 MB = ~2500 colour-stage rays)
+        # keep the re-run.
+        self.save_activations = True
+        self.max_saved_activation_bytes = 256 << 20
         # Optional: restrict parameter gradients to these decoders, e.g. ("color",).  The reference's autograd
         # produces dW for every decoder in every stage although src/Mapper.py:335-341 only ever steps the colour
         # decoder (and the fine one when fix_fine is False); None = reference semantics (requires_grad decides).
@@ -360,6 +370,17 @@ class Renderer(object):
             finally:
                 self._gt_max = None
         return _RenderFn.apply(meta, rays_o, rays_d, *[grids[s] for s in slots], *gates)
+
+    def _attach_acts(self, a, stage, n, S, dev):
+        """allocate the activation buffer of a differentiable forward and point the argument block at it (None: re-run)"""
+        if not self.save_activations or stage == "coarse":
+            return None
+        nfl = _capi.get_lib().nsr_acts_floats(_capi.STAGE_ID[stage], n, S)
+        if nfl <= 0 or 4 * nfl > self.max_saved_activation_bytes:
+            return None
+        acts = torch.empty((nfl,), dtype=torch.float32, device=dev)
+        a.acts = acts.data_ptr()
+        return acts
 
     def render_img(self, c, decoders, c2w, device, stage, gt_depth=None):
         """Renderer.py:200-255 (the reference requires gt_depth here; we also accept None)."""

@@ -66,6 +66,7 @@ class HostScene:
         self.enl = float(coarse_enlarge)
         self.n_samples, self.n_surface = n_samples, n_surface
         self.save_z = True          # exercise the saved-depth path of the backward; False = recompute
+        self.save_acts = os.environ.get("NSR_EMU_SAVE_ACTS", "1") == "1"     # saved decoder activations (default) vs forward re-run
         self.grids = {}
         for k, v in grids.items():          # [1,32,Z,Y,X] -> [Z,Y,X,32] contiguous
             a = v.detach().numpy()[0].transpose(1, 2, 3, 0)
@@ -124,6 +125,10 @@ class HostScene:
         if self.save_z:
             out["zvals"] = np.full((n, S), np.nan)
             a.zvals = ptr(out["zvals"])
+        if self.save_acts and stage != "coarse":           # nsr_render_args.acts: the backward loads instead of re-running
+            nfl = self.lib.nsr_acts_floats(_capi.STAGE_ID[stage], n, S)
+            out["acts"] = np.full((max(1, nfl),), np.nan, dtype=np.float32)
+            a.acts = ptr(out["acts"])
         self.lib.check(self.lib.nsr_render_fwd(C.byref(a), None), "fwd")
         out["_ctx"] = (a, keep, rays_o, rays_d, gt, S)
         return out

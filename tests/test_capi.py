@@ -35,7 +35,10 @@ def test_header_symbols_are_bound_and_exported(lib):
 
 def test_sizes_and_error_reporting(lib):
     from nice_slam_amd.layout import param_count
-    assert lib.nsr_version() == 2
+    assert lib.nsr_version() == 3
+    # activation slots: passes x 11 slots x points x 16 floats (0 for the coarse stage)
+    assert lib.nsr_acts_floats(0, 1000, 32) == 0 and lib.nsr_acts_floats(3, 1000, 48) == 3 * 11 * 48000 * 16
+    assert lib.nsr_acts_floats(1, 7, 48) == 11 * 7 * 48 * 16 and lib.nsr_acts_floats(4, 7, 48) == -1
     assert [lib.nsr_param_count(i) for i in range(4)] == [param_count(s) for s in ("coarse", "middle", "fine", "color")] \
         == [6337, 15800, 20920, 15899]
     assert [lib.nsr_packed_count(i) for i in range(4)] == [836 + 6144, 836 + 15360, 836 + 20480, 836 + 15360]    # [aux table | operand stream]
@@ -108,7 +111,7 @@ def test_kernel_register_budget():
     res = json.load(open(build.RESOURCES))
     bwd = {k: v for k, v in res.items() if "render_bwd_kernel" in k}
     fwd = {k: v for k, v in res.items() if "render_fwd_kernel" in k or "eval_points_kernel" in k}
-    assert len(bwd) == 4 and len(fwd) == 8
+    assert len(bwd) == 7 and len(fwd) == 11              # 4 stages + 3 saved-activation variants each; eval_points: 4
     for k, v in bwd.items():
         assert v["occupancy_waves_per_simd"] == 1 and v["scratch_bytes_per_lane"] <= 1024, (k, v)
     for k, v in fwd.items():

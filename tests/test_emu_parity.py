@@ -582,9 +582,37 @@ def test_full_size_forward_blocks_in_a_subprocess():
     import subprocess, sys
     if os.environ.get("NSR_FWD_SMALL") == "0":
         pytest.skip("already the inner run")
-    env = dict(os.environ, NSR_FWD_SMALL="0")
+    env = dict(os.environ, NSR_FWD_SMALL="0", NSR_EMU_SAVE_ACTS="0")      # ... and the forward re-run path of the backward
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k",
                         "golden_forward or random_scene or fused_mapping_loss or other_sample_counts"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("stage", ["middle", "fine", "color"])
+def test_saved_activations_equal_the_forward_rerun(emu, stage):
+    """nsr_render_args.acts: the forward writes every decoder's hidden states + relu masks, the backward loads them instead
+    of re-running the decoder -- same numbers as the re-run path (the loaded values ARE the re-run's values; only the
+    order of the unordered gradient atomics may differ), ragged ray count, two-block persistent grid."""
+    s = make_scene(seed=120, n_rays=29, small=True)
+    res = {}
+    for mode in (True, False):
+        sc = _host_scene(emu, s["grids"], s["params"], s["bound"].numpy())
+        sc.save_acts = mode
+        fwd = sc.forward(stage, s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy())
+        assert ("acts" in fwd) == mode
+        if mode:
+            slots = fwd["acts"].reshape(-1, 11, fwd["raw"].shape[0] * fwd["raw"].shape[1] * 16)   # [pass][slot][point, lane group, 4]
+            assert not np.isnan(slots[:, :10]).any()            # every hidden-state slot of every point was written (slot 10: mask bits)
+        res[mode] = (fwd, sc.backward(stage, fwd, s["w"]["depth"].numpy(), s["w"]["var"].numpy(), s["w"]["rgb"].numpy(), max_blocks=2))
+    for k in ("depth", "var", "rgb", "raw"):
+        assert np.array_equal(res[True][0][k], res[False][0][k]), k
+    for k, v in res[False][1].items():
+        assert rel_err(res[True][1][k], v) < 1e-5, (stage, k)      # (emulated blocks run on several OS threads: atomics order)
+    # without parameter gradients (tracking): the specialisation without accumulators takes the same path
+    sc = _host_scene(emu, s["grids"], s["params"], s["bound"].numpy())
+    fwd = sc.forward(stage, s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy())
+    r2 = sc.backward(stage, fwd, s["w"]["depth"].numpy(), s["w"]["var"].numpy(), s["w"]["rgb"].numpy(), want_params=False, want_grid=False)
+    for k in ("d_rays_o", "d_rays_d"):
+        assert rel_err(r2[k], res[False][1][k]) < 1e-5, k
