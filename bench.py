@@ -279,6 +279,13 @@ def main():
         stages_cfg = (args.stage,)
     mix = {s: _CYCLE.count(s) for s in stages_cfg} if C["stages"] == "mix" and not args.stage else {s: 1 for s in stages_cfg}
 
+    def acts_saved(stage, n):            # does Renderer._attach_acts hand the forward an activation buffer at this size?
+        if not renderer.save_activations or stage == "coarse":
+            return False
+        from nice_slam_amd import _capi
+        nfl = _capi.get_lib().nsr_acts_floats(_capi.STAGE_ID[stage], n, 48)
+        return 0 < 4 * nfl <= renderer.max_saved_activation_bytes
+
     def stage_of(it):
         if len(stages_cfg) == 1:
             return stages_cfg[0]
@@ -443,7 +450,9 @@ def main():
                                         " (all grid + all decoder grads, like the reference autograd), no optimiser"),
                        "decoder_grads": "none (tracking)" if tracking else ("colour decoder only (what Mapper's optimiser steps)" if args.stepped_grads_only else "all decoders (reference autograd semantics)"),
                        "launch": "hipGraph replay (one captured graph per stage)" if use_graph else "eager",
-                       "activations": "saved by the forward (704 B per point and decoder), loaded by the backward"
+                       "activations": ("saved by the forward (704 B per point and decoder) and loaded by the backward where the buffer "
+                                       "stays below %d MB, else the decoder forward is re-run in the backward"
+                                       % (renderer.max_saved_activation_bytes >> 20))
                                       if renderer.save_activations else "decoder forward re-run in the backward",
                        "timed_windows_ms": [round(w_ * 1e3, 3) for w_ in windows], "reported": "median window",
                        "parallelism": exchange},
@@ -456,7 +465,9 @@ def main():
             traffic, tsrc = None, None
             tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")      # from a separate rocprofv3 --pmc run (tools/pmc_summary.py)
             if os.path.exists(tpath) and args.config == "1" and rays_rank == 1000:
-                tj = json.load(open(tpath)).get("nsr::render_bwd_kernel<3>", {})
+                tall = json.load(open(tpath))                 # one entry per kernel variant: "<3>" / "<3, false>" re-run, "<3, true>" saved
+                tj = tall.get("nsr::render_bwd_kernel<3, true>", {}) if acts_saved(dom, rays_rank) else \
+                    tall.get("nsr::render_bwd_kernel<3, false>", tall.get("nsr::render_bwd_kernel<3>", {}))
                 traffic, tsrc = tj.get("hbm_bytes_per_launch"), "profiles/r02_traffic.json: " + tj.get("note", "")
             res["roofline"] = {"bound": "mfma", "kernel": f"render_bwd_kernel<{dom}>", "achieved": ach / 1e12, "peak": FP32_PEAK / 1e12,
                                "unit": "TFLOP/s", "frac": ach / FP32_PEAK, "traffic": traffic, "traffic_source": tsrc,
@@ -464,10 +475,12 @@ def main():
                                "measured": "HIP events recorded inside nsr_render_bwd on the launch stream, eager iterations of this process"
                                            + (" (the timed region replays the captured graph of the same kernels)" if use_graph else ""),
                                "algorithmic_flop_per_launch": nec,
-                               "executed_frac": (pts * EXEC_BWD_MAC[dom] * 2 / (ms * 1e-3)) / FP32_PEAK
+                               "executed_frac": (pts * (EXEC_BWD_MAC[dom] - (FWD_MAC[dom] if acts_saved(dom, rays_rank) else 0)) * 2
+                                                 / (ms * 1e-3)) / FP32_PEAK
                                if not (args.stepped_grads_only or tracking) else None,
-                               "executed_note": "MFMA work the kernel actually issues (forward re-run + dX + dW for every decoder, "
-                                                "the reference autograd's semantics) over the same peak; `frac` counts only the necessary part"}
+                               "executed_note": "MFMA work the kernel actually issues (dX + dW for every decoder -- the reference "
+                                                "autograd's semantics -- plus the decoder forward re-run where the activations were not "
+                                                "saved) over the same peak; `frac` counts only the necessary part"}
         if shard is not None:
             res["config"]["grad_exchange_MB_last_iter"] = round(shard.last_exchange_floats * 4 / 1e6, 2)
         res["kernel_ms"] = {f"render_bwd<{s}>": round(v[0], 4) for s, v in ksum.items()}

@@ -66,6 +66,23 @@ def test_forward_backward_small(stage):
     _compare(hip_render(sc, stage, backward=True), oracle_render(sc, stage, backward=True), stage, sc, stage)
 
 
+@pytest.mark.parametrize("stage", ("middle", "fine", "color"))
+def test_saved_activations_and_forward_rerun_agree(stage):
+    """Renderer.save_activations (default: the forward writes hidden states + relu masks, a backward kernel variant loads
+    them) against the variant that re-runs the decoder forward: same outputs bit for bit, same gradients up to the order of
+    the gradient atomics; the re-run variant is also held to the oracle (the default one is by every other test)."""
+    sc = make_scene(seed=14, n_rays=301, small=True)
+    prod = build_product(sc, "cuda:0")
+    saved = hip_render(sc, stage, backward=True, product=prod)
+    prod[0].save_activations = False
+    rerun = hip_render(sc, stage, backward=True, product=prod)
+    for k in ("depth", "var", "rgb"):
+        assert torch.equal(saved[k], rerun[k]), k
+    for k, v in rerun.items():
+        assert rel_err(saved[k], v) < 1e-5, (stage, k)
+    _compare(rerun, oracle_render(sc, stage, backward=True), stage + "/rerun", sc, stage)
+
+
 @pytest.mark.parametrize("stage", ("middle", "color"))
 def test_forward_without_depth(stage):
     sc = make_scene(seed=12, n_rays=64, small=True)
