@@ -280,7 +280,7 @@ def main():
     mix = {s: _CYCLE.count(s) for s in stages_cfg} if C["stages"] == "mix" and not args.stage else {s: 1 for s in stages_cfg}
 
     def acts_saved(stage, n):            # does Renderer._attach_acts hand the forward an activation buffer at this size?
-        if not renderer.save_activations or stage == "coarse":
+        if not renderer.save_activations:
             return False
         from nice_slam_amd import _capi
         nfl = _capi.get_lib().nsr_acts_floats(_capi.STAGE_ID[stage], n, 48)

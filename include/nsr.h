@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define NSR_VERSION 3
+#define NSR_VERSION 4
 
 /* stages of NICE.forward (decoder.py:312-342) */
 enum { NSR_STAGE_COARSE = 0, NSR_STAGE_MIDDLE = 1, NSR_STAGE_FINE = 2, NSR_STAGE_COLOR = 3 };

@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401  -- must be loaded first: libnsr.so binds to the HIP runtime (libamdhip64.so.7) torch already mapped
 
 MAX_SAMPLES = 64
-ABI_VERSION = 3
+ABI_VERSION = 4
 STAGE_ID = {"coarse": 0, "middle": 1, "fine": 2, "color": 3}
 SLOT_NAMES = ("coarse", "middle", "fine", "color")
 

@@ -58,6 +58,52 @@ int bwd_blocks(long long n_groups, int max_blocks) {
 // per-scene cost weights.)
 int bwd_passes(int stage) { return stage == NSR_STAGE_COARSE ? 1 : stage; }     // middle 1, fine 2, colour 3
 
+// ---- split backward over saved activations (nsr_bwd2.h) -----------------------------------------------------------------
+// layout of nsr_render_args.acts (floats): [passes][kActSlots][npad][16] saved by the forward | [passes][kDySlots][npad][16]
+// dY (dX kernel -> dW kernel) | [npad][4] d raw | [npad][4] doubles: sample position + depth.  npad = the sample points
+// rounded up to whole 16-point tiles, so that every tile of every slot is 1 KB inside its own slot (DMA pieces).
+struct SplitLayout {
+    long long npts, npad, stride;      // stride: floats between two slots
+    long long o_dy, o_draw, o_pd, total;
+};
+SplitLayout split_layout(int stage, long long n_rays, int S) {
+    SplitLayout L;
+    const int passes = bwd_passes(stage);
+    L.npts = n_rays * S;
+    L.npad = (L.npts + nsr::kTile - 1) / nsr::kTile * nsr::kTile;
+    L.stride = L.npad * 16;
+    L.o_dy = (long long)passes * nsr::kActSlots * L.stride;
+    L.o_draw = L.o_dy + (long long)passes * nsr::kDySlots * L.stride;
+    L.o_pd = L.o_draw + L.npad * 4;
+    L.total = L.o_pd + L.npad * 8;
+    return L;
+}
+// launch geometry: the dX kernel runs `nb` blocks of `waves` waves per decoder pass (one block per CU over all passes,
+// fewer waves per block when the batch is small: every CU gets work); the dW kernel `nimg` blocks per pass, each of which
+// leaves one partial image of the gradient blob.
+struct SplitGeo { int nb, waves, nimg; };
+int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return (e && e[0]) ? atoi(e) : dflt;
+}
+SplitGeo split_geo(int stage, long long n_rays, int S, int max_blocks) {
+    static const int dw_mult = env_int("NSR_DW_BLOCKS_PER_CU", 1);
+    SplitGeo G;
+    const int passes = bwd_passes(stage);
+    const long long tiles = (n_rays * S + nsr::kTile - 1) / nsr::kTile;
+    const int cap = max_blocks > 0 ? max_blocks : kDefaultBwdBlocks;
+    int per_pass = cap / passes;
+    if (per_pass < 1) per_pass = 1;
+    long long w = (tiles + per_pass - 1) / per_pass;
+    G.waves = (int)(w < 1 ? 1 : (w > nsr::kDxMaxWaves ? nsr::kDxMaxWaves : w));
+    const long long nb = (tiles + G.waves - 1) / G.waves;
+    G.nb = (int)(nb < 1 ? 1 : (nb > per_pass ? per_pass : nb));
+    long long ni = (long long)per_pass * (dw_mult < 1 ? 1 : dw_mult);
+    if (ni > tiles) ni = tiles;
+    G.nimg = (int)(ni < 1 ? 1 : ni);
+    return G;
+}
+
 // validate + translate the public argument block
 int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays, bool bwd = false) {
     if (!a) return fail("nsr: null argument block");
@@ -92,8 +138,9 @@ int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays,
     P.n_groups = (P.n_rays + P.rays_per_block - 1) / P.rays_per_block;
     P.rays_o = a->rays_o;
     P.rays_d = a->rays_d;
-    P.acts = a->stage == NSR_STAGE_COARSE ? nullptr : a->acts;
+    P.acts = a->acts;
     P.n_points_total = (long long)P.n_rays * P.S;
+    P.act_stride = split_layout(P.stage, P.n_rays, P.S).stride;
     P.gt_depth = guided ? a->gt_depth : nullptr;
     P.gt_max = a->gt_max;
     for (int i = 0; i < 3; ++i) { P.blo[i] = a->bound_lo[i]; P.bhi[i] = a->bound_hi[i]; }
@@ -166,6 +213,85 @@ int bwd_lds_bytes(int stage, int npts, int rays, int waves) {
     return need;
 }
 
+// the backward as comp_bwd -> dX -> dW -> finalize over the activations the forward saved (nsr_bwd2.h)
+int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::RenderParams &P, bool any_params, void *stream) {
+    const SplitLayout L = split_layout(P.stage, P.n_rays, P.S);
+    if (L.stride * 4 >= (1ll << 31)) return fail("nsr_render_bwd: batch too large for the saved-activation path (pass acts = NULL)");
+    const SplitGeo G = split_geo(P.stage, P.n_rays, P.S, b->max_blocks);
+    const int passes = bwd_passes(P.stage);
+    P.dy = P.acts + L.o_dy;
+    P.draw = P.acts + L.o_draw;
+    P.pd = reinterpret_cast<double *>(P.acts + L.o_pd);
+    P.dw_blocks = G.nimg;
+    static const int xflags = env_int("NSR_X", 0);
+    P.xflags = xflags;
+    if (any_params) {
+        const long long need = (long long)passes * ((long long)G.nimg * P.partial_stride + (long long)G.nb * nsr::kDbPart);
+        if (!b->workspace || b->workspace_floats < need) return fail("nsr_render_bwd: workspace too small");
+        P.partials = b->workspace;
+        P.dbpart = b->workspace + (long long)passes * G.nimg * P.partial_stride;
+    }
+    if (b->ev_start) nsr::rt_record(b->ev_start, stream);
+    {
+        const int tb = 256, rays_per_block = tb / 64;
+        NSR_LAUNCH(nsr::comp_bwd_kernel, dim3((unsigned)((P.n_rays + rays_per_block - 1) / rays_per_block)), dim3(tb), 0, stream, P);
+    }
+    const bool rays = P.d_rays_o != nullptr;
+    {
+        int lds = 0;
+        const int first = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE, last = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : P.stage;
+        for (int kind = first; kind <= last; ++kind) {
+            const int need = (nsr::AUX_FLOATS + nsr::packedT_total(kind) + G.waves * nsr::kDxStg) * 4;
+            lds = need > lds ? need : lds;
+        }
+        const dim3 grid(G.nb, passes), block(64 * G.waves);
+#define NSR_DX(ST, RY)                                                                                  \
+    if (int rc = launch_cfg(nsr::render_bwd_dx_kernel<ST, RY>, lds, "nsr_render_bwd(dx)")) return rc;   \
+    NSR_LAUNCH((nsr::render_bwd_dx_kernel<ST, RY>), grid, block, lds, stream, P);
+        switch (P.stage) {
+            case 0: if (rays) { NSR_DX(0, true) } else { NSR_DX(0, false) } break;
+            case 1: if (rays) { NSR_DX(1, true) } else { NSR_DX(1, false) } break;
+            case 2: if (rays) { NSR_DX(2, true) } else { NSR_DX(2, false) } break;
+            default: if (rays) { NSR_DX(3, true) } else { NSR_DX(3, false) } break;
+        }
+#undef NSR_DX
+    }
+    if (any_params) {
+        const int lds = nsr::dw_lds_floats(P.stage >= NSR_STAGE_FINE ? NSR_FINE : NSR_MIDDLE) * 4;
+        const dim3 grid(G.nimg, passes), block(64 * nsr::kDwWaves);
+#define NSR_DW(ST)                                                                                  \
+    if (int rc = launch_cfg(nsr::render_bwd_dw_kernel<ST>, lds, "nsr_render_bwd(dw)")) return rc;   \
+    NSR_LAUNCH((nsr::render_bwd_dw_kernel<ST>), grid, block, lds, stream, P);
+        switch (P.stage) {
+            case 0: NSR_DW(0) break;
+            case 1: NSR_DW(1) break;
+            case 2: NSR_DW(2) break;
+            default: NSR_DW(3) break;
+        }
+#undef NSR_DW
+        const int first = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE, last = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : P.stage;
+        nsr::FinalParams R;
+        R.stride = P.partial_stride; R.overwrite = b->overwrite_dparams ? 1 : 0;
+        int rows = 0, nblocks = 0;
+        for (int s = first; s <= last; ++s) {
+            if (!P.dec[s].dparams) continue;
+            const int pass = P.stage == NSR_STAGE_COARSE ? 0 : s - NSR_MIDDLE;
+            nsr::FinalJob &J = R.job[rows++];
+            J.images = P.partials + (long long)pass * G.nimg * P.partial_stride;
+            J.dbpart = P.dbpart + (long long)pass * G.nb * nsr::kDbPart;
+            J.params = P.dec[s].params; J.dparams = P.dec[s].dparams;
+            J.kind = s; J.nimg = G.nimg; J.ndx = G.nb;
+            const int dbeg = s == NSR_COARSE ? 0 : nsr::xyz_w(nsr::cdim_of(s), 0);
+            const int nb = (nsr::param_total(s) - dbeg + 63) / 64 + 5 + (s == NSR_COARSE ? 0 : 5 * nsr::cdim_of(s) / 8);
+            nblocks = nb > nblocks ? nb : nblocks;
+        }
+        for (int r = rows; r < 3; ++r) R.job[r] = nsr::FinalJob{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+        NSR_LAUNCH(nsr::bwd_finalize_kernel, dim3(nblocks, rows), dim3(1024), (2048 + 32) * 4, stream, R);
+    }
+    if (b->ev_stop) nsr::rt_record(b->ev_stop, stream);
+    return finish("nsr_render_bwd(split)");
+}
+
 }  // namespace
 
 extern "C" {
@@ -178,8 +304,7 @@ int64_t nsr_packed_count(int slot) { return (slot < 0 || slot > 3) ? -1 : nsr::p
 
 int64_t nsr_acts_floats(int stage, int64_t n_rays, int n_samples_total) {
     if (stage < 0 || stage > 3 || n_rays < 0 || n_samples_total < 1 || n_samples_total > NSR_MAX_SAMPLES) return -1;
-    if (stage == NSR_STAGE_COARSE) return 0;
-    return (int64_t)stage * nsr::kActSlots * n_rays * n_samples_total * 16;      // passes x slots x points x 64 bytes
+    return split_layout(stage, n_rays, n_samples_total).total;
 }
 
 int64_t nsr_bwd_workspace_floats(int stage, int64_t n_rays, int n_samples_total, int max_blocks) {
@@ -188,7 +313,11 @@ int64_t nsr_bwd_workspace_floats(int stage, int64_t n_rays, int n_samples_total,
     const long long groups = (n_rays + rb - 1) / rb;
     long long blocks = bwd_blocks(groups, max_blocks);
     if (blocks < 1) blocks = 1;
-    return (int64_t)stage_passes(stage) * blocks * max_param_count(stage);
+    const long long rerun = (long long)stage_passes(stage) * blocks * max_param_count(stage);
+    // split backward: partial images of the dW kernel + d _B partials of the dX kernel
+    const SplitGeo G = split_geo(stage, n_rays, n_samples_total, max_blocks);
+    const long long split = (long long)bwd_passes(stage) * ((long long)G.nimg * max_param_count(stage) + (long long)G.nb * nsr::kDbPart);
+    return (int64_t)(rerun > split ? rerun : split);
 }
 
 int nsr_pack_params(int slot, const float *params, float *packed, void *stream) {
@@ -217,7 +346,7 @@ int nsr_render_fwd(const nsr_render_args *a, void *stream) {
     NSR_LAUNCH((nsr::render_fwd_kernel<ST, SV>), grid, block, lds, stream, P);
     const bool save = P.acts != nullptr;           // the variant that also writes the activation slots (nsr_render_args.acts)
     switch (P.stage) {
-        case 0: NSR_FWD(0, false) break;
+        case 0: if (save) { NSR_FWD(0, true) } else { NSR_FWD(0, false) } break;
         case 1: if (save) { NSR_FWD(1, true) } else { NSR_FWD(1, false) } break;
         case 2: if (save) { NSR_FWD(2, true) } else { NSR_FWD(2, false) } break;
         default: if (save) { NSR_FWD(3, true) } else { NSR_FWD(3, false) } break;
@@ -241,10 +370,11 @@ int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream
     if (const char *e = getenv("NSR_DBG_PTR")) P.dbg = reinterpret_cast<long long *>(strtoull(e, nullptr, 16));
 #endif
     const int passes = bwd_passes(P.stage);
-    const int nblk = bwd_blocks(P.n_groups, b->max_blocks);
     bool any_params = false;
     for (int s = 0; s < 4; ++s) any_params |= P.dec[s].dparams != nullptr;
     P.partial_stride = max_param_count(P.stage);
+    if (P.acts && a->zvals) return render_bwd_split(a, b, P, any_params, stream);      // else: the re-run kernel (nsr_bwd.h)
+    const int nblk = bwd_blocks(P.n_groups, b->max_blocks);
     if (any_params) {
         const long long need = (long long)passes * nblk * P.partial_stride;
         if (!b->workspace || b->workspace_floats < need) return fail("nsr_render_bwd: workspace too small");
@@ -257,13 +387,12 @@ int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream
 #define NSR_BWD(ST, SV)                                                                               \
     if (int rc = launch_cfg(nsr::render_bwd_kernel<ST, SV>, lds, "nsr_render_bwd")) return rc;         \
     NSR_LAUNCH((nsr::render_bwd_kernel<ST, SV>), grid, block, lds, stream, P);
-    const bool saved = P.acts != nullptr;          // the forward wrote the activation slots (nsr_render_args.acts)
     if (b->ev_start) nsr::rt_record(b->ev_start, stream);
     switch (P.stage) {
         case 0: NSR_BWD(0, false) break;
-        case 1: if (saved) { NSR_BWD(1, true) } else { NSR_BWD(1, false) } break;
-        case 2: if (saved) { NSR_BWD(2, true) } else { NSR_BWD(2, false) } break;
-        default: if (saved) { NSR_BWD(3, true) } else { NSR_BWD(3, false) } break;
+        case 1: NSR_BWD(1, false) break;
+        case 2: NSR_BWD(2, false) break;
+        default: NSR_BWD(3, false) break;
     }
 #undef NSR_BWD
     if (b->ev_stop) nsr::rt_record(b->ev_stop, stream);

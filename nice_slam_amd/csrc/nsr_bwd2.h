@@ -1,0 +1,797 @@
+// nsr_bwd2.h -- split backward of the render path over saved activations (third generation), included by nsr_kernels.h.
+//
+// The second-generation kernel (nsr_bwd.h) keeps every parameter-gradient accumulator of a decoder in the registers of
+// ONE wave, which pins it to one wave per SIMD with spills.  When the forward has saved the decoders' activations
+// (nsr_render_args.acts: hidden states, relu masks, grid features), the backward is four launches instead:
+//   comp_bwd_kernel        one wave per ray: d raw per sample from the output gradients (compositor backward), the sample's
+//                          fp64 position and its bound test                                  (common.py:231-244 differentiated)
+//   render_bwd_dx_kernel   "dX": per 16-point tile dh = W^T dY through the five layers (masks from the forward), dc += U^T dh,
+//                          embedding backward, grid scatter, ray gradients; writes dY_i for the dW kernel.  No parameter-gradient
+//                          accumulators (only the 18 partial sums of d embedder._B): forward-like register budget, 3 waves/SIMD.
+//                          W^T operands come from a second, transposed operand stream (nsr_layout.h) so that one conflict-free
+//                          16-byte LDS read feeds four MFMAs (the second generation read W^T through scalar LDS reads with
+//                          4-way bank conflicts).
+//   render_bwd_dw_kernel   "dW": split-K GEMM over the sample points, dW_i = sum_p dY_i[p]^T x_i[p].  A block streams 16-point
+//                          tiles of every operand (dY_i, h_i, c, positions, d raw) through a three-slot LDS ring with
+//                          global->LDS DMA (no staging registers), its 8 waves own disjoint 16x16 output tiles (<= 12 each), so
+//                          there is no cross-wave reduction; one partial image of the flat gradient blob per block.
+//                          The fc_c weights are not contracted directly: dH_i = W_{i+1}^T dY_{i+1}, hence
+//                          dU_i = W_{i+1}^T (sum_p dY_{i+1}[p]^T c[p]) =: W_{i+1}^T G_{i+1}  (and dv_i = W_{i+1}^T db_{i+1}):
+//                          the kernel accumulates G_j (stored in the image where dU_{j-1} lives), the finalize kernel applies
+//                          the 32x32 matrices -- 224 instead of 240 MFMAs per tile, and no dH in memory.
+//   bwd_finalize_kernel    sums the partial images (and the dX kernel's d _B partials), applies W^T to G / db, writes dparams.
+// References: autograd of Renderer.render_batch_ray (src/utils/Renderer.py:63-198), MLP / MLP_no_xyz (src/conv_onet/models/
+// decoder.py:177-203, 262-274), src/Mapper.py:503, src/Tracker.py:125.
+#pragma once
+
+namespace nsr {
+
+constexpr int kDySlots = 10;                  // dY_i k-tile T at slot 2 i + T (same [n_points][16] form as the activation slots)
+constexpr int kDxMaxWaves = 12;
+// per-wave LDS staging of the dX kernel (floats): Tx[16][kTxS] | tab[256] (grid scatter) | P[3][16] | DP[3][16]
+constexpr int kDxTx = 0, kDxTab = kTile * kTxS, kDxP = kDxTab + 256, kDxDP = kDxP + 48, kDxStg = kDxDP + 48;
+static_assert(kDxStg % 4 == 0, "staging regions must stay 16-byte aligned");
+constexpr int kDbPart = 288;                  // d _B partial image of a dX block: [3][96]
+
+// ------------------------------------------------------------------------------------------------
+// compositor backward, one wave per ray (lane = sample): d raw, fp64 sample position, bound test
+// ------------------------------------------------------------------------------------------------
+NSR_KERNEL void comp_bwd_kernel(const RenderParams P) {
+    const int lane = tid() & 63, wave = tid() >> 6, nw = nthreads() >> 6;
+    const long long ray = (long long)bid_x() * nw + wave;
+    if (ray >= P.n_rays) return;
+    const int S = P.S;
+    const bool act = lane < S;
+    const long long gp = ray * S + (act ? lane : 0);
+    const F4 rw = act ? ld4(P.raw + gp * 4) : F4{0.f, 0.f, 0.f, 0.f};
+    const double gD = P.d_depth ? P.d_depth[ray] : 0.0, gV = P.d_var ? P.d_var[ray] : 0.0, dep = P.g_depth[ray];
+    float gr = 0.f, gg = 0.f, gb = 0.f;
+    if (P.d_rgb) { gr = P.d_rgb[ray * 3 + 0]; gg = P.d_rgb[ray * 3 + 1]; gb = P.d_rgb[ray * 3 + 2]; }
+    const double z = act ? P.zvals[gp] : 0.0;
+    const Comp cw = comp_weights(rw.w, act, lane);
+    const double dz = z - dep;
+    const double s1 = wave_sum_d((double)cw.w * dz);
+    const float Gz = (float)(gD * z + gV * (dz * dz - 2.0 * s1 * z));
+    const float Gw = Gz + fmaf(gb, rw.z, fmaf(gg, rw.y, gr * rw.x));
+    float v = act ? Gw * cw.w : 0.f;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = shfl_down(v, d);
+        if (lane + d < 64) v += o;
+    }
+    float suffix = shfl_down(v, 1);
+    if (lane == 63) suffix = 0.f;
+    const float dalpha = Gw * cw.T - suffix / cw.t;
+    float docc = 10.f * (dalpha * ((1.f - cw.alpha) * cw.alpha));
+    // pts = o + d z in fp64 (Renderer.py:172-174); outside the un-enlarged bound the occupancy is overridden and its
+    // gradient cut (Renderer.py:57)
+    const double px = (double)P.rays_o[ray * 3 + 0] + (double)P.rays_d[ray * 3 + 0] * z;
+    const double py = (double)P.rays_o[ray * 3 + 1] + (double)P.rays_d[ray * 3 + 1] * z;
+    const double pz = (double)P.rays_o[ray * 3 + 2] + (double)P.rays_d[ray * 3 + 2] * z;
+    const bool inside = (px > P.blo[0]) && (px < P.bhi[0]) && (py > P.blo[1]) && (py < P.bhi[1]) && (pz > P.blo[2]) && (pz < P.bhi[2]);
+    if (!inside) docc = 0.f;
+    if (act) {
+        st4(P.draw + gp * 4, F4{cw.w * gr, cw.w * gg, cw.w * gb, docc});
+        double *q = P.pd + gp * 4;
+        q[0] = px; q[1] = py; q[2] = pz; q[3] = z;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dX kernel
+// ------------------------------------------------------------------------------------------------
+// dx[Tk] += W(slice)^T dy: A = transposed stream (one 16-byte LDS read per (Tk, To) = four k-steps), B = the dy registers;
+// result CL (lane (pt, g) holds input channels 16 Tk + 4 g + r).  k-steps alternate between the NTK accumulators.
+template <int NTK>
+NSR_DEV void gemv_t(f32x4 (&dx)[NTK], const Act<2> &dy, const float *wt, int lane) {
+#pragma unroll
+    for (int To = 0; To < 2; ++To) {
+        f32x4 a[NTK];
+#pragma unroll
+        for (int Tk = 0; Tk < NTK; ++Tk) a[Tk] = to_v(ld4(wt + ((Tk * 2 + To) * 64 + lane) * 4));
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int Tk = 0; Tk < NTK; ++Tk) dx[Tk] = mfma16(a[Tk][r], dy.t[To][r], dx[Tk]);
+    }
+    sched_fence_gemv();
+}
+
+struct DxIn {
+    double px, py, pz, z;
+    F4 dr;
+    unsigned m0, m1;
+    bool act;
+};
+
+NSR_DEV DxIn dx_load(const RenderParams &P, const float *acts_pass, long long tile, int pt, int g) {
+    DxIn I;
+    const long long gp = tile * kTile + pt;
+    I.act = gp < P.n_points_total;
+    const long long q = I.act ? gp : 0;
+    const double *pp = P.pd + q * 4;
+    I.px = pp[0]; I.py = pp[1]; I.pz = pp[2]; I.z = pp[3];
+    I.dr = ld4(P.draw + q * 4);
+    const float *mp = acts_pass + kActMask * P.act_stride + (q * 4 + g) * 4;
+    I.m0 = __builtin_bit_cast(unsigned, mp[0]);
+    I.m1 = __builtin_bit_cast(unsigned, mp[1]);
+    if (!I.act) { I.dr = F4{0.f, 0.f, 0.f, 0.f}; I.m0 = 0u; I.m1 = 0u; }
+    return I;
+}
+NSR_DEV void dx_keep(const DxIn &I) {           // force the loads behind `I` to have landed (see dx_pass)
+    keep_alive((float)I.z); keep_alive(I.dr.w); keep_alive(__builtin_bit_cast(float, I.m1));
+}
+
+template <int KIND, bool PARAMS, bool RAYS>
+NSR_DEV void dx_pass(const RenderParams &P) {
+    constexpr bool XYZ = KIND != NSR_COARSE;
+    constexpr int NOUT = nout_of(KIND);
+    char *lds = lds_base();
+    const int lane = tid() & 63, wave = tid() >> 6, nw = nthreads() >> 6;
+    const int pt = lane & 15, g = lane >> 4;
+    float *aux = reinterpret_cast<float *>(lds);
+    float *wt = aux + AUX_FLOATS;                            // transposed operand stream of this decoder
+    float *stg = wt + packedT_total(KIND);
+    float *Sw = stg + wave * kDxStg;
+    const GridDev &G = P.grid[KIND];
+    const DecDev &D = P.dec[KIND];
+    const bool do_grid = G.dfeat != nullptr;
+    if (!do_grid && !PARAMS && !RAYS) return;
+    copy_f4<AUX_FLOATS / 4>(aux, D.packed);
+    copy_f4<packedT_total(KIND) / 4>(wt, D.packed + AUX_FLOATS + packed_total(KIND));
+    block_sync();
+
+    const long long sstride = P.act_stride;
+    const float *acts_pass = P.acts + (long long)act_pass(KIND) * kActSlots * sstride;
+    float *dys = P.dy + (long long)act_pass(KIND) * kDySlots * sstride;
+    const long long ntiles = (P.n_points_total + kTile - 1) / kTile;
+    const long long tstep = (long long)nblk_x() * nw;
+    const bool need_dc = do_grid || RAYS;
+    float aB[kET][3];                                        // d _B partial sums of lane (channel j, point group)
+#pragma unroll
+    for (int k = 0; k < kET; ++k) { aB[k][0] = 0.f; aB[k][1] = 0.f; aB[k][2] = 0.f; }
+
+    long long tile = (long long)bid_x() * nw + wave;
+    DxIn cur;
+    if (tile < ntiles) cur = dx_load(P, acts_pass, tile, pt, g);
+    for (; tile < ntiles; tile += tstep) {
+        loop_fence();
+        // the next tile's inputs are requested now and waited for before this tile's scatter atomics are issued: the
+        // vector-memory counter is in-order, a load behind the atomics would wait for all of them
+        const bool has_next = tile + tstep < ntiles;
+        DxIn nx = cur;
+        if (has_next) nx = dx_load(P, acts_pass, tile + tstep, pt, g);
+        const long long gp = tile * kTile + pt;
+        const bool active = cur.act;
+        const float px = (float)cur.px, py = (float)cur.py, pz = (float)cur.pz;       // decoder.py:189
+        unsigned mk[5];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mk[i] = (cur.m0 >> (8 * i)) & 255u;
+        mk[4] = cur.m1 & 255u;
+        float d_out[4] = {0.f, 0.f, 0.f, 0.f};
+        if (NOUT == 1) d_out[0] = cur.dr.w;
+        else { d_out[0] = cur.dr.x; d_out[1] = cur.dr.y; d_out[2] = cur.dr.z; }      // decoder.py:341 overwrites the 4th colour output
+        // output layer
+        Act<2> dh;
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            f32x4 v = f4zero();
+#pragma unroll
+            for (int n = 0; n < (NOUT == 1 ? 1 : 3); ++n) {
+                const F4 w = ld4(aux + AUX_WO + n * 32 + 16 * T + 4 * g);
+                v[0] = fmaf(w.x, d_out[n], v[0]); v[1] = fmaf(w.y, d_out[n], v[1]);
+                v[2] = fmaf(w.z, d_out[n], v[2]); v[3] = fmaf(w.w, d_out[n], v[3]);
+            }
+            dh.t[T] = v;
+        }
+        Act<2> dc, dY0, dY3;
+        act_zero(dc); act_zero(dY0); act_zero(dY3);
+        float *dyp = dys + (gp * 4 + g) * 4;
+#pragma unroll
+        for (int I = 4; I >= 0; --I) {
+            if (XYZ && need_dc) gemv_t<2>(dc.t, dh, wt + xyzT_u(I), lane);         // gradient of (U_i c + v_i) is dh itself
+            const Act<2> dY = apply_mask(dh, mk[I]);
+            if (PARAMS && active && !(P.xflags & 2)) {
+                st4(dyp + (2 * I) * sstride, to_F4(dY.t[0]));
+                st4(dyp + (2 * I + 1) * sstride, to_F4(dY.t[1]));
+            }
+            if (I == 3) dY3 = dY;
+            if (I == 0) dY0 = dY;
+            if (!XYZ) {
+                if (I == 3 && need_dc) gemv_t<2>(dc.t, dY, wt + nox_mat(NW3C).pk, lane);
+                if (I == 0 && need_dc) gemv_t<2>(dc.t, dY, wt + nox_mat(NW0).pk, lane);
+            }
+            if (I > 0) {
+                Act<2> nd;
+                act_zero(nd);
+                if (XYZ) gemv_t<2>(nd.t, dY, wt + xyzT_wh(I - 1), lane);
+                else gemv_t<2>(nd.t, dY, wt + nox_mat(I == 1 ? NW1 : (I == 2 ? NW2 : (I == 3 ? NW3H : NW4))).pk, lane);
+                dh = nd;
+            }
+        }
+        // ---- embedding backward: dE = W0^T dY0 + W3e^T dY3, d arg = dE cos(arg); d p (rays) and d _B (parameters)
+        float dpe[3] = {0.f, 0.f, 0.f};
+        if (XYZ && PARAMS && !(P.xflags & 4)) {
+            // "lane = channel" form: swapping the MFMA operands (A = dY registers, B = transposed stream) yields
+            // dE[point 4 g + r][channel 16 Tk + j] in lane (j, g) -- the layout the contraction over points for d _B needs
+            if (g == 0) { Sw[kDxP + pt] = px; Sw[kDxP + 16 + pt] = py; Sw[kDxP + 32 + pt] = pz; }
+            wave_fence();
+            const f32x4 qx = to_v(ld4(Sw + kDxP + 4 * g)), qy = to_v(ld4(Sw + kDxP + 16 + 4 * g)), qz = to_v(ld4(Sw + kDxP + 32 + 4 * g));
+            f32x4 sx = f4zero(), sy = f4zero(), sz = f4zero();
+#pragma unroll
+            for (int Tk = 0; Tk < kET; ++Tk) {
+                f32x4 e0 = f4zero(), e3 = f4zero();
+#pragma unroll
+                for (int To = 0; To < 2; ++To) {
+                    const f32x4 a0 = to_v(ld4(wt + xyzT_w0() + ((Tk * 2 + To) * 64 + lane) * 4));
+                    const f32x4 a3 = to_v(ld4(wt + xyzT_w3e() + ((Tk * 2 + To) * 64 + lane) * 4));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        e0 = mfma16(dY0.t[To][r], a0[r], e0);
+                        e3 = mfma16(dY3.t[To][r], a3[r], e3);
+                    }
+                }
+                sched_fence_emb();
+                const F4 b = load_b1(aux, 16 * Tk + pt);
+                const f32x4 darg = (e0 + e3) * cos_acc4(vfma(qz, splat(b.z), vfma(qy, splat(b.y), qx * splat(b.x))));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    aB[Tk][0] = fmaf(darg[r], qx[r], aB[Tk][0]); aB[Tk][1] = fmaf(darg[r], qy[r], aB[Tk][1]);
+                    aB[Tk][2] = fmaf(darg[r], qz[r], aB[Tk][2]);
+                }
+                if (RAYS) { sx = vfma(darg, splat(b.x), sx); sy = vfma(darg, splat(b.y), sy); sz = vfma(darg, splat(b.z), sz); }
+            }
+            if (RAYS) {
+                // d p[point][d] = sum over channels: across the 16 lanes of the row, then over to the CL lane of the point
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sx[r] += shfl_xor(sx[r], m); sy[r] += shfl_xor(sy[r], m); sz[r] += shfl_xor(sz[r], m); }
+                if (pt == 0) { st4(Sw + kDxDP + 4 * g, to_F4(sx)); st4(Sw + kDxDP + 16 + 4 * g, to_F4(sy)); st4(Sw + kDxDP + 32 + 4 * g, to_F4(sz)); }
+                wave_fence();
+                dpe[0] = Sw[kDxDP + pt]; dpe[1] = Sw[kDxDP + 16 + pt]; dpe[2] = Sw[kDxDP + 32 + pt];
+            }
+            wave_fence();
+        } else if (XYZ && RAYS) {
+            f32x4 dE[kET];
+#pragma unroll
+            for (int Tk = 0; Tk < kET; ++Tk) dE[Tk] = f4zero();
+            gemv_t<kET>(dE, dY0, wt + xyzT_w0(), lane);
+            gemv_t<kET>(dE, dY3, wt + xyzT_w3e(), lane);
+            float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+            for (int Tk = 0; Tk < kET; ++Tk) {
+                const B4 b = load_b4(aux, 4 * Tk + g);
+                const f32x4 darg = dE[Tk] * cos_acc4(vfma(splat(pz), b.z, vfma(splat(py), b.y, splat(px) * b.x)));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ax = fmaf(darg[r], b.x[r], ax); ay = fmaf(darg[r], b.y[r], ay); az = fmaf(darg[r], b.z[r], az); }
+                sched_fence_emb();
+            }
+            dpe[0] = red_g(ax); dpe[1] = red_g(ay); dpe[2] = red_g(az);
+        }
+        // ---- grid: coordinate gradient, scatter; ray gradients
+        Lvl L;
+        if (need_dc) L = make_level(G, cur.px, cur.py, cur.pz);
+        float dux = 0.f, duy = 0.f, duz = 0.f;
+        if (RAYS) coord_grad(G, L, g, dc, dux, duy, duz);
+        dx_keep(nx);
+        if (do_grid && !(P.xflags & 1))
+            scatter_merged(G, L, lane, dc, active, Sw + kDxTx, Sw + kDxTab, (P.xflags & 8) ? (unsigned)(tile * 64 + (lane >> 5) + 1) : 0u);
+        if (RAYS) {
+            // d p = d u * (n-1)/2 * 2/(hi-lo) (+ embedding part), fp64 like autograd through Renderer.py:172;
+            // d rays_o += d p, d rays_d += d p * z
+            double v[6];
+            const bool mine = active && g == 0;
+            v[0] = mine ? (double)dux * (2.0 * G.inv[0]) + (double)dpe[0] : 0.0;
+            v[1] = mine ? (double)duy * (2.0 * G.inv[1]) + (double)dpe[1] : 0.0;
+            v[2] = mine ? (double)duz * (2.0 * G.inv[2]) + (double)dpe[2] : 0.0;
+            v[3] = v[0] * cur.z; v[4] = v[1] * cur.z; v[5] = v[2] * cur.z;
+            if ((P.S & (kTile - 1)) == 0) {                      // a tile never straddles two rays: one atomic per component
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1)
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) v[q] += shfl_xor_d(v[q], m);
+                if (lane == 0 && active) {
+                    const long long ray = gp / P.S;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        atomic_add_global(P.d_rays_o + ray * 3 + q, (float)v[q]);
+                        atomic_add_global(P.d_rays_d + ray * 3 + q, (float)v[3 + q]);
+                    }
+                }
+            } else if (mine) {
+                const long long ray = gp / P.S;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    atomic_add_global(P.d_rays_o + ray * 3 + q, (float)v[q]);
+                    atomic_add_global(P.d_rays_d + ray * 3 + q, (float)v[3 + q]);
+                }
+            }
+        }
+        cur = nx;
+    }
+    if (XYZ && PARAMS) {
+        // d _B of this block: sum over the lane groups, then over the waves through LDS (the staging regions are free)
+        block_sync();
+#pragma unroll
+        for (int k = 0; k < kET; ++k)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                float v = aB[k][d];
+                v += shfl_xor(v, 16); v += shfl_xor(v, 32);
+                if (g == 0) stg[wave * kDbPart + d * 96 + 16 * k + pt] = v;
+            }
+        block_sync();
+        float *part = P.dbpart + ((long long)bid_y() * nblk_x() + bid_x()) * kDbPart;
+        for (int t = tid(); t < kDbPart; t += nthreads()) {
+            float s = 0.f;
+            for (int w = 0; w < nw; ++w) s += stg[w * kDbPart + t];
+            part[t] = s;
+        }
+    }
+}
+
+// grid = (blocks per pass, decoder passes of the stage); a block stages ONE decoder's transposed stream and walks the tiles
+// tile = block * waves + wave, + blocks * waves, ... of its pass.
+template <int STAGE, bool RAYS>
+NSR_KERNEL NSR_BOUNDS(64 * kDxMaxWaves) void render_bwd_dx_kernel(const RenderParams P) {
+    if (STAGE == NSR_STAGE_COARSE) {
+        if (P.dec[NSR_COARSE].dparams) dx_pass<NSR_COARSE, true, RAYS>(P); else dx_pass<NSR_COARSE, false, RAYS>(P);
+    } else {
+        const int pass = bid_y();
+        if (pass == 0) {
+            if (P.dec[NSR_MIDDLE].dparams) dx_pass<NSR_MIDDLE, true, RAYS>(P); else dx_pass<NSR_MIDDLE, false, RAYS>(P);
+        } else if (pass == 1) {
+            if (STAGE >= NSR_STAGE_FINE) { if (P.dec[NSR_FINE].dparams) dx_pass<NSR_FINE, true, RAYS>(P); else dx_pass<NSR_FINE, false, RAYS>(P); }
+        } else {
+            if (STAGE == NSR_STAGE_COLOR) { if (P.dec[NSR_COLOR].dparams) dx_pass<NSR_COLOR, true, RAYS>(P); else dx_pass<NSR_COLOR, false, RAYS>(P); }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dW kernel: split-K GEMM over the sample points through an LDS ring
+// ------------------------------------------------------------------------------------------------
+constexpr int kDwWaves = 8, kDwRing = 3;
+template <int KIND>
+struct DwLay {
+    static constexpr bool XYZ = KIND != NSR_COARSE;
+    static constexpr int NC = KIND == NSR_FINE ? 4 : 2;          // feature operand tiles ([c_fine | c_mid] for the fine decoder)
+    static constexpr int oDY = 0, oH = 10 * 256, oC = 20 * 256;   // operand tiles: [16 points][16 channels] floats, as in memory
+    static constexpr int oPD = (20 + NC) * 256;                   // [16][4] doubles
+    static constexpr int oDR = oPD + 128;                         // [16][4] floats
+    static constexpr int kSlot = oDR + 64;
+    static constexpr int NOPS = 20 + NC + 2;                      // DMA pieces per tile
+    static constexpr int CNT = (NOPS + kDwWaves - 1) / kDwWaves;  // ... per wave (uniform: the tail repeats the last piece)
+};
+constexpr int dw_lds_floats(int kind) { return kDwRing * (kind == NSR_FINE ? DwLay<NSR_FINE>::kSlot : DwLay<NSR_MIDDLE>::kSlot); }
+
+// request tile `tile`'s operands into ring slot `slot` (this wave's share of the pieces)
+template <int KIND>
+NSR_DEV void dw_issue(const RenderParams &P, long long tile, float *slot, int wave, int lane) {
+    typedef DwLay<KIND> Y;
+    const long long ss = P.act_stride;
+    const float *acts_pass = P.acts + (long long)act_pass(KIND) * kActSlots * ss;
+    const float *dys = P.dy + (long long)act_pass(KIND) * kDySlots * ss;
+#pragma unroll
+    for (int k = 0; k < Y::CNT; ++k) {
+        int n = wave + k * kDwWaves;
+        if (n > Y::NOPS - 1) n = Y::NOPS - 1;
+        if (n < 10) dma16(dys + n * ss + tile * 256 + lane * 4, slot + Y::oDY + n * 256, lane);
+        else if (n < 20) dma16(acts_pass + (n - 10) * ss + tile * 256 + lane * 4, slot + Y::oH + (n - 10) * 256, lane);
+        else if (n < 22) dma16(acts_pass + (kActC + n - 20) * ss + tile * 256 + lane * 4, slot + Y::oC + (n - 20) * 256, lane);
+        else if (n < 20 + Y::NC) dma16(P.acts + (kActC + n - 22) * ss + tile * 256 + lane * 4, slot + Y::oC + (n - 20) * 256, lane);   // fine: middle features (pass 0)
+        else if (n == 20 + Y::NC) { if (lane < 32) dma16(reinterpret_cast<const float *>(P.pd) + tile * 128 + lane * 4, slot + Y::oPD, lane); }
+        else { if (lane < 16) dma16(P.draw + tile * 64 + lane * 4, slot + Y::oDR, lane); }
+    }
+}
+
+// operand tile in "lane = channel" form: element q = X[point 4 q + g][channel i]   (lane = 16 g + i; conflict-free dword reads)
+NSR_DEV f32x4 lds_op(const float *tile, int lane) {
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = tile[q * 64 + lane];
+    return v;
+}
+// d[n] += a[n]^T x over the 16 points of the tile, k-steps alternating between the accumulators
+template <int N>
+NSR_DEV void dw_acc(f32x4 (&d)[N], const f32x4 (&a)[N], const f32x4 x) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int n = 0; n < N; ++n) d[n] = mfma16(a[n][q], x[q], d[n]);
+}
+NSR_DEV void img_tile(float *img, const Mat m, int To, int Tk, const f32x4 acc, int i, int g) {
+    if (16 * Tk + i < m.kcols) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) img[m.off + (16 * To + 4 * g + r) * m.stride + m.kbeg + 16 * Tk + i] = acc[r];
+    }
+}
+NSR_DEV float red_g4(float v) { v += shfl_xor(v, 16); v += shfl_xor(v, 32); return v; }
+
+// what one wave of an xyz-decoder block owns (see the header): waves 0..5 the Fourier-feature blocks W0 / W3e of embedding
+// k-tile `wave` (they share one sine evaluation) plus a part of layers 3 / 4, the output layer or the first bias; waves 6 / 7
+// layers 1 / 2.
+template <int KIND, int WAVE>
+struct DwXyzWave {
+    typedef DwLay<KIND> Y;
+    static constexpr int CD = cdim_of(KIND), NC = Y::NC, NOUT = nout_of(KIND), NO = NOUT == 1 ? 1 : 3;
+    static constexpr bool kWe = WAVE < 6;
+    static constexpr int LJ = WAVE == 6 ? 1 : (WAVE == 7 ? 2 : (WAVE < 2 ? 3 : (WAVE < 4 ? 4 : 0)));     // layer of the Wh / G tiles, 0: none
+    static constexpr int R0 = WAVE >= 6 ? 0 : (WAVE & 1), NR = WAVE >= 6 ? 2 : (LJ ? 1 : 0);              // output row tiles To = R0 .. R0 + NR - 1
+    static constexpr bool kOut = WAVE == 4, kB0 = WAVE == 5;
+    f32x4 we[4];               // [W0 To 0, W0 To 1, W3e To 0, W3e To 1] x embedding k-tile WAVE
+    f32x4 wh[2][2], gg[2][4];  // [row][k-tile]
+    float vb[2];               // bias sums of layer LJ (rows R0..) / of layer 0 (kB0)
+    float wo[3][2], bo[3], go[3][4];
+    float bx, by, bz;          // Fourier matrix column of channel 16 WAVE + i
+
+    NSR_DEV void init(const RenderParams &P, int i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) we[k] = f4zero();
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            vb[a] = 0.f;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) wh[a][b] = f4zero();
+#pragma unroll
+            for (int b = 0; b < 4; ++b) gg[a][b] = f4zero();
+        }
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            bo[n] = 0.f; wo[n][0] = wo[n][1] = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) go[n][b] = 0.f;
+        }
+        bx = by = bz = 0.f;
+        if (kWe) {
+            const F4 b = load_b1(P.dec[KIND].packed, 16 * WAVE + i);     // aux table of the packed buffer (global)
+            bx = b.x; by = b.y; bz = b.z;
+        }
+    }
+    NSR_DEV void tile(const float *s, int lane) {
+        const int g = lane >> 4;
+        if (kWe) {
+            f32x4 y[4];
+            y[0] = lds_op(s + Y::oDY + 0 * 256, lane); y[1] = lds_op(s + Y::oDY + 1 * 256, lane);
+            y[2] = lds_op(s + Y::oDY + 6 * 256, lane); y[3] = lds_op(s + Y::oDY + 7 * 256, lane);
+            const double *pd = reinterpret_cast<const double *>(s + Y::oPD);
+            f32x4 qx, qy, qz;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                qx[q] = (float)pd[(4 * q + g) * 4 + 0]; qy[q] = (float)pd[(4 * q + g) * 4 + 1]; qz[q] = (float)pd[(4 * q + g) * 4 + 2];
+            }
+            const f32x4 e = sin_acc4(vfma(qz, splat(bz), vfma(qy, splat(by), qx * splat(bx))));     // decoder.py:29-30
+            dw_acc<4>(we, y, e);
+            if (kB0) { vb[0] += sum4(y[0]); vb[1] += sum4(y[1]); }
+        }
+        if (LJ > 0) {
+            f32x4 a[NR > 0 ? NR : 1];
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                a[rr] = lds_op(s + Y::oDY + (2 * LJ + R0 + rr) * 256, lane);
+                vb[rr] += sum4(a[rr]);
+            }
+#pragma unroll
+            for (int Tk = 0; Tk < 2; ++Tk) {
+                const f32x4 x = lds_op(s + Y::oH + (2 * (LJ - 1) + Tk) * 256, lane);
+                f32x4 d[NR > 0 ? NR : 1];
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) d[rr] = wh[rr][Tk];
+                dw_acc<(NR > 0 ? NR : 1)>(d, a, x);
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) wh[rr][Tk] = d[rr];
+            }
+#pragma unroll
+            for (int Tc = 0; Tc < NC; ++Tc) {
+                const f32x4 x = lds_op(s + Y::oC + Tc * 256, lane);
+                f32x4 d[NR > 0 ? NR : 1];
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) d[rr] = gg[rr][Tc];
+                dw_acc<(NR > 0 ? NR : 1)>(d, a, x);
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) gg[rr][Tc] = d[rr];
+            }
+        }
+        if (kOut) {
+            // output layer: d Wo[n][k] = sum_p d_out[p][n] h4[p][k], d bo, and g_out[n][c] = sum_p d_out[p][n] c[p][c] (-> dU_4)
+            f32x4 dn[NO];
+#pragma unroll
+            for (int n = 0; n < NO; ++n)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dn[n][q] = s[Y::oDR + (4 * q + g) * 4 + (NOUT == 1 ? 3 : n)];
+            const f32x4 h0 = lds_op(s + Y::oH + 8 * 256, lane), h1 = lds_op(s + Y::oH + 9 * 256, lane);
+#pragma unroll
+            for (int n = 0; n < NO; ++n) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { wo[n][0] = fmaf(dn[n][q], h0[q], wo[n][0]); wo[n][1] = fmaf(dn[n][q], h1[q], wo[n][1]); }
+                bo[n] += sum4(dn[n]);
+            }
+#pragma unroll
+            for (int Tc = 0; Tc < NC; ++Tc) {
+                const f32x4 x = lds_op(s + Y::oC + Tc * 256, lane);
+#pragma unroll
+                for (int n = 0; n < NO; ++n)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) go[n][Tc] = fmaf(dn[n][q], x[q], go[n][Tc]);
+            }
+        }
+    }
+    NSR_DEV void flush(float *img, int lane) {
+        const int i = lane & 15, g = lane >> 4;
+        if (kWe) {
+            img_tile(img, xyz_mat(CD, XW0), 0, WAVE, we[0], i, g); img_tile(img, xyz_mat(CD, XW0), 1, WAVE, we[1], i, g);
+            img_tile(img, xyz_mat(CD, XW3E), 0, WAVE, we[2], i, g); img_tile(img, xyz_mat(CD, XW3E), 1, WAVE, we[3], i, g);
+        }
+        if (kB0) {
+#pragma unroll
+            for (int T = 0; T < 2; ++T) { const float v = red_g4(vb[T]); if (g == 0) img[bias_off(KIND, 0) + 16 * T + i] = v; }
+        }
+        if (LJ > 0) {
+            const Mat mh = xyz_mat(CD, LJ == 1 ? XW1 : (LJ == 2 ? XW2 : (LJ == 3 ? XW3H : XW4)));
+            const Mat mg = xyz_mat(CD, LJ == 1 ? XU0 : (LJ == 2 ? XU1 : (LJ == 3 ? XU2 : XU3)));          // G_j sits where dU_{j-1} lives
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+#pragma unroll
+                for (int Tk = 0; Tk < 2; ++Tk) img_tile(img, mh, R0 + rr, Tk, wh[rr][Tk], i, g);
+#pragma unroll
+                for (int Tc = 0; Tc < NC; ++Tc) img_tile(img, mg, R0 + rr, Tc, gg[rr][Tc], i, g);
+                const float v = red_g4(vb[rr]);
+                if (g == 0) img[bias_off(KIND, LJ) + 16 * (R0 + rr) + i] = v;
+            }
+        }
+        if (kOut) {
+#pragma unroll
+            for (int n = 0; n < NO; ++n) {
+#pragma unroll
+                for (int T = 0; T < 2; ++T) { const float v = red_g4(wo[n][T]); if (g == 0) img[wo_off(KIND) + n * 32 + 16 * T + i] = v; }
+                const float vbo = red_g4(bo[n]);
+                if (lane == 0) img[bo_off(KIND) + n] = vbo;
+#pragma unroll
+                for (int Tc = 0; Tc < NC; ++Tc) { const float v = red_g4(go[n][Tc]); if (g == 0) img[xyz_fcw(CD, 4) + n * CD + 16 * Tc + i] = v; }
+            }
+            if (NOUT == 4 && lane < 32) img[wo_off(KIND) + 3 * 32 + lane] = 0.f;      // decoder.py:341: the 4th colour output is discarded
+            if (NOUT == 4 && lane == 0) img[bo_off(KIND) + 3] = 0.f;
+        }
+    }
+};
+
+// MLP_no_xyz: wave m < 6 owns the four 16x16 tiles of matrix m (NW0, NW1, NW2, NW3C, NW3H, NW4) and, where it reads a
+// layer's dY first, its bias sums; wave 6 the output layer.
+template <int WAVE>
+struct DwNoxWave {
+    typedef DwLay<NSR_COARSE> Y;
+    static constexpr int LJ = WAVE == NW3C ? 3 : (WAVE == NW3H ? 3 : (WAVE == NW4 ? 4 : WAVE));       // layer whose dY this matrix contracts
+    static constexpr bool kMat = WAVE < 6, kBias = kMat && WAVE != NW3H, kOut = WAVE == 6;
+    f32x4 w[2][2];
+    float vb[2], wo[2], bo;
+    NSR_DEV void init(const RenderParams &, int) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) { vb[a] = 0.f; wo[a] = 0.f; w[a][0] = f4zero(); w[a][1] = f4zero(); }
+        bo = 0.f;
+    }
+    NSR_DEV void tile(const float *s, int lane) {
+        const int g = lane >> 4;
+        if (kMat) {
+            f32x4 a[2];
+            a[0] = lds_op(s + Y::oDY + (2 * LJ) * 256, lane); a[1] = lds_op(s + Y::oDY + (2 * LJ + 1) * 256, lane);
+            if (kBias) { vb[0] += sum4(a[0]); vb[1] += sum4(a[1]); }
+#pragma unroll
+            for (int Tk = 0; Tk < 2; ++Tk) {
+                // input of the matrix: the features (NW0, NW3C) or the previous hidden state
+                const float *xs = (WAVE == NW0 || WAVE == NW3C) ? s + Y::oC + Tk * 256 : s + Y::oH + (2 * (LJ - 1) + Tk) * 256;
+                const f32x4 x = lds_op(xs, lane);
+                f32x4 d[2] = {w[0][Tk], w[1][Tk]};
+                dw_acc<2>(d, a, x);
+                w[0][Tk] = d[0]; w[1][Tk] = d[1];
+            }
+        }
+        if (kOut) {
+            f32x4 dn;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dn[q] = s[Y::oDR + (4 * q + g) * 4 + 3];
+            const f32x4 h0 = lds_op(s + Y::oH + 8 * 256, lane), h1 = lds_op(s + Y::oH + 9 * 256, lane);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { wo[0] = fmaf(dn[q], h0[q], wo[0]); wo[1] = fmaf(dn[q], h1[q], wo[1]); }
+            bo += sum4(dn);
+        }
+    }
+    NSR_DEV void flush(float *img, int lane) {
+        const int i = lane & 15, g = lane >> 4;
+        if (kMat) {
+            const Mat m = nox_mat(WAVE);
+#pragma unroll
+            for (int To = 0; To < 2; ++To)
+#pragma unroll
+                for (int Tk = 0; Tk < 2; ++Tk) img_tile(img, m, To, Tk, w[To][Tk], i, g);
+            if (kBias) {
+#pragma unroll
+                for (int T = 0; T < 2; ++T) { const float v = red_g4(vb[T]); if (g == 0) img[nox_b(LJ) + 16 * T + i] = v; }
+            }
+        }
+        if (kOut) {
+#pragma unroll
+            for (int T = 0; T < 2; ++T) { const float v = red_g4(wo[T]); if (g == 0) img[nox_wo() + 16 * T + i] = v; }
+            const float vbo = red_g4(bo);
+            if (lane == 0) img[nox_bo()] = vbo;
+        }
+    }
+};
+
+template <int KIND, class W>
+NSR_DEV void dw_wave(const RenderParams &P, W &Wv, float *ring, float *img, int wave, int lane) {
+    typedef DwLay<KIND> Y;
+    Wv.init(P, lane & 15);
+    const long long ntiles = (P.n_points_total + kTile - 1) / kTile;
+    const long long last = ntiles - 1, step = nblk_x();
+    long long t = bid_x();
+    // ring: tile t in slot (it % 3); two tiles requested ahead.  Every wave always issues its CNT pieces per tile (requests
+    // beyond the block's last tile repeat that tile into a slot nobody reads), so "all but the newest CNT * k requests have
+    // landed" is a constant wait count.
+    auto clampt = [&](long long x) { return x < ntiles ? x : last; };
+    dw_issue<KIND>(P, clampt(t), ring, wave, lane);
+    dw_issue<KIND>(P, clampt(t + step), ring + Y::kSlot, wave, lane);
+    int it = 0;
+    for (; t < ntiles; t += step, ++it) {
+        loop_fence();
+        float *s = ring + (it % kDwRing) * Y::kSlot;
+        dma_wait<Y::CNT>();                          // this wave's pieces of tile t have landed ...
+        block_sync();                                // ... and everybody else's; everyone is done with the previous tile's slot
+        dw_issue<KIND>(P, clampt(t + 2 * step), ring + ((it + 2) % kDwRing) * Y::kSlot, wave, lane);
+        if (t == last && (P.n_points_total & (kTile - 1))) {
+            // ragged last tile: rows beyond the last point hold whatever the padding holds -- zero them (every wave of the block)
+            const int nvalid = (int)(P.n_points_total & (kTile - 1));
+            for (int idx = tid(); idx < Y::kSlot; idx += nthreads()) {
+                const int row = idx < Y::oPD ? ((idx & 255) >> 4) : (idx < Y::oDR ? (idx - Y::oPD) >> 3 : (idx - Y::oDR) >> 2);
+                if (row >= nvalid) s[idx] = 0.f;
+            }
+            block_sync();
+        }
+        Wv.tile(s, lane);
+    }
+    dma_wait<0>();
+    Wv.flush(img, lane);
+}
+
+template <int KIND>
+NSR_DEV void dw_pass(const RenderParams &P) {
+    float *ring = reinterpret_cast<float *>(lds_base());
+    const int lane = tid() & 63, wave = uniform(tid() >> 6);
+    float *img = P.partials + ((long long)bid_y() * nblk_x() + bid_x()) * P.partial_stride;
+    if constexpr (KIND == NSR_COARSE) {
+        switch (wave) {
+            case 0: { DwNoxWave<0> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
+            case 1: { DwNoxWave<1> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
+            case 2: { DwNoxWave<2> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
+            case 3: { DwNoxWave<3> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
+            case 4: { DwNoxWave<4> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
+            case 5: { DwNoxWave<5> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
+            case 6: { DwNoxWave<6> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
+            default: { DwNoxWave<7> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
+        }
+    } else {
+        switch (wave) {
+            case 0: { DwXyzWave<KIND, 0> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
+            case 1: { DwXyzWave<KIND, 1> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
+            case 2: { DwXyzWave<KIND, 2> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
+            case 3: { DwXyzWave<KIND, 3> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
+            case 4: { DwXyzWave<KIND, 4> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
+            case 5: { DwXyzWave<KIND, 5> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
+            case 6: { DwXyzWave<KIND, 6> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
+            default: { DwXyzWave<KIND, 7> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
+        }
+    }
+}
+
+// grid = (partial images per pass, decoder passes of the stage); passes without parameter gradients exit at once
+template <int STAGE>
+NSR_KERNEL NSR_BOUNDS(64 * kDwWaves) void render_bwd_dw_kernel(const RenderParams P) {
+    if (STAGE == NSR_STAGE_COARSE) {
+        if (P.dec[NSR_COARSE].dparams) dw_pass<NSR_COARSE>(P);
+    } else {
+        const int pass = bid_y();
+        if (pass == 0) { if (P.dec[NSR_MIDDLE].dparams) dw_pass<NSR_MIDDLE>(P); }
+        else if (pass == 1) { if (STAGE >= NSR_STAGE_FINE && P.dec[NSR_FINE].dparams) dw_pass<NSR_FINE>(P); }
+        else { if (STAGE == NSR_STAGE_COLOR && P.dec[NSR_COLOR].dparams) dw_pass<NSR_COLOR>(P); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: dparams (+)= f(sum of the partial images).  grid = (blocks, decoders with gradients), 1024 threads.
+//   blocks [0, nd):        64 directly accumulated parameters each (pts_linears, output_linear; everything for MLP_no_xyz)
+//   blocks [nd, nd + 5):   d embedder._B from the dX kernel's partials (64 each)
+//   blocks [nd + 5, + 5 c_dim / 8):  fc_c.i, eight feature columns each: dU_i = W_{i+1}^T G_{i+1} (G summed from the images,
+//                          where it sits in dU_i's place), dv_i = W_{i+1}^T db_{i+1};  i = 4: Wo^T g_out, Wo^T d bo
+// ------------------------------------------------------------------------------------------------
+struct FinalJob {
+    const float *images;     // [nimg][stride]
+    const float *dbpart;     // [ndx][kDbPart]
+    const float *params;     // flat parameter blob (the 32x32 matrices of the transforms)
+    float *dparams;
+    int kind, nimg, ndx;
+};
+struct FinalParams {
+    FinalJob job[3];
+    int stride, overwrite;
+};
+NSR_DEV void final_store(const FinalParams &R, float *p, float v) { *p = R.overwrite ? v : *p + v; }
+
+NSR_KERNEL void bwd_finalize_kernel(const FinalParams R) {
+    const FinalJob J = R.job[bid_y()];
+    float *red = reinterpret_cast<float *>(lds_base());            // [2048 + 32] floats
+    const int kind = J.kind, cd = cdim_of(kind), nout = nout_of(kind);
+    const bool xyz = kind != NSR_COARSE;
+    const int dbeg = xyz ? xyz_w(cd, 0) : 0, total = param_total(kind);
+    const int nd = (total - dbeg + 63) / 64;
+    const int b = bid_x(), t = tid(), nt = nthreads();
+    const int lane = t & 63, slice = t >> 6, nslice = nt >> 6;
+    if (b < nd + 5) {
+        // plain sums: 64 parameters x nslice slices of the image list
+        const bool isB = b >= nd;
+        if (isB && !xyz) return;
+        const int e = (isB ? (b - nd) : b) * 64 + lane;             // element within the region
+        const int n = isB ? 3 * kE : total - dbeg;
+        float s = 0.f;
+        if (e < n) {
+            if (isB) {
+                const int d = e / kE, ch = e - d * kE;
+                for (int k = slice; k < J.ndx; k += nslice) s += J.dbpart[(long long)k * kDbPart + d * 96 + ch];
+            } else {
+                for (int k = slice; k < J.nimg; k += nslice) s += J.images[(long long)k * R.stride + dbeg + e];
+            }
+        }
+        red[t] = s;
+        block_sync();
+        if (slice == 0 && e < n) {
+            for (int k = 1; k < nslice; ++k) s += red[k * 64 + lane];
+            final_store(R, J.dparams + (isB ? xyz_B(cd) : dbeg) + e, s);
+        }
+        return;
+    }
+    if (!xyz) return;
+    // fc_c layer i, feature columns [8 chunk, 8 chunk + 8): S[o][c] = sum over the images of G (rows o < nrow of dU_i's place),
+    // 256 elements x 4 slices of the image list; chunk 0 also forms the bias sums db (32 slices) and dv_i
+    const int per = cd / 8, i = (b - nd - 5) / per, chunk = (b - nd - 5) % per;
+    if (i > 4) return;                                              // (grid sized for the largest decoder of the stage)
+    // the colour decoder's 4th output is discarded (decoder.py:341): three rows
+    const int nrow = i < 4 ? 32 : (nout == 1 ? 1 : 3), goff = xyz_fcw(cd, i);
+    const int e = t & 255, o = e >> 3, c = 8 * chunk + (e & 7), sl = t >> 8;
+    {
+        float sg = 0.f;
+        if (o < nrow)
+            for (int k = sl; k < J.nimg; k += 4) sg += J.images[(long long)k * R.stride + goff + o * cd + c];
+        red[t] = sg;
+    }
+    if (chunk == 0) {
+        const int ob = t & 31, sb = t >> 5;
+        const int boff = i < 4 ? xyz_b(cd, i + 1) : xyz_bo(cd, nout);
+        float sbv = 0.f;
+        if (ob < nrow)
+            for (int k = sb; k < J.nimg; k += 32) sbv += J.images[(long long)k * R.stride + boff + ob];
+        red[1024 + t] = sbv;
+    }
+    block_sync();
+    if (t < 256) red[t] = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
+    if (chunk == 0 && t >= 256 && t < 288) {
+        float sbv = 0.f;
+        for (int k = 0; k < 32; ++k) sbv += red[1024 + k * 32 + (t - 256)];
+        red[2048 + (t - 256)] = sbv;
+    }
+    block_sync();
+    // W[o][k]: pts_linears.(i+1).weight (hidden-state columns) or output_linear.weight
+    const int woff = i < 4 ? xyz_w(cd, i + 1) + (i == 2 ? kE : 0) : xyz_wo(cd);
+    const int wstr = i < 4 ? xyz_in(i + 1) : 32;
+    if (t < 256) {
+        const int k = t >> 3, cc = t & 7;
+        float sv = 0.f;
+        for (int oo = 0; oo < nrow; ++oo) sv = fmaf(J.params[woff + oo * wstr + k], red[oo * 8 + cc], sv);
+        final_store(R, J.dparams + goff + k * cd + 8 * chunk + cc, sv);
+    } else if (chunk == 0 && t < 288) {
+        const int k = t - 256;
+        float sv = 0.f;
+        for (int oo = 0; oo < nrow; ++oo) sv = fmaf(J.params[woff + oo * wstr + k], red[2048 + oo], sv);
+        final_store(R, J.dparams + xyz_fcb(cd, i) + k, sv);
+    }
+}
+
+}  // namespace nsr

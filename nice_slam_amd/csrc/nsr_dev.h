@@ -96,6 +96,14 @@ NSR_DEV void prefetch_line(const float *p, float *lds_sink) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)p,
                                      (__attribute__((address_space(3))) void *)lds_sink, 4, 0, 0);
 }
+// 16 bytes per lane, global -> LDS without a destination register (gfx950 global_load_lds_dwordx4): lane l's bytes land at
+// lds_base + 16 l, i.e. one wave instruction moves 1 KB; completion is tracked by the vector-memory counter (dma_wait).
+NSR_DEV void dma16(const float *gsrc, float *lds_base, int /*lane*/) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_base, 16, 0, 0);
+}
+// wait until at most N of this wave's vector-memory requests are outstanding (they complete in order)
+template <int N> NSR_DEV void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 NSR_DEV void atomic_add_global(float *p, float v) { unsafeAtomicAdd(p, v); }
 NSR_DEV void atomic_add_lds(float *p, float v) { atomicAdd(p, v); }
 NSR_DEV void atomic_add_lds_i(int *p, int v) { atomicAdd(p, v); }

@@ -70,7 +70,8 @@ struct RenderParams {
     float *rgb, *raw;
     double *zvals;            // [N][S] saved sample depths (optional)
     float *acts;              // saved decoder activations (optional, see ActSink): the backward then loads h_i / relu masks
-    long long n_points_total; // n_rays * S (slot stride of `acts`)
+    long long n_points_total; // n_rays * S
+    long long act_stride;     // floats between two activation slots: 16 * (n_points_total rounded up to whole 16-point tiles)
     // backward only
     const double *d_depth, *d_var, *g_depth;
     const float *d_rgb;
@@ -86,6 +87,13 @@ struct RenderParams {
     float *dl_rgb;            // forward: d loss / d rgb per ray    [N][3]
     float w_color;            // weight of the colour term (colour stage only)
     long long *dbg;           // profiling stamps (NSR_TS builds only), else NULL
+    // split backward (nsr_bwd2.h): scratch behind the saved activations in `acts`
+    float *dy;                // [passes][kDySlots][n_points][16]  dY_i of every decoder pass (same slot form as `acts`)
+    float *draw;              // [n_points][4]  d raw per sample (compositor backward)
+    double *pd;               // [n_points][4]  sample position (fp64) and depth: px, py, pz, z
+    float *dbpart;            // [passes][dx blocks][288]  per-block partial sums of d embedder._B
+    int dw_blocks;            // blocks per pass of the dW kernel = partial images per pass
+    int xflags;               // measurement switches (NSR_X environment variable; 0 in normal operation)
     // eval_points only
     const double *points;
     long long n_points;
@@ -126,15 +134,31 @@ NSR_KERNEL void pack_kernel(const float *__restrict__ flat, float *__restrict__ 
     if (gidx < AUX_FLOATS) { packed[gidx] = aux_value<KIND>(flat, gidx); return; }
     const int idx = gidx - AUX_FLOATS;
     float v = 0.f;
+    if (idx < packed_total(KIND)) {
 #pragma unroll
-    for (int id = 0; id < nmat_of(KIND); ++id) {
-        const Mat m = mat_of(KIND, id);
-        const int rel = idx - m.pk;
-        if (rel >= 0 && rel < m.nt * 512) {
-            const int r = rel & 3, lane = (rel >> 2) & 63, Tp = (rel >> 8) & 1, T = rel >> 9;
-            const int o = 16 * Tp + (lane & 15);
-            const int k = 16 * T + 4 * (lane >> 4) + r;
-            if (k < m.kcols) v = flat[m.off + o * m.stride + m.kbeg + k];
+        for (int id = 0; id < nmat_of(KIND); ++id) {
+            const Mat m = mat_of(KIND, id);
+            const int rel = idx - m.pk;
+            if (rel >= 0 && rel < m.nt * 512) {
+                const int r = rel & 3, lane = (rel >> 2) & 63, Tp = (rel >> 8) & 1, T = rel >> 9;
+                const int o = 16 * Tp + (lane & 15);
+                const int k = 16 * T + 4 * (lane >> 4) + r;
+                if (k < m.kcols) v = flat[m.off + o * m.stride + m.kbeg + k];
+            }
+        }
+    } else {
+        // transposed stream (nsr_layout.h): T[((Tk*2 + To)*64 + lane)*4 + r] = W[16 To + 4 (lane>>4) + r][kbeg + 16 Tk + (lane&15)]
+        const int idt = idx - packed_total(KIND);
+#pragma unroll
+        for (int id = 0; id < nmatT_of(KIND); ++id) {
+            const Mat m = matT_of(KIND, id);
+            const int rel = idt - m.pk;
+            if (rel >= 0 && rel < m.nt * 512) {
+                const int r = rel & 3, lane = (rel >> 2) & 63, To = (rel >> 8) & 1, Tk = rel >> 9;
+                const int o = 16 * To + 4 * (lane >> 4) + r;
+                const int k = 16 * Tk + (lane & 15);
+                if (k < m.kcols) v = flat[m.off + o * m.stride + m.kbeg + k];
+            }
         }
     }
     packed[gidx] = v;
@@ -366,7 +390,8 @@ NSR_DEV void coord_grad(const GridDev &G, const Lvl &L, int g, const Act<2> &dc,
 // issuing ONE 32-lane atomic (two full 64-byte lines) per run of equal voxels.
 //   Tx  : [16][kTxS] floats  dc of the tile, point-major
 //   tab : [16][8] ints (corner voxel or -1) followed by [16][8] floats (corner weight)
-NSR_DEV void scatter_merged(const GridDev &G, const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab) {
+NSR_DEV void scatter_merged(const GridDev &G, const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab,
+                            unsigned salt = 0u) {       // salt != 0: measurement only (NSR_X & 8): spread the voxels, same request count
     const int pt = lane & 15, g = lane >> 4;
     int *vt = reinterpret_cast<int *>(tab);
     float *wt = tab + 128;
@@ -395,13 +420,13 @@ NSR_DEV void scatter_merged(const GridDev &G, const Lvl &L, int lane, const Act<
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             if (v[p] != cur) {
-                if (cur >= 0) atomic_add_global(G.dfeat + (long long)cur * kC + ch, acc);
+                if (cur >= 0) atomic_add_global(G.dfeat + (long long)(salt ? (int)(((unsigned)cur * 2654435761u + salt * 40503u + (unsigned)(p * 8 + k)) % (unsigned)(G.X * G.Y * G.Z)) : cur) * kC + ch, acc);
                 acc = 0.f;
                 cur = v[p];
             }
             acc = fmaf(x[p], w[p], acc);
         }
-        if (cur >= 0) atomic_add_global(G.dfeat + (long long)cur * kC + ch, acc);
+        if (cur >= 0) atomic_add_global(G.dfeat + (long long)(salt ? (int)(((unsigned)cur * 2654435761u + salt * 40503u + (unsigned)k) % (unsigned)(G.X * G.Y * G.Z)) : cur) * kC + ch, acc);
     }
     wave_fence();
 }
@@ -590,20 +615,24 @@ struct Kept {
 // Saved activations (288 GB of HBM buy the backward its forward re-run): per xyz decoder pass p (middle 0, fine 1, colour 2)
 // and sample point, the five hidden states h_i (what the next layer reads) and the five relu masks -- exactly the `Kept`
 // registers of the lane that computed them.  Slot j (16 bytes per lane) of lane (pt, g) working on global point gp:
-//     acts + (((p * kActSlots + j) * n_points_total + gp) * 4 + g) * 4          j = 2 i + T: h_i k-tile T;  j = 10: masks
-// i.e. a wave's 64 lanes write / read 1 KB contiguous per slot, whatever the tile / ray-group geometry of the kernel.
-constexpr int kActSlots = 11;
+//     acts + (((p * kActSlots + j) * n_points_total + gp) * 4 + g) * 4          j = 2 i + T: h_i k-tile T;  j = 10: masks;
+//                                                                               j = 11 + T: the decoder's own grid features c
+// i.e. a wave's 64 lanes write / read 1 KB contiguous per slot, whatever the tile / ray-group geometry of the kernel; a slot
+// is a row-major [n_points][16] matrix (16 consecutive channels of one activation), which is how the dW kernel (nsr_bwd2.h)
+// reads it.  The coarse decoder (MLP_no_xyz) uses pass 0 with the same slots.
+constexpr int kActSlots = 13;
+constexpr int kActMask = 10, kActC = 11;
 struct ActSink {
     float *p;                // slot 0 of this lane, NULL for a lane without a point
     long long stride;        // floats between two slots (n_points_total * 16)
 };
 NSR_DEV ActSink act_sink(const RenderParams &P, int pass, long long gp, int g) {
     ActSink a;
-    a.stride = P.n_points_total * 16;
+    a.stride = P.act_stride;
     a.p = (P.acts && gp >= 0) ? P.acts + (long long)pass * kActSlots * a.stride + (gp * 4 + g) * 4 : nullptr;
     return a;
 }
-NSR_DEV int act_pass(int kind) { return kind - NSR_MIDDLE; }
+NSR_DEV int act_pass(int kind) { return kind == NSR_COARSE ? 0 : kind - NSR_MIDDLE; }
 
 // MLP (decoder.py:177-203): h_i = relu(W_i x_i + b_i) + (U_i c + v_i), x_3 = [e | h_2]
 // `save` (forward kernel only): non-NULL = write h_i and the relu masks to the lane's activation slots
@@ -644,8 +673,11 @@ NSR_DEV void mlp_xyz_fwd(const float *pk, const float *aux, float px, float py, 
             if (i < 4) mpack0 |= m << (8 * i); else mpack1 = m;
         }
     }
-    if (SAVE && save->p)
-        st4(save->p + 10 * save->stride, F4{__builtin_bit_cast(float, mpack0), __builtin_bit_cast(float, mpack1), 0.f, 0.f});
+    if (SAVE && save->p) {
+        st4(save->p + kActMask * save->stride, F4{__builtin_bit_cast(float, mpack0), __builtin_bit_cast(float, mpack1), 0.f, 0.f});
+        st4(save->p + kActC * save->stride, to_F4(c.t[0]));
+        st4(save->p + (kActC + 1) * save->stride, to_F4(c.t[1]));
+    }
 #pragma unroll
     for (int n = 0; n < NOUT; ++n) {
         const F4 w0 = ld4(aux + AUX_WO + n * 32 + 4 * g), w1 = ld4(aux + AUX_WO + n * 32 + 16 + 4 * g);
@@ -678,10 +710,12 @@ NSR_DEV Act<2> load_hidden(const ActSink &a, int i) {
 }
 
 // MLP_no_xyz (decoder.py:262-274): h = c; h = relu(W_i h + b_i); after i == 2: h = [c | h]
-template <bool KEEP>
-NSR_DEV void mlp_nox_fwd(const float *pk, const float *aux, const Act<2> &c, int lane, float (&out)[1], Kept<0> *kept) {
+template <bool KEEP, bool SAVE = false>
+NSR_DEV void mlp_nox_fwd(const float *pk, const float *aux, const Act<2> &c, int lane, float (&out)[1], Kept<0> *kept,
+                         const ActSink *save = nullptr) {
     const int g = lane >> 4;
     Act<2> h = c;
+    unsigned mpack0 = 0, mpack1 = 0;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         f32x4 acc[2];
@@ -694,10 +728,19 @@ NSR_DEV void mlp_nox_fwd(const float *pk, const float *aux, const Act<2> &c, int
             gemv_fwd<2>(acc, h, pk + nox_mat(i == 0 ? NW0 : (i == 1 ? NW1 : (i == 2 ? NW2 : NW4))).pk, lane);
         }
         unsigned m = 0;
-        if (KEEP) m = relu_mask(acc); else relu_plain(acc);
+        if (KEEP || SAVE) m = relu_mask(acc); else relu_plain(acc);
         h.t[0] = acc[0];
         h.t[1] = acc[1];
         if (KEEP) { kept->h[i] = h; kept->mask[i] = m; }
+        if (SAVE) {
+            if (save->p) { st4(save->p + (2 * i) * save->stride, to_F4(h.t[0])); st4(save->p + (2 * i + 1) * save->stride, to_F4(h.t[1])); }
+            if (i < 4) mpack0 |= m << (8 * i); else mpack1 = m;
+        }
+    }
+    if (SAVE && save->p) {
+        st4(save->p + kActMask * save->stride, F4{__builtin_bit_cast(float, mpack0), __builtin_bit_cast(float, mpack1), 0.f, 0.f});
+        st4(save->p + kActC * save->stride, to_F4(c.t[0]));
+        st4(save->p + (kActC + 1) * save->stride, to_F4(c.t[1]));
     }
     const F4 w0 = ld4(aux + AUX_WO + 4 * g), w1 = ld4(aux + AUX_WO + 16 + 4 * g);
     float s = w0.x * h.t[0][0];
@@ -762,7 +805,8 @@ NSR_DEV F4 decode_tile_lds(const RenderParams &P, const float *aux, float *wl, d
         const Lvl L = make_level(P.grid[NSR_COARSE], px, py, pz);
         const Act<2> c = gather_feat(P.grid[NSR_COARSE], L, g);
         float o[1];
-        mlp_nox_fwd<false>(wl, aux, c, lane, o, nullptr);
+        const ActSink sc = act_sink(P, 0, gp, g);
+        mlp_nox_fwd<false, SAVE>(wl, aux, c, lane, o, nullptr, &sc);
         raw.w = o[0];
     } else {
         const float fx = (float)px, fy = (float)py, fz = (float)pz;     // decoder.py:189
@@ -1530,3 +1574,4 @@ NSR_KERNEL void camera_from_tensor_kernel(const CamParams P) {
 }  // namespace nsr
 
 #include "nsr_bwd.h"
+#include "nsr_bwd2.h"

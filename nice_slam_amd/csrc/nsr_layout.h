@@ -122,8 +122,33 @@ constexpr int AUX_WO = 320;    // wo[4][32]  output weights (rows >= nout are ze
 constexpr int AUX_BO = 448;    // bo[4]
 constexpr int AUX_BM = 452;    // Bm[24][4][4]  Fourier matrix: per group of 4 channels Bx[4] | By[4] | Bz[4] | 0
 constexpr int AUX_FLOATS = 452 + 96 * 4;   // 836
-// device buffer written by nsr_pack_params for one decoder: [aux table | packed operand stream]
-constexpr int packed_buf_total(int kind) { return AUX_FLOATS + packed_total(kind); }
+// ---- transposed operand stream (split backward, nsr_bwd2.h): dx = W^T dy -------------------------------------
+// For a [32][32 or 96] column slice W: T[((Tk * 2 + To) * 64 + lane) * 4 + r] = W[16 To + 4 (lane >> 4) + r][kbeg + 16 Tk + (lane & 15)]
+// (zero beyond kcols): one 16-byte LDS read per lane = the A operand (B operand in the "lane = channel" form) of four MFMA
+// k-steps.  xyz decoders: U0..U4 (first 32 feature columns only: the decoder's own grid; the middle features of the fine
+// decoder carry no gradient, decoder.py:185), W1, W2, W3h, W4, W0, W3e.  MLP_no_xyz: NW0..NW4 at their forward offsets.
+constexpr int xyzT_u(int i) { return i * 1024; }
+constexpr int xyzT_wh(int m) { return 5120 + m * 1024; }      // m: 0 W1, 1 W2, 2 W3h, 3 W4
+constexpr int xyzT_w0() { return 9216; }
+constexpr int xyzT_w3e() { return 12288; }
+constexpr int xyzT_total() { return 15360; }
+constexpr int packedT_total(int kind) { return kind == 0 ? nox_packed_total() : xyzT_total(); }
+// source slice of entry `id` of the transposed stream (xyz: 0..4 U_i, 5..8 W1 W2 W3h W4, 9 W0, 10 W3e) and its offset
+constexpr int xyzT_nmat() { return 11; }
+constexpr Mat xyzT_mat(int cd, int id) {
+    return id < 5 ? Mat{xyz_fcw(cd, id), cd, 0, 32, 2, xyzT_u(id)}
+         : id == 5 ? Mat{xyz_w(cd, 1), 32, 0, 32, 2, xyzT_wh(0)}
+         : id == 6 ? Mat{xyz_w(cd, 2), 32, 0, 32, 2, xyzT_wh(1)}
+         : id == 7 ? Mat{xyz_w(cd, 3), kE + 32, kE, 32, 2, xyzT_wh(2)}
+         : id == 8 ? Mat{xyz_w(cd, 4), 32, 0, 32, 2, xyzT_wh(3)}
+         : id == 9 ? Mat{xyz_w(cd, 0), kE, 0, kE, kET, xyzT_w0()}
+                   : Mat{xyz_w(cd, 3), kE + 32, 0, kE, kET, xyzT_w3e()};
+}
+constexpr int nmatT_of(int kind) { return kind == 0 ? (int)NNMAT : xyzT_nmat(); }
+constexpr Mat matT_of(int kind, int id) { return kind == 0 ? nox_mat(id) : xyzT_mat(cdim_of(kind), id); }
+
+// device buffer written by nsr_pack_params for one decoder: [aux table | forward operand stream | transposed stream]
+constexpr int packed_buf_total(int kind) { return AUX_FLOATS + packed_total(kind) + packedT_total(kind); }
 static_assert(AUX_FLOATS % 4 == 0, "the operand stream behind the aux table must stay 16-byte aligned");
 
 }  // namespace nsr

@@ -302,14 +302,13 @@ class Renderer(object):
             tmpl.t_surface[i] = v
         self._arg_template = bytes(tmpl)
         self.bwd_max_blocks = 0                 # 0 = library default persistent-grid cap
-        # Saved activations: the forward of a call that will be differentiated also writes the decoders' hidden states and
-        # relu masks (704 B per sample point and decoder: 101 MB per 1000 colour-stage rays) and the backward loads them
-        # instead of re-running the decoder forward.  Measured on MI355X: backward -9 % at 1000 rays with parameter gradients,
-        # -36 % for the tracker's 200 rays (only the masks are read there); the forward's extra stores cancel the gain from
-        # ~5000 rays on, so batches whose buffer would exceed `max_saved_activation_bytes` (256 MB = ~2500 colour-stage rays)
-        # keep the re-run.
+        # Saved activations: the forward of a call that will be differentiated also writes the decoders' hidden states, relu
+        # masks and grid features (832 B per sample point and decoder) and the backward runs as the split dX / dW kernels over
+        # them (csrc/nsr_bwd2.h; +640 B per point and decoder of dY scratch in the same buffer: 212 MB per 1000 colour-stage
+        # rays) instead of the re-run kernel (csrc/nsr_bwd.h), which holds every parameter-gradient accumulator in one wave.
+        # Batches whose buffer would exceed `max_saved_activation_bytes` keep the re-run kernel (24 B per point of saved state).
         self.save_activations = True
-        self.max_saved_activation_bytes = 256 << 20
+        self.max_saved_activation_bytes = 64 << 30
         # Optional: restrict parameter gradients to these decoders, e.g. ("color",).  The reference's autograd
         # produces dW for every decoder in every stage although src/Mapper.py:335-341 only ever steps the colour
         # decoder (and the fine one when fix_fine is False); None = reference semantics (requires_grad decides).
@@ -373,7 +372,7 @@ class Renderer(object):
 
     def _attach_acts(self, a, stage, n, S, dev):
         """allocate the activation buffer of a differentiable forward and point the argument block at it (None: re-run)"""
-        if not self.save_activations or stage == "coarse":
+        if not self.save_activations:
             return None
         nfl = _capi.get_lib().nsr_acts_floats(_capi.STAGE_ID[stage], n, S)
         if nfl <= 0 or 4 * nfl > self.max_saved_activation_bytes:

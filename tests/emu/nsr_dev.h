@@ -166,6 +166,8 @@ NSR_DEV void loop_fence() {}
 NSR_DEV void block_sync() { emu::block_sync_impl(); }
 
 NSR_DEV void prefetch_line(const float *, float *) {}
+NSR_DEV void dma16(const float *gsrc, float *lds_base, int lane) { std::memcpy(lds_base + lane * 4, gsrc, 16); }
+template <int N> NSR_DEV void dma_wait() {}
 NSR_DEV void atomic_add_global(float *p, float v) {
     // blocks may run on different OS threads: real atomic read-modify-write
     uint32_t *u = reinterpret_cast<uint32_t *>(p);

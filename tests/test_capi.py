@@ -35,17 +35,20 @@ def test_header_symbols_are_bound_and_exported(lib):
 
 def test_sizes_and_error_reporting(lib):
     from nice_slam_amd.layout import param_count
-    assert lib.nsr_version() == 3
-    # activation slots: passes x 11 slots x points x 16 floats (0 for the coarse stage)
-    assert lib.nsr_acts_floats(0, 1000, 32) == 0 and lib.nsr_acts_floats(3, 1000, 48) == 3 * 11 * 48000 * 16
-    assert lib.nsr_acts_floats(1, 7, 48) == 11 * 7 * 48 * 16 and lib.nsr_acts_floats(4, 7, 48) == -1
+    assert lib.nsr_version() == 4
+    # [passes][13 + 10 slots][points padded to 16][16] + d raw [.][4] + positions [.][4] doubles
+    assert lib.nsr_acts_floats(0, 1000, 32) == 23 * 32000 * 16 + 32000 * 12
+    assert lib.nsr_acts_floats(3, 1000, 48) == 3 * 23 * 48000 * 16 + 48000 * 12
+    assert lib.nsr_acts_floats(1, 7, 47) == 23 * 336 * 16 + 336 * 12 and lib.nsr_acts_floats(4, 7, 48) == -1
     assert [lib.nsr_param_count(i) for i in range(4)] == [param_count(s) for s in ("coarse", "middle", "fine", "color")] \
         == [6337, 15800, 20920, 15899]
-    assert [lib.nsr_packed_count(i) for i in range(4)] == [836 + 6144, 836 + 15360, 836 + 20480, 836 + 15360]    # [aux table | operand stream]
+    # [aux table | forward operand stream | transposed stream of the split backward]
+    assert [lib.nsr_packed_count(i) for i in range(4)] == [836 + 6144 + 6144, 836 + 15360 + 15360, 836 + 20480 + 15360, 836 + 15360 + 15360]
     assert lib.nsr_param_count(7) == -1
     # color stage, 1000 rays, S=48: 3 passes x min(groups, cap) blocks x the largest decoder blob
     assert lib.nsr_bwd_workspace_floats(3, 1000, 48, 7) == 3 * 7 * 20920
-    assert lib.nsr_bwd_workspace_floats(0, 1000, 32, 5) == 1 * 5 * 6337
+    # split backward (saved activations): per pass `cap / passes` partial images + as many d _B partials of 288 floats
+    assert lib.nsr_bwd_workspace_floats(0, 1000, 32, 5) == 1 * 5 * (6337 + 288)
     # argument validation happens before any device work
     assert lib.nsr_pack_params(9, None, None, None) != 0
     assert b"slot" in lib.nsr_last_error()
@@ -100,9 +103,10 @@ def test_ctypes_struct_fields_follow_the_header():
 
 
 def test_kernel_register_budget():
-    """The backward kernels hold every parameter-gradient accumulator in registers (one wave per SIMD, 256 VGPR + 256 AGPR);
-    the build records what the compiler made of it.  A change that tips them into heavy scratch use is a 1.5x slowdown that
-    no numerical test notices -- it shows up here."""
+    """The build records what the compiler made of every kernel.  The split backward (csrc/nsr_bwd2.h) exists to get out of
+    the one-wave-per-SIMD corner of the re-run kernel: its dX kernels must keep a forward-like budget (>= 3 waves/SIMD) and
+    the dW kernels stay small (>= 4 waves/SIMD, no scratch).  A change that tips one of them over is a slowdown no
+    numerical test notices -- it shows up here."""
     import json
     import os
     from nice_slam_amd import build
@@ -110,9 +114,15 @@ def test_kernel_register_budget():
         pytest.skip("libnsr.resources.json not present (library built by an older build.py)")
     res = json.load(open(build.RESOURCES))
     bwd = {k: v for k, v in res.items() if "render_bwd_kernel" in k}
+    dx = {k: v for k, v in res.items() if "render_bwd_dx_kernel" in k}
+    dw = {k: v for k, v in res.items() if "render_bwd_dw_kernel" in k}
     fwd = {k: v for k, v in res.items() if "render_fwd_kernel" in k or "eval_points_kernel" in k}
-    assert len(bwd) == 7 and len(fwd) == 11              # 4 stages + 3 saved-activation variants each; eval_points: 4
-    for k, v in bwd.items():
+    assert len(bwd) == 4 and len(dx) == 8 and len(dw) == 4 and len(fwd) == 12     # fwd: 4 stages x {plain, saving} + eval_points: 4
+    for k, v in bwd.items():                  # the re-run kernel (no saved activations): one wave per SIMD, bounded scratch
         assert v["occupancy_waves_per_simd"] == 1 and v["scratch_bytes_per_lane"] <= 1024, (k, v)
+    for k, v in dx.items():
+        assert v["occupancy_waves_per_simd"] >= 3 and v["scratch_bytes_per_lane"] <= 192, (k, v)
+    for k, v in dw.items():
+        assert v["occupancy_waves_per_simd"] >= 4 and v["scratch_bytes_per_lane"] == 0, (k, v)
     for k, v in fwd.items():
         assert v["occupancy_waves_per_simd"] >= 3 and v["scratch_bytes_per_lane"] <= 64, (k, v)

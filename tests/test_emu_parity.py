@@ -590,11 +590,11 @@ def test_full_size_forward_blocks_in_a_subprocess():
     assert " passed" in r.stdout
 
 
-@pytest.mark.parametrize("stage", ["middle", "fine", "color"])
+@pytest.mark.parametrize("stage", ["coarse", "middle", "fine", "color"])
 def test_saved_activations_equal_the_forward_rerun(emu, stage):
-    """nsr_render_args.acts: the forward writes every decoder's hidden states + relu masks, the backward loads them instead
-    of re-running the decoder -- same numbers as the re-run path (the loaded values ARE the re-run's values; only the
-    order of the unordered gradient atomics may differ), ragged ray count, two-block persistent grid."""
+    """nsr_render_args.acts: the forward writes every decoder's hidden states, relu masks and grid features, and the backward
+    runs as the split dX / dW kernels over them (nsr_bwd2.h) instead of the re-run kernel (nsr_bwd.h) -- same gradients up
+    to summation order (the fc_c weights come out as W^T G), ragged ray count (a partial last tile), small persistent grid."""
     s = make_scene(seed=120, n_rays=29, small=True)
     res = {}
     for mode in (True, False):
@@ -603,8 +603,12 @@ def test_saved_activations_equal_the_forward_rerun(emu, stage):
         fwd = sc.forward(stage, s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy())
         assert ("acts" in fwd) == mode
         if mode:
-            slots = fwd["acts"].reshape(-1, 11, fwd["raw"].shape[0] * fwd["raw"].shape[1] * 16)   # [pass][slot][point, lane group, 4]
-            assert not np.isnan(slots[:, :10]).any()            # every hidden-state slot of every point was written (slot 10: mask bits)
+            npts = fwd["raw"].shape[0] * fwd["raw"].shape[1]
+            npad = (npts + 15) // 16 * 16
+            passes = max(1, ["coarse", "middle", "fine", "color"].index(stage))
+            slots = fwd["acts"][:passes * 13 * npad * 16].reshape(passes, 13, npad, 16)   # [pass][slot][point][lane group, 4]
+            assert not np.isnan(slots[:, :10, :npts]).any()     # every hidden-state slot of every point was written (slot 10: mask bits)
+            assert not np.isnan(slots[:, 11:, :npts]).any()     # ... and its grid features
         res[mode] = (fwd, sc.backward(stage, fwd, s["w"]["depth"].numpy(), s["w"]["var"].numpy(), s["w"]["rgb"].numpy(), max_blocks=2))
     for k in ("depth", "var", "rgb", "raw"):
         assert np.array_equal(res[True][0][k], res[False][0][k]), k
