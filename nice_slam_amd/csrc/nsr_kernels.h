@@ -263,6 +263,7 @@ struct Lvl {
     float fx, fy, fz;   // weight of the +1 neighbour
     float gx, gy, gz;   // weight of the base corner ((i0+1) - u, the ATen form)
     float mx, my, mz;   // d u / d g_normalised, 0 when the coordinate was clipped
+    int par;            // parity of the base corner's voxel coordinates: (x0 & 1) | (y0 & 1) << 1 | (z0 & 1) << 2
 };
 
 // a / b for a divisor whose correctly rounded reciprocal `rb` is known: one residual correction gives the correctly
@@ -295,6 +296,7 @@ NSR_DEV Lvl make_level(const GridDev &G, double px, double py, double pz) {
     axis_setup(py, G.lo[1], G.ext[1], G.inv[1], G.Y, y0, L.gy, L.fy, L.my);
     axis_setup(pz, G.lo[2], G.ext[2], G.inv[2], G.Z, z0, L.gz, L.fz, L.mz);
     L.vox = (z0 * G.Y + y0) * G.X + x0;
+    L.par = (x0 & 1) | ((y0 & 1) << 1) | ((z0 & 1) << 2);
     L.sx = G.X > 1 ? 1 : 0;
     L.sy = G.Y > 1 ? G.X : 0;
     L.sz = G.Z > 1 ? G.X * G.Y : 0;
@@ -385,11 +387,15 @@ NSR_DEV void coord_grad(const GridDev &G, const Lvl &L, int g, const Act<2> &dc,
 // Measured on MI355X (tools/atomic_probe.hip): a global f32 atomic costs one request per touched 64-byte
 // line (~21 G lines/s chip-wide) no matter how many of its 16 dwords an instruction updates, and lanes of
 // one instruction that hit the SAME dword serialise.  So the tile is re-laid out through LDS to
-// "lane = channel": each half-wave owns one corner index k and walks the tile's 16 points (consecutive
-// samples of a ray, i.e. spatially sorted), summing weighted dc while the corner voxel stays the same and
-// issuing ONE 32-lane atomic (two full 64-byte lines) per run of equal voxels.
+// "lane = channel": each half-wave owns one PARITY CLASS of voxels ((x & 1) | (y & 1) << 1 | (z & 1) << 2: the eight corners
+// of a cell fall into the eight classes, corner k into class k ^ parity(base corner)) and walks the tile's 16 points
+// (consecutive samples of a ray, i.e. spatially sorted), summing weighted dc while the class's voxel stays the same and
+// issuing ONE 32-lane atomic (two full 64-byte lines) per run of equal voxels.  A voxel keeps its class from cell to cell, so
+// the corners two consecutive cells share (4 of 8 when the ray steps one cell along one axis) meet in the same walk and
+// merge -- walking by corner INDEX, as the first two generations did, only merged samples inside one cell (613 k instead
+// of 396 k voxel updates per 1000 colour-stage rays of the bench scene).
 //   Tx  : [16][kTxS] floats  dc of the tile, point-major
-//   tab : [16][8] ints (corner voxel or -1) followed by [16][8] floats (corner weight)
+//   tab : [16][8] ints (voxel of the class or -1) followed by [16][8] floats (its weight)
 NSR_DEV void scatter_merged(const GridDev &G, const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab,
                             unsigned salt = 0u) {       // salt != 0: measurement only (NSR_X & 8): spread the voxels, same request count
     const int pt = lane & 15, g = lane >> 4;
@@ -398,9 +404,9 @@ NSR_DEV void scatter_merged(const GridDev &G, const Lvl &L, int lane, const Act<
     tx_store(Tx, dc, pt, g);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        const int k = 2 * g + c;
-        vt[pt * 8 + k] = active ? corner_vox(L, k) : -1;
-        wt[pt * 8 + k] = corner_w(L, k);
+        const int k = 2 * g + c, cls = k ^ L.par;
+        vt[pt * 8 + cls] = active ? corner_vox(L, k) : -1;
+        wt[pt * 8 + cls] = corner_w(L, k);
     }
     wave_fence();
     const int h = lane >> 5, ch = lane & 31;
