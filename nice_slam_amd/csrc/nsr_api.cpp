@@ -59,12 +59,12 @@ int bwd_blocks(long long n_groups, int max_blocks) {
 int bwd_passes(int stage) { return stage == NSR_STAGE_COARSE ? 1 : stage; }     // middle 1, fine 2, colour 3
 
 // ---- split backward over saved activations (nsr_bwd2.h) -----------------------------------------------------------------
-// layout of nsr_render_args.acts (floats): [passes][kActSlots][npad][16] saved by the forward | [passes][kDySlots][npad][16]
-// dY (dX kernel -> dW kernel) | [npad][4] d raw | [npad][4] doubles: sample position + depth.  npad = the sample points
-// rounded up to whole 16-point tiles, so that every tile of every slot is 1 KB inside its own slot (DMA pieces).
+// layout of nsr_render_args.acts (floats): [passes][tiles][kActSlots][16][16] saved by the forward | [passes][tiles][kDySlots]
+// [16][16] dY (dX kernel -> dW kernel) | [npad][4] d raw | [npad][4] fp32 positions | [npad][4] doubles: position + depth.  npad = 16 * tiles = the
+// sample points rounded up to whole 16-point tiles (DMA pieces of 1 KB).
 struct SplitLayout {
     long long npts, npad, stride;      // stride: floats between two slots
-    long long o_dy, o_draw, o_pd, total;
+    long long o_dy, o_draw, o_pf, o_pd, total;
 };
 SplitLayout split_layout(int stage, long long n_rays, int S) {
     SplitLayout L;
@@ -74,7 +74,8 @@ SplitLayout split_layout(int stage, long long n_rays, int S) {
     L.stride = L.npad * 16;
     L.o_dy = (long long)passes * nsr::kActSlots * L.stride;
     L.o_draw = L.o_dy + (long long)passes * nsr::kDySlots * L.stride;
-    L.o_pd = L.o_draw + L.npad * 4;
+    L.o_pf = L.o_draw + L.npad * 4;
+    L.o_pd = L.o_pf + L.npad * 4;
     L.total = L.o_pd + L.npad * 8;
     return L;
 }
@@ -140,7 +141,7 @@ int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays,
     P.rays_d = a->rays_d;
     P.acts = a->acts;
     P.n_points_total = (long long)P.n_rays * P.S;
-    P.act_stride = split_layout(P.stage, P.n_rays, P.S).stride;
+    P.act_tiles = split_layout(P.stage, P.n_rays, P.S).npad / nsr::kTile;
     P.gt_depth = guided ? a->gt_depth : nullptr;
     P.gt_max = a->gt_max;
     for (int i = 0; i < 3; ++i) { P.blo[i] = a->bound_lo[i]; P.bhi[i] = a->bound_hi[i]; }
@@ -221,6 +222,7 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
     const int passes = bwd_passes(P.stage);
     P.dy = P.acts + L.o_dy;
     P.draw = P.acts + L.o_draw;
+    P.pf = P.acts + L.o_pf;
     P.pd = reinterpret_cast<double *>(P.acts + L.o_pd);
     P.dw_blocks = G.nimg;
     static const int xflags = env_int("NSR_X", 0);
@@ -257,7 +259,7 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
 #undef NSR_DX
     }
     if (any_params) {
-        const int lds = nsr::dw_lds_floats(P.stage >= NSR_STAGE_FINE ? NSR_FINE : NSR_MIDDLE) * 4;
+        const int lds = nsr::dw_lds_bytes(P.stage >= NSR_STAGE_FINE ? NSR_FINE : NSR_MIDDLE);
         const dim3 grid(G.nimg, passes), block(64 * nsr::kDwWaves);
 #define NSR_DW(ST)                                                                                  \
     if (int rc = launch_cfg(nsr::render_bwd_dw_kernel<ST>, lds, "nsr_render_bwd(dw)")) return rc;   \
@@ -282,7 +284,7 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
             J.params = P.dec[s].params; J.dparams = P.dec[s].dparams;
             J.kind = s; J.nimg = G.nimg; J.ndx = G.nb;
             const int dbeg = s == NSR_COARSE ? 0 : nsr::xyz_w(nsr::cdim_of(s), 0);
-            const int nb = (nsr::param_total(s) - dbeg + 63) / 64 + 5 + (s == NSR_COARSE ? 0 : 5 * nsr::cdim_of(s) / 8);
+            const int nb = (nsr::param_total(s) - dbeg + 63) / 64 + 5 + (s == NSR_COARSE ? 0 : 5 * nsr::cdim_of(s) / 4);
             nblocks = nb > nblocks ? nb : nblocks;
         }
         for (int r = rows; r < 3; ++r) R.job[r] = nsr::FinalJob{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
@@ -384,15 +386,15 @@ int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream
     const int waves = kBwdWaves;
     const int lds = bwd_lds_bytes(P.stage, npts, P.rays_per_block, waves);
     const dim3 grid(nblk, passes), block(64 * waves);
-#define NSR_BWD(ST, SV)                                                                               \
-    if (int rc = launch_cfg(nsr::render_bwd_kernel<ST, SV>, lds, "nsr_render_bwd")) return rc;         \
-    NSR_LAUNCH((nsr::render_bwd_kernel<ST, SV>), grid, block, lds, stream, P);
+#define NSR_BWD(ST)                                                                               \
+    if (int rc = launch_cfg(nsr::render_bwd_kernel<ST>, lds, "nsr_render_bwd")) return rc;         \
+    NSR_LAUNCH((nsr::render_bwd_kernel<ST>), grid, block, lds, stream, P);
     if (b->ev_start) nsr::rt_record(b->ev_start, stream);
     switch (P.stage) {
-        case 0: NSR_BWD(0, false) break;
-        case 1: NSR_BWD(1, false) break;
-        case 2: NSR_BWD(2, false) break;
-        default: NSR_BWD(3, false) break;
+        case 0: NSR_BWD(0) break;
+        case 1: NSR_BWD(1) break;
+        case 2: NSR_BWD(2) break;
+        default: NSR_BWD(3) break;
     }
 #undef NSR_BWD
     if (b->ev_stop) nsr::rt_record(b->ev_stop, stream);

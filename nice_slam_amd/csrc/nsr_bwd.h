@@ -283,15 +283,14 @@ NSR_DEV void flush_acc(ACC &A, float *wl, const float *aux, float *scratch, floa
 // ------------------------------------------------------------------------------------------------
 // xyz decoder, one tile
 // ------------------------------------------------------------------------------------------------
-template <int KIND, bool PARAMS, bool SAVED>
+template <int KIND, bool PARAMS>
 struct XyzTile {
     static constexpr int CD = cdim_of(KIND), NTC = CD / 16;
     const float *wl;     // packed operand stream of this decoder (LDS)
     const float *aux;
     float *S;            // this wave's staging region
     XyzAcc<CD> &A;
-    const Kept<KIND> &K; // SAVED: only the masks are filled; hidden states come from `acts` one at a time
-    const ActSink &acts;
+    const Kept<KIND> &K;
     BwdFlags F;
     int lane;
     Act<2> &dc;
@@ -316,7 +315,7 @@ struct XyzTile {
         if (I == 0) dY0 = dY;
         if (PARAMS) {
             st_store(S + kStA1, dY, i16, g);
-            if (I > 0) st_store(S + kStX0, SAVED ? load_hidden(acts, I > 0 ? I - 1 : 0) : K.h[I > 0 ? I - 1 : 0], i16, g);
+            if (I > 0) st_store(S + kStX0, K.h[I > 0 ? I - 1 : 0], i16, g);
             else st_store(S + kStX0, dY3, i16, g);                           // layer 0: the W0 / W3e blocks need dY3 too
             if (kOwn) block_sync(); else wave_fence();                       // owner-computed dU: every wave's dH tile is staged
             const f32x4 y0 = st_load_cm(S + kStA1, 0, i16, g), y1 = st_load_cm(S + kStA1, 1, i16, g);
@@ -381,17 +380,15 @@ struct XyzTile {
 // With owner_du(KIND) && PARAMS every wave of the block must call this function (one block barrier per layer).
 // `mid`: called once the hidden-state chain is done (before the embedding stage); the pass issues the NEXT tile's feature
 // gather there, so that its latency hides behind the embedding stage.
-template <int KIND, bool PARAMS, bool SAVED, class Mid>
+template <int KIND, bool PARAMS, class Mid>
 NSR_DEV void xyz_bwd_tile(const float *pk, const float *aux, float *S, XyzAcc<cdim_of(KIND)> &A,
                           float px, float py, float pz, const Act<cdim_of(KIND) / 16> &c,
                           const F4 dr, BwdFlags F, int lane, Act<2> &dc, float (&dp)[3], const Dbg dbg, int ts, Mid &&mid,
-                          const float *stg, int wave, const ActSink &acts) {
+                          const float *stg, int wave) {
     constexpr int CD = cdim_of(KIND), NOUT = nout_of(KIND), NTC = CD / 16;
     const int i16 = lane & 15, g = lane >> 4;
     Kept<KIND> K;
-    if (SAVED) {                                                 // the forward kept the hidden states and relu masks of this point
-        load_masks<KIND>(K, acts);
-    } else {
+    {
         float out[NOUT];
         mlp_xyz_fwd<KIND, true>(pk, aux, px, py, pz, c, lane, out, &K);
         (void)out;
@@ -428,7 +425,7 @@ NSR_DEV void xyz_bwd_tile(const float *pk, const float *aux, float *S, XyzAcc<cd
             cq.t[0] = c.t[2 * q]; cq.t[1] = c.t[2 * q + 1];
             st_store(S + kStC + q * 512, cq, i16, g);
         }
-        st_store(S + kStX0, SAVED ? load_hidden(acts, 4) : K.h[4], i16, g);
+        st_store(S + kStX0, K.h[4], i16, g);
         wave_fence();
         const f32x4 h0 = st_load_cm(S + kStX0, 0, i16, g), h1 = st_load_cm(S + kStX0, 1, i16, g);
 #pragma unroll
@@ -444,7 +441,7 @@ NSR_DEV void xyz_bwd_tile(const float *pk, const float *aux, float *S, XyzAcc<cd
 
     act_zero(dc);
     dbg.stamp(ts + 2);
-    XyzTile<KIND, PARAMS, SAVED> X{pk, aux, S, A, K, acts, F, lane, dc, dh, stg, wave};
+    XyzTile<KIND, PARAMS> X{pk, aux, S, A, K, F, lane, dc, dh, stg, wave};
     act_zero(X.dY3);
     act_zero(X.dY0);
     X.template layer<4>(); dbg.stamp(ts + 3);
@@ -615,7 +612,7 @@ struct TileCtx {
     Lvl L;
 };
 
-template <int KIND, bool PARAMS, bool SAVED>
+template <int KIND, bool PARAMS>
 NSR_DEV void bwd_pass(const RenderParams &P) {
     char *lds = lds_base();
     const int npts = P.rays_per_block * P.S, S = P.S;
@@ -727,14 +724,6 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
             const Lvl Lm = setup(cur, wave);
             if (KIND == NSR_FINE) { gather_issue(raw, P.grid[NSR_MIDDLE], Lm, g); cm = gather_finish(raw, Lm); }
             gather_issue(raw, G, cur.L, g);
-            if constexpr (KIND != NSR_COARSE) {
-                if (SAVED && cur.active) {                       // first tile's saved activations towards the L2 (see `mid` below)
-                    const ActSink a0 = act_sink(P, act_pass(KIND), ray0 * S + cur.pidx, g);
-                    float *sink = reinterpret_cast<float *>(ztmp);
-#pragma unroll
-                    for (int j = PARAMS ? 0 : 10; j < kActSlots; ++j) prefetch_line(a0.p + j * a0.stride, sink);
-                }
-            }
         }
         // ---- compositor backward: d raw per sample (common.py:231-244 differentiated), one wave per ray
         for (int r = wave; r < P.rays_per_block; r += nwaves) {
@@ -811,14 +800,6 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
                     Lm_next = setup(nx, tile + nwaves);
                     touch(G, nx.L);
                     if constexpr (KIND == NSR_FINE) touch(P.grid[NSR_MIDDLE], Lm_next);
-                    if constexpr (KIND != NSR_COARSE) {
-                        if (SAVED && nx.active) {                 // the next tile's saved activations: masks (+ hidden states for dW)
-                            const ActSink an = act_sink(P, act_pass(KIND), ray0 * S + nx.pidx, g);
-                            float *sink = reinterpret_cast<float *>(ztmp);
-#pragma unroll
-                            for (int j = PARAMS ? 0 : 10; j < kActSlots; ++j) prefetch_line(an.p + j * an.stride, sink);
-                        }
-                    }
                 }
             };
             F4 dr = cur.active ? draw[cur.pidx] : F4{0.f, 0.f, 0.f, 0.f};
@@ -830,11 +811,9 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
             } else if constexpr (KIND == NSR_FINE) {
                 Act<4> cc;
                 cc.t[0] = c.t[0]; cc.t[1] = c.t[1]; cc.t[2] = cm.t[0]; cc.t[3] = cm.t[1];
-                const ActSink as = act_sink(P, act_pass(KIND), cur.active ? ray0 * S + cur.pidx : -1, g);
-                xyz_bwd_tile<NSR_FINE, PARAMS, SAVED>(wl, aux, Sw, A, cur.px, cur.py, cur.pz, cc, dr, F, lane, dc, dpe, dbg, ts, mid, stg, wave, as);
+                xyz_bwd_tile<NSR_FINE, PARAMS>(wl, aux, Sw, A, cur.px, cur.py, cur.pz, cc, dr, F, lane, dc, dpe, dbg, ts, mid, stg, wave);
             } else {
-                const ActSink as = act_sink(P, act_pass(KIND), cur.active ? ray0 * S + cur.pidx : -1, g);
-                xyz_bwd_tile<KIND, PARAMS, SAVED>(wl, aux, Sw, A, cur.px, cur.py, cur.pz, c, dr, F, lane, dc, dpe, dbg, ts, mid, stg, wave, as);
+                xyz_bwd_tile<KIND, PARAMS>(wl, aux, Sw, A, cur.px, cur.py, cur.pz, c, dr, F, lane, dc, dpe, dbg, ts, mid, stg, wave);
             }
             // every load of the next tile is consumed before this tile's atomics are issued (see the header)
             Act<2> c_next, cm_next;
@@ -896,20 +875,20 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
 }
 
 // grid = (blocks per pass, decoder passes of the stage): block (x, p) takes the ray groups x, x + gridDim.x, ... of pass p.
-// SAVED: the variant that loads the activations the forward saved (RenderParams.acts) instead of re-running the decoder --
-// a kernel of its own: both variants inside one kernel cost the re-run path 30 % (register allocation over the union).
-template <int STAGE, bool SAVED = false>
+// This is the backward of calls WITHOUT an activation buffer (nsr_render_args.acts == NULL): it re-runs the decoder it
+// differentiates.  With saved activations the split kernels of nsr_bwd2.h run instead.
+template <int STAGE>
 NSR_KERNEL NSR_BOUNDS(64 * kBwdWaves) void render_bwd_kernel(const RenderParams P) {
     if (STAGE == NSR_STAGE_COARSE) {
-        if (P.dec[NSR_COARSE].dparams) bwd_pass<NSR_COARSE, true, false>(P); else bwd_pass<NSR_COARSE, false, false>(P);
+        if (P.dec[NSR_COARSE].dparams) bwd_pass<NSR_COARSE, true>(P); else bwd_pass<NSR_COARSE, false>(P);
     } else {
         const int pass = bid_y();
         if (pass == 0) {
-            if (P.dec[NSR_MIDDLE].dparams) bwd_pass<NSR_MIDDLE, true, SAVED>(P); else bwd_pass<NSR_MIDDLE, false, SAVED>(P);
+            if (P.dec[NSR_MIDDLE].dparams) bwd_pass<NSR_MIDDLE, true>(P); else bwd_pass<NSR_MIDDLE, false>(P);
         } else if (pass == 1) {
-            if (STAGE >= NSR_STAGE_FINE) { if (P.dec[NSR_FINE].dparams) bwd_pass<NSR_FINE, true, SAVED>(P); else bwd_pass<NSR_FINE, false, SAVED>(P); }
+            if (STAGE >= NSR_STAGE_FINE) { if (P.dec[NSR_FINE].dparams) bwd_pass<NSR_FINE, true>(P); else bwd_pass<NSR_FINE, false>(P); }
         } else {
-            if (STAGE == NSR_STAGE_COLOR) { if (P.dec[NSR_COLOR].dparams) bwd_pass<NSR_COLOR, true, SAVED>(P); else bwd_pass<NSR_COLOR, false, SAVED>(P); }
+            if (STAGE == NSR_STAGE_COLOR) { if (P.dec[NSR_COLOR].dparams) bwd_pass<NSR_COLOR, true>(P); else bwd_pass<NSR_COLOR, false>(P); }
         }
     }
 }

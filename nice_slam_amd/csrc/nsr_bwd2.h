@@ -11,10 +11,12 @@
 //                          W^T operands come from a second, transposed operand stream (nsr_layout.h) so that one conflict-free
 //                          16-byte LDS read feeds four MFMAs (the second generation read W^T through scalar LDS reads with
 //                          4-way bank conflicts).
-//   render_bwd_dw_kernel   "dW": split-K GEMM over the sample points, dW_i = sum_p dY_i[p]^T x_i[p].  A block streams 16-point
-//                          tiles of every operand (dY_i, h_i, c, positions, d raw) through a three-slot LDS ring with
-//                          global->LDS DMA (no staging registers), its 8 waves own disjoint 16x16 output tiles (<= 12 each), so
-//                          there is no cross-wave reduction; one partial image of the flat gradient blob per block.
+//   render_bwd_dw_kernel   "dW": split-K GEMM over the sample points, dW_i = sum_p dY_i[p]^T x_i[p].  Two loader waves per
+//                          block stream 16-point tiles of every operand (dY_i, h_i, c, positions, d raw) through a six-slot LDS
+//                          ring with global->LDS DMA (no staging registers); the slot layout of the saved activations IS the
+//                          MFMA operand layout of a contraction over points; 8 compute waves own disjoint 16x16 output tiles
+//                          (<= 10 each) and run free of barriers (LDS flag words), so there is no cross-wave reduction;
+//                          one partial image of the flat gradient blob per block.
 //                          The fc_c weights are not contracted directly: dH_i = W_{i+1}^T dY_{i+1}, hence
 //                          dU_i = W_{i+1}^T (sum_p dY_{i+1}[p]^T c[p]) =: W_{i+1}^T G_{i+1}  (and dv_i = W_{i+1}^T db_{i+1}):
 //                          the kernel accumulates G_j (stored in the image where dU_{j-1} lives), the finalize kernel applies
@@ -74,6 +76,7 @@ NSR_KERNEL void comp_bwd_kernel(const RenderParams P) {
         st4(P.draw + gp * 4, F4{cw.w * gr, cw.w * gg, cw.w * gb, docc});
         double *q = P.pd + gp * 4;
         q[0] = px; q[1] = py; q[2] = pz; q[3] = z;
+        st4(P.pf + gp * 4, F4{(float)px, (float)py, (float)pz, 0.f});       // float32(p): what the embedding sees (decoder.py:189)
     }
 }
 
@@ -112,7 +115,7 @@ NSR_DEV DxIn dx_load(const RenderParams &P, const float *acts_pass, long long ti
     const double *pp = P.pd + q * 4;
     I.px = pp[0]; I.py = pp[1]; I.pz = pp[2]; I.z = pp[3];
     I.dr = ld4(P.draw + q * 4);
-    const float *mp = acts_pass + kActMask * P.act_stride + (q * 4 + g) * 4;
+    const float *mp = acts_pass + ((q >> 4) * kActSlots + kActMask) * 256 + ((q & 15) * 4 + g) * 4;
     I.m0 = __builtin_bit_cast(unsigned, mp[0]);
     I.m1 = __builtin_bit_cast(unsigned, mp[1]);
     if (!I.act) { I.dr = F4{0.f, 0.f, 0.f, 0.f}; I.m0 = 0u; I.m1 = 0u; }
@@ -141,9 +144,9 @@ NSR_DEV void dx_pass(const RenderParams &P) {
     copy_f4<packedT_total(KIND) / 4>(wt, D.packed + AUX_FLOATS + packed_total(KIND));
     block_sync();
 
-    const long long sstride = P.act_stride;
-    const float *acts_pass = P.acts + (long long)act_pass(KIND) * kActSlots * sstride;
-    float *dys = P.dy + (long long)act_pass(KIND) * kDySlots * sstride;
+    constexpr long long sstride = 256;                       // floats between two slots of a tile
+    const float *acts_pass = P.acts + (long long)act_pass(KIND) * P.act_tiles * kActSlots * 256;
+    float *dys = P.dy + (long long)act_pass(KIND) * P.act_tiles * kDySlots * 256;
     const long long ntiles = (P.n_points_total + kTile - 1) / kTile;
     const long long tstep = (long long)nblk_x() * nw;
     const bool need_dc = do_grid || RAYS;
@@ -186,7 +189,7 @@ NSR_DEV void dx_pass(const RenderParams &P) {
         }
         Act<2> dc, dY0, dY3;
         act_zero(dc); act_zero(dY0); act_zero(dY3);
-        float *dyp = dys + (gp * 4 + g) * 4;
+        float *dyp = dys + tile * (kDySlots * 256) + (pt * 4 + g) * 4;
 #pragma unroll
         for (int I = 4; I >= 0; --I) {
             if (XYZ && need_dc) gemv_t<2>(dc.t, dh, wt + xyzT_u(I), lane);         // gradient of (U_i c + v_i) is dh itself
@@ -350,56 +353,76 @@ NSR_KERNEL NSR_BOUNDS(64 * kDxMaxWaves) void render_bwd_dx_kernel(const RenderPa
 }
 
 // ------------------------------------------------------------------------------------------------
-// dW kernel: split-K GEMM over the sample points through an LDS ring
+// dW kernel: split-K GEMM over the sample points; loader waves stream the operands through an LDS ring, compute waves run free
 // ------------------------------------------------------------------------------------------------
-constexpr int kDwWaves = 8, kDwRing = 3;
+// A slot tile is a row-major [16 points][16 channels] matrix (1 KB): lane (i = channel, g) reads the dwords q * 64 + lane,
+// q = 0..3, i.e. X[point 4 q + g][channel i] -- the "lane = channel" operand form of a contraction over points, conflict-free
+// in LDS, no transposition anywhere.  Block = 8 compute waves, which own disjoint output tiles (roles below), + 2 loader
+// waves, which copy the 16-point tiles of the block with global -> LDS DMA into a ring of kDwRing slots (22 / 24 pieces of
+// 1 KB per tile, tiles alternating between the loaders, two tiles in flight each).  There is NO block barrier: a loader
+// publishes "my m-th tile has landed" in an LDS word, every compute wave publishes "I am done with tile k", the loaders
+// reuse a slot when the slowest compute wave has left it.  Compute waves therefore drift apart, and on every SIMD the LDS
+// reads / sines of one wave run under the MFMAs of the other.
+// (Measured alternatives, profiles/r03_dw_variants.txt: every compute wave issuing its share of the DMA pieces and ONE
+// barrier per tile or per pair of tiles, 8 or 16 waves, 3..6 slots, roles balanced per SIMD, second-half waves in
+// anti-phase: 70-75 us per 1000 colour-stage rays for 29 us of MFMA work whatever the arrangement -- the time was the SUM
+// of the DMA cadence (35 us), the LDS read phases and the MFMAs: lock-step phases behind the barriers, the youngest waves
+// of a SIMD starving at issue.  Operands straight from global memory into registers, no LDS: 159 us, 240-256 VGPRs.)
+constexpr int kDwCompute = 8, kDwLoaders = 2, kDwWaves = kDwCompute + kDwLoaders, kDwRing = 6;
 template <int KIND>
 struct DwLay {
-    static constexpr bool XYZ = KIND != NSR_COARSE;
     static constexpr int NC = KIND == NSR_FINE ? 4 : 2;          // feature operand tiles ([c_fine | c_mid] for the fine decoder)
-    static constexpr int oDY = 0, oH = 10 * 256, oC = 20 * 256;   // operand tiles: [16 points][16 channels] floats, as in memory
-    static constexpr int oPD = (20 + NC) * 256;                   // [16][4] doubles
-    static constexpr int oDR = oPD + 128;                         // [16][4] floats
+    static constexpr int oDY = 0, oH = 10 * 256, oCM = 22 * 256;  // LDS slot: dY (10 KB) | h_0..h_4, c (12 KB) | fine: c_mid (2 KB)
+    static constexpr int oPF = (20 + NC) * 256, oDR = oPF + 64;   // [16][4] fp32 positions | [16][4] d raw
     static constexpr int kSlot = oDR + 64;
     static constexpr int NOPS = 20 + NC + 2;                      // DMA pieces per tile
-    static constexpr int CNT = (NOPS + kDwWaves - 1) / kDwWaves;  // ... per wave (uniform: the tail repeats the last piece)
 };
-constexpr int dw_lds_floats(int kind) { return kDwRing * (kind == NSR_FINE ? DwLay<NSR_FINE>::kSlot : DwLay<NSR_MIDDLE>::kSlot); }
-
-// request tile `tile`'s operands into ring slot `slot` (this wave's share of the pieces)
+constexpr int dw_lds_bytes(int kind) { return (kDwRing * (kind == NSR_FINE ? DwLay<NSR_FINE>::kSlot : DwLay<NSR_MIDDLE>::kSlot) + 16) * 4; }
+struct DwSrc {                 // where one 16-point tile's operands live (LDS slot)
+    const float *dy;           // [kDySlots][16][16]   dY_i
+    const float *act;          // [12][16][16]         h_i, c
+    const float *cm;           // fine decoder: the middle decoder's features, addressed like activation slots kActC, kActC + 1
+    const float *pf;           // [16][4] float positions
+    const float *dr;           // [16][4] d raw
+};
 template <int KIND>
-NSR_DEV void dw_issue(const RenderParams &P, long long tile, float *slot, int wave, int lane) {
+NSR_DEV DwSrc dw_src(const float *slot) {
     typedef DwLay<KIND> Y;
-    const long long ss = P.act_stride;
-    const float *acts_pass = P.acts + (long long)act_pass(KIND) * kActSlots * ss;
-    const float *dys = P.dy + (long long)act_pass(KIND) * kDySlots * ss;
+    DwSrc s;
+    s.dy = slot + Y::oDY; s.act = slot + Y::oH; s.cm = slot + Y::oCM - kActC * 256; s.pf = slot + Y::oPF; s.dr = slot + Y::oDR;
+    return s;
+}
+// request tile `tile`'s operands into ring slot `slot` (one loader wave: NOPS pieces)
+template <int KIND>
+NSR_DEV void dw_issue(const RenderParams &P, long long tile, float *slot, int lane) {
+    typedef DwLay<KIND> Y;
+    // a tile's dY (10 KB) and its hidden states + features (12 KB) are contiguous spans in memory: piece n = the n-th KB
+    const float *dt = P.dy + ((long long)act_pass(KIND) * P.act_tiles + tile) * (kDySlots * 256);
+    const float *at = P.acts + ((long long)act_pass(KIND) * P.act_tiles + tile) * (kActSlots * 256);
 #pragma unroll
-    for (int k = 0; k < Y::CNT; ++k) {
-        int n = wave + k * kDwWaves;
-        if (n > Y::NOPS - 1) n = Y::NOPS - 1;
-        if (n < 10) dma16(dys + n * ss + tile * 256 + lane * 4, slot + Y::oDY + n * 256, lane);
-        else if (n < 20) dma16(acts_pass + (n - 10) * ss + tile * 256 + lane * 4, slot + Y::oH + (n - 10) * 256, lane);
-        else if (n < 22) dma16(acts_pass + (kActC + n - 20) * ss + tile * 256 + lane * 4, slot + Y::oC + (n - 20) * 256, lane);
-        else if (n < 20 + Y::NC) dma16(P.acts + (kActC + n - 22) * ss + tile * 256 + lane * 4, slot + Y::oC + (n - 20) * 256, lane);   // fine: middle features (pass 0)
-        else if (n == 20 + Y::NC) { if (lane < 32) dma16(reinterpret_cast<const float *>(P.pd) + tile * 128 + lane * 4, slot + Y::oPD, lane); }
-        else { if (lane < 16) dma16(P.draw + tile * 64 + lane * 4, slot + Y::oDR, lane); }
+    for (int n = 0; n < 10; ++n) dma16(dt + n * 256 + lane * 4, slot + Y::oDY + n * 256, lane);
+#pragma unroll
+    for (int n = 0; n < 12; ++n) dma16(at + n * 256 + lane * 4, slot + Y::oH + n * 256, lane);
+    if (KIND == NSR_FINE) {                                       // the middle decoder's features of the same tile (pass 0)
+        const float *cm = P.acts + (tile * kActSlots + kActC) * 256;
+        dma16(cm + lane * 4, slot + Y::oCM, lane);
+        dma16(cm + 256 + lane * 4, slot + Y::oCM + 256, lane);
+    }
+    if (lane < 16) {
+        dma16(P.pf + tile * 64 + lane * 4, slot + Y::oPF, lane);
+        dma16(P.draw + tile * 64 + lane * 4, slot + Y::oDR, lane);
     }
 }
-
-// operand tile in "lane = channel" form: element q = X[point 4 q + g][channel i]   (lane = 16 g + i; conflict-free dword reads)
-NSR_DEV f32x4 lds_op(const float *tile, int lane) {
+NSR_DEV f32x4 gop(const float *tile, int lane) {
     f32x4 v;
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = tile[q * 64 + lane];
     return v;
 }
-// d[n] += a[n]^T x over the 16 points of the tile, k-steps alternating between the accumulators
-template <int N>
-NSR_DEV void dw_acc(f32x4 (&d)[N], const f32x4 (&a)[N], const f32x4 x) {
+// rows of the ragged last tile beyond the last point: element q of lane (i, g) is point 4 q + g
+NSR_DEV void rag(f32x4 &v, int g, int nvalid) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int n = 0; n < N; ++n) d[n] = mfma16(a[n][q], x[q], d[n]);
+    for (int q = 0; q < 4; ++q) if (4 * q + g >= nvalid) v[q] = 0.f;
 }
 NSR_DEV void img_tile(float *img, const Mat m, int To, int Tk, const f32x4 acc, int i, int g) {
     if (16 * Tk + i < m.kcols) {
@@ -409,34 +432,36 @@ NSR_DEV void img_tile(float *img, const Mat m, int To, int Tk, const f32x4 acc, 
 }
 NSR_DEV float red_g4(float v) { v += shfl_xor(v, 16); v += shfl_xor(v, 32); return v; }
 
-// what one wave of an xyz-decoder block owns (see the header): waves 0..5 the Fourier-feature blocks W0 / W3e of embedding
-// k-tile `wave` (they share one sine evaluation) plus a part of layers 3 / 4, the output layer or the first bias; waves 6 / 7
-// layers 1 / 2.
+// What one wave of an xyz-decoder block owns.  16x16 output tiles in units: W0 / W3e against embedding k-tile k ("We_k": 4
+// tiles, one sine evaluation), a row tile of a layer's hidden-state block ("Wh(j, row)": 2 tiles) and of its feature block
+// ("G(j, row)": c_dim / 16 tiles).  Waves w and w + 4 share a SIMD, so the units are dealt such that every SIMD carries the
+// same number of MFMAs (14 tiles per 16 points, 18 for the fine decoder):
+//   w = 0..3:  We_w + Wh(j, row) + G(j, row)   with j = 1 (w < 2) or 2, row = w & 1
+//   w = 4, 5:  We_w + G(3, w - 4)              w = 4 also the bias sums of layer 0, w = 5 the output layer
+//   w = 6, 7:  Wh(4, row) + G(4, row) + Wh(3, row),  row = w - 6
+// The bias sums of layer j go with its Wh unit.  Within a tile the k-steps of ALL the wave's output tiles are issued
+// round-robin (a 16x16x4 fp32 MFMA has a 40-cycle dependent latency against a 32-cycle issue interval).
 template <int KIND, int WAVE>
 struct DwXyzWave {
     typedef DwLay<KIND> Y;
     static constexpr int CD = cdim_of(KIND), NC = Y::NC, NOUT = nout_of(KIND), NO = NOUT == 1 ? 1 : 3;
     static constexpr bool kWe = WAVE < 6;
-    static constexpr int LJ = WAVE == 6 ? 1 : (WAVE == 7 ? 2 : (WAVE < 2 ? 3 : (WAVE < 4 ? 4 : 0)));     // layer of the Wh / G tiles, 0: none
-    static constexpr int R0 = WAVE >= 6 ? 0 : (WAVE & 1), NR = WAVE >= 6 ? 2 : (LJ ? 1 : 0);              // output row tiles To = R0 .. R0 + NR - 1
-    static constexpr bool kOut = WAVE == 4, kB0 = WAVE == 5;
+    static constexpr int WJ = WAVE < 2 ? 1 : (WAVE < 4 ? 2 : (WAVE < 6 ? 0 : 4));        // layer of the first Wh unit (0: none)
+    static constexpr int GJ = WAVE < 2 ? 1 : (WAVE < 4 ? 2 : (WAVE < 6 ? 3 : 4));        // layer of the G unit
+    static constexpr int W2J = WAVE >= 6 ? 3 : 0;                                         // layer of the second Wh unit
+    static constexpr int ROW = WAVE < 4 ? (WAVE & 1) : (WAVE < 6 ? WAVE - 4 : WAVE - 6);
+    static constexpr bool kOut = WAVE == 5, kB0 = WAVE == 4;
     f32x4 we[4];               // [W0 To 0, W0 To 1, W3e To 0, W3e To 1] x embedding k-tile WAVE
-    f32x4 wh[2][2], gg[2][4];  // [row][k-tile]
-    float vb[2];               // bias sums of layer LJ (rows R0..) / of layer 0 (kB0)
+    f32x4 wh[2], w2[2], gg[4]; // row ROW of layers WJ / W2J (hidden-state k-tiles), of layer GJ (feature k-tiles)
+    float vb, vb2, vb0[2];     // bias sums: layer WJ, layer W2J (row ROW); layer 0 (kB0)
     float wo[3][2], bo[3], go[3][4];
     float bx, by, bz;          // Fourier matrix column of channel 16 WAVE + i
 
     NSR_DEV void init(const RenderParams &P, int i) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) we[k] = f4zero();
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            vb[a] = 0.f;
-#pragma unroll
-            for (int b = 0; b < 2; ++b) wh[a][b] = f4zero();
-#pragma unroll
-            for (int b = 0; b < 4; ++b) gg[a][b] = f4zero();
-        }
+        for (int k = 0; k < 4; ++k) { we[k] = f4zero(); gg[k] = f4zero(); }
+        wh[0] = wh[1] = w2[0] = w2[1] = f4zero();
+        vb = vb2 = vb0[0] = vb0[1] = 0.f;
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
             bo[n] = 0.f; wo[n][0] = wo[n][1] = 0.f;
@@ -449,74 +474,95 @@ struct DwXyzWave {
             bx = b.x; by = b.y; bz = b.z;
         }
     }
-    NSR_DEV void tile(const float *s, int lane) {
+    // operands of one tile as loaded ("lane = channel" form); nothing here is computed on, so that fetch() only issues loads
+    struct Ops { f32x4 y[4], a1, a2, ag, h1[2], h2[2], c[NC], h4[2]; F4 pos[4]; float dn[NO][4]; };
+    NSR_DEV void fetch(const DwSrc s, int lane, Ops &o) {
         const int g = lane >> 4;
         if (kWe) {
-            f32x4 y[4];
-            y[0] = lds_op(s + Y::oDY + 0 * 256, lane); y[1] = lds_op(s + Y::oDY + 1 * 256, lane);
-            y[2] = lds_op(s + Y::oDY + 6 * 256, lane); y[3] = lds_op(s + Y::oDY + 7 * 256, lane);
-            const double *pd = reinterpret_cast<const double *>(s + Y::oPD);
-            f32x4 qx, qy, qz;
+            o.y[0] = gop(s.dy + 0 * 256, lane); o.y[1] = gop(s.dy + 1 * 256, lane);
+            o.y[2] = gop(s.dy + 6 * 256, lane); o.y[3] = gop(s.dy + 7 * 256, lane);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                qx[q] = (float)pd[(4 * q + g) * 4 + 0]; qy[q] = (float)pd[(4 * q + g) * 4 + 1]; qz[q] = (float)pd[(4 * q + g) * 4 + 2];
-            }
-            const f32x4 e = sin_acc4(vfma(qz, splat(bz), vfma(qy, splat(by), qx * splat(bx))));     // decoder.py:29-30
-            dw_acc<4>(we, y, e);
-            if (kB0) { vb[0] += sum4(y[0]); vb[1] += sum4(y[1]); }
+            for (int q = 0; q < 4; ++q) o.pos[q] = ld4(s.pf + (4 * q + g) * 4);
         }
-        if (LJ > 0) {
-            f32x4 a[NR > 0 ? NR : 1];
-#pragma unroll
-            for (int rr = 0; rr < NR; ++rr) {
-                a[rr] = lds_op(s + Y::oDY + (2 * LJ + R0 + rr) * 256, lane);
-                vb[rr] += sum4(a[rr]);
-            }
-#pragma unroll
-            for (int Tk = 0; Tk < 2; ++Tk) {
-                const f32x4 x = lds_op(s + Y::oH + (2 * (LJ - 1) + Tk) * 256, lane);
-                f32x4 d[NR > 0 ? NR : 1];
-#pragma unroll
-                for (int rr = 0; rr < NR; ++rr) d[rr] = wh[rr][Tk];
-                dw_acc<(NR > 0 ? NR : 1)>(d, a, x);
-#pragma unroll
-                for (int rr = 0; rr < NR; ++rr) wh[rr][Tk] = d[rr];
-            }
-#pragma unroll
-            for (int Tc = 0; Tc < NC; ++Tc) {
-                const f32x4 x = lds_op(s + Y::oC + Tc * 256, lane);
-                f32x4 d[NR > 0 ? NR : 1];
-#pragma unroll
-                for (int rr = 0; rr < NR; ++rr) d[rr] = gg[rr][Tc];
-                dw_acc<(NR > 0 ? NR : 1)>(d, a, x);
-#pragma unroll
-                for (int rr = 0; rr < NR; ++rr) gg[rr][Tc] = d[rr];
-            }
+        if (WJ) {
+            o.a1 = gop(s.dy + (2 * WJ + ROW) * 256, lane);
+            o.h1[0] = gop(s.act + (2 * (WJ - 1)) * 256, lane); o.h1[1] = gop(s.act + (2 * (WJ - 1) + 1) * 256, lane);
         }
+        if (W2J) {
+            o.a2 = gop(s.dy + (2 * W2J + ROW) * 256, lane);
+            o.h2[0] = gop(s.act + (2 * (W2J - 1)) * 256, lane); o.h2[1] = gop(s.act + (2 * (W2J - 1) + 1) * 256, lane);
+        }
+        if (GJ != WJ) o.ag = gop(s.dy + (2 * GJ + ROW) * 256, lane);
+#pragma unroll
+        for (int Tc = 0; Tc < NC; ++Tc) o.c[Tc] = gop((Tc < 2 ? s.act : s.cm) + (kActC + (Tc & 1)) * 256, lane);
         if (kOut) {
-            // output layer: d Wo[n][k] = sum_p d_out[p][n] h4[p][k], d bo, and g_out[n][c] = sum_p d_out[p][n] c[p][c] (-> dU_4)
-            f32x4 dn[NO];
+            o.h4[0] = gop(s.act + 8 * 256, lane); o.h4[1] = gop(s.act + 9 * 256, lane);
 #pragma unroll
             for (int n = 0; n < NO; ++n)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) dn[n][q] = s[Y::oDR + (4 * q + g) * 4 + (NOUT == 1 ? 3 : n)];
-            const f32x4 h0 = lds_op(s + Y::oH + 8 * 256, lane), h1 = lds_op(s + Y::oH + 9 * 256, lane);
+                for (int q = 0; q < 4; ++q) o.dn[n][q] = s.dr[(4 * q + g) * 4 + (NOUT == 1 ? 3 : n)];
+        }
+    }
+    // the tile's sums; nvalid < 16: the ragged last tile (rows beyond the last point hold whatever the padding holds)
+    NSR_DEV void consume(Ops &o, int lane, int nvalid) {
+        const int g = lane >> 4;
+        if (nvalid < kTile) {
+            if (kWe) { rag(o.y[0], g, nvalid); rag(o.y[1], g, nvalid); rag(o.y[2], g, nvalid); rag(o.y[3], g, nvalid); }
+            if (WJ) { rag(o.a1, g, nvalid); rag(o.h1[0], g, nvalid); rag(o.h1[1], g, nvalid); }
+            if (W2J) { rag(o.a2, g, nvalid); rag(o.h2[0], g, nvalid); rag(o.h2[1], g, nvalid); }
+            if (GJ != WJ) rag(o.ag, g, nvalid);
 #pragma unroll
-            for (int n = 0; n < NO; ++n) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { wo[n][0] = fmaf(dn[n][q], h0[q], wo[n][0]); wo[n][1] = fmaf(dn[n][q], h1[q], wo[n][1]); }
-                bo[n] += sum4(dn[n]);
-            }
-#pragma unroll
-            for (int Tc = 0; Tc < NC; ++Tc) {
-                const f32x4 x = lds_op(s + Y::oC + Tc * 256, lane);
+            for (int Tc = 0; Tc < NC; ++Tc) rag(o.c[Tc], g, nvalid);
+            if (kOut) {
+                rag(o.h4[0], g, nvalid); rag(o.h4[1], g, nvalid);
 #pragma unroll
                 for (int n = 0; n < NO; ++n)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) go[n][Tc] = fmaf(dn[n][q], x[q], go[n][Tc]);
+                    for (int q = 0; q < 4; ++q) if (4 * q + g >= nvalid) o.dn[n][q] = 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (kWe && 4 * q + g >= nvalid) o.pos[q] = F4{0.f, 0.f, 0.f, 0.f};
+        }
+        const f32x4 ag = (GJ == WJ) ? o.a1 : o.ag;
+        f32x4 e = f4zero();
+        if (kWe) {
+            f32x4 qx, qy, qz;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { qx[q] = o.pos[q].x; qy[q] = o.pos[q].y; qz[q] = o.pos[q].z; }
+            e = sin_acc4(vfma(qz, splat(bz), vfma(qy, splat(by), qx * splat(bx))));     // decoder.py:29-30
+            if (kB0) { vb0[0] += sum4(o.y[0]); vb0[1] += sum4(o.y[1]); }
+        }
+        if (WJ) vb += sum4(o.a1);
+        if (W2J) vb2 += sum4(o.a2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (kWe) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) we[n] = mfma16(o.y[n][q], e[q], we[n]);
+            }
+            if (WJ) { wh[0] = mfma16(o.a1[q], o.h1[0][q], wh[0]); wh[1] = mfma16(o.a1[q], o.h1[1][q], wh[1]); }
+#pragma unroll
+            for (int Tc = 0; Tc < NC; ++Tc) gg[Tc] = mfma16(ag[q], o.c[Tc][q], gg[Tc]);
+            if (W2J) { w2[0] = mfma16(o.a2[q], o.h2[0][q], w2[0]); w2[1] = mfma16(o.a2[q], o.h2[1][q], w2[1]); }
+        }
+        if (kOut) {
+            // output layer: d Wo[n][k] = sum_p d_out[p][n] h4[p][k], d bo, and g_out[n][c] = sum_p d_out[p][n] c[p][c] (-> dU_4)
+#pragma unroll
+            for (int n = 0; n < NO; ++n) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    wo[n][0] = fmaf(o.dn[n][q], o.h4[0][q], wo[n][0]); wo[n][1] = fmaf(o.dn[n][q], o.h4[1][q], wo[n][1]);
+                    bo[n] += o.dn[n][q];
+                }
+#pragma unroll
+                for (int Tc = 0; Tc < NC; ++Tc)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) go[n][Tc] = fmaf(o.dn[n][q], o.c[Tc][q], go[n][Tc]);
             }
         }
     }
+    static constexpr int hid_of(int j) { return j == 1 ? XW1 : (j == 2 ? XW2 : (j == 3 ? XW3H : XW4)); }
+    static constexpr int u_of(int j) { return j == 1 ? XU0 : (j == 2 ? XU1 : (j == 3 ? XU2 : XU3)); }      // G_j sits where dU_{j-1} lives
     NSR_DEV void flush(float *img, int lane) {
         const int i = lane & 15, g = lane >> 4;
         if (kWe) {
@@ -525,26 +571,26 @@ struct DwXyzWave {
         }
         if (kB0) {
 #pragma unroll
-            for (int T = 0; T < 2; ++T) { const float v = red_g4(vb[T]); if (g == 0) img[bias_off(KIND, 0) + 16 * T + i] = v; }
+            for (int T = 0; T < 2; ++T) { const float v = red_g4(vb0[T]); if (g == 0) img[bias_off(KIND, 0) + 16 * T + i] = v; }
         }
-        if (LJ > 0) {
-            const Mat mh = xyz_mat(CD, LJ == 1 ? XW1 : (LJ == 2 ? XW2 : (LJ == 3 ? XW3H : XW4)));
-            const Mat mg = xyz_mat(CD, LJ == 1 ? XU0 : (LJ == 2 ? XU1 : (LJ == 3 ? XU2 : XU3)));          // G_j sits where dU_{j-1} lives
-#pragma unroll
-            for (int rr = 0; rr < NR; ++rr) {
-#pragma unroll
-                for (int Tk = 0; Tk < 2; ++Tk) img_tile(img, mh, R0 + rr, Tk, wh[rr][Tk], i, g);
-#pragma unroll
-                for (int Tc = 0; Tc < NC; ++Tc) img_tile(img, mg, R0 + rr, Tc, gg[rr][Tc], i, g);
-                const float v = red_g4(vb[rr]);
-                if (g == 0) img[bias_off(KIND, LJ) + 16 * (R0 + rr) + i] = v;
-            }
+        if (WJ) {
+            img_tile(img, xyz_mat(CD, hid_of(WJ)), ROW, 0, wh[0], i, g); img_tile(img, xyz_mat(CD, hid_of(WJ)), ROW, 1, wh[1], i, g);
+            const float v = red_g4(vb);
+            if (g == 0) img[bias_off(KIND, WJ) + 16 * ROW + i] = v;
         }
+        if (W2J) {
+            img_tile(img, xyz_mat(CD, hid_of(W2J)), ROW, 0, w2[0], i, g); img_tile(img, xyz_mat(CD, hid_of(W2J)), ROW, 1, w2[1], i, g);
+            const float v = red_g4(vb2);
+            if (g == 0) img[bias_off(KIND, W2J) + 16 * ROW + i] = v;
+        }
+#pragma unroll
+        for (int Tc = 0; Tc < NC; ++Tc) img_tile(img, xyz_mat(CD, u_of(GJ)), ROW, Tc, gg[Tc], i, g);
         if (kOut) {
 #pragma unroll
             for (int n = 0; n < NO; ++n) {
 #pragma unroll
                 for (int T = 0; T < 2; ++T) { const float v = red_g4(wo[n][T]); if (g == 0) img[wo_off(KIND) + n * 32 + 16 * T + i] = v; }
+                // every lane of a point group summed the same d_out: one lane per group
                 const float vbo = red_g4(bo[n]);
                 if (lane == 0) img[bo_off(KIND) + n] = vbo;
 #pragma unroll
@@ -560,7 +606,6 @@ struct DwXyzWave {
 // layer's dY first, its bias sums; wave 6 the output layer.
 template <int WAVE>
 struct DwNoxWave {
-    typedef DwLay<NSR_COARSE> Y;
     static constexpr int LJ = WAVE == NW3C ? 3 : (WAVE == NW3H ? 3 : (WAVE == NW4 ? 4 : WAVE));       // layer whose dY this matrix contracts
     static constexpr bool kMat = WAVE < 6, kBias = kMat && WAVE != NW3H, kOut = WAVE == 6;
     f32x4 w[2][2];
@@ -570,30 +615,41 @@ struct DwNoxWave {
         for (int a = 0; a < 2; ++a) { vb[a] = 0.f; wo[a] = 0.f; w[a][0] = f4zero(); w[a][1] = f4zero(); }
         bo = 0.f;
     }
-    NSR_DEV void tile(const float *s, int lane) {
+    struct Ops { f32x4 a[2], x[2]; float dn[4]; };
+    NSR_DEV void fetch(const DwSrc s, int lane, Ops &o) {
         const int g = lane >> 4;
         if (kMat) {
-            f32x4 a[2];
-            a[0] = lds_op(s + Y::oDY + (2 * LJ) * 256, lane); a[1] = lds_op(s + Y::oDY + (2 * LJ + 1) * 256, lane);
-            if (kBias) { vb[0] += sum4(a[0]); vb[1] += sum4(a[1]); }
+            o.a[0] = gop(s.dy + (2 * LJ) * 256, lane); o.a[1] = gop(s.dy + (2 * LJ + 1) * 256, lane);
 #pragma unroll
-            for (int Tk = 0; Tk < 2; ++Tk) {
-                // input of the matrix: the features (NW0, NW3C) or the previous hidden state
-                const float *xs = (WAVE == NW0 || WAVE == NW3C) ? s + Y::oC + Tk * 256 : s + Y::oH + (2 * (LJ - 1) + Tk) * 256;
-                const f32x4 x = lds_op(xs, lane);
-                f32x4 d[2] = {w[0][Tk], w[1][Tk]};
-                dw_acc<2>(d, a, x);
-                w[0][Tk] = d[0]; w[1][Tk] = d[1];
-            }
+            for (int Tk = 0; Tk < 2; ++Tk)      // input of the matrix: the features (NW0, NW3C) or the previous hidden state
+                o.x[Tk] = gop(s.act + ((WAVE == NW0 || WAVE == NW3C) ? kActC + Tk : 2 * (LJ - 1) + Tk) * 256, lane);
         }
         if (kOut) {
-            f32x4 dn;
+            o.x[0] = gop(s.act + 8 * 256, lane); o.x[1] = gop(s.act + 9 * 256, lane);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dn[q] = s[Y::oDR + (4 * q + g) * 4 + 3];
-            const f32x4 h0 = lds_op(s + Y::oH + 8 * 256, lane), h1 = lds_op(s + Y::oH + 9 * 256, lane);
+            for (int q = 0; q < 4; ++q) o.dn[q] = s.dr[(4 * q + g) * 4 + 3];
+        }
+    }
+    NSR_DEV void consume(Ops &o, int lane, int nvalid) {
+        const int g = lane >> 4;
+        if (nvalid < kTile) {
+            if (kMat) { rag(o.a[0], g, nvalid); rag(o.a[1], g, nvalid); }
+            if (kMat || kOut) { rag(o.x[0], g, nvalid); rag(o.x[1], g, nvalid); }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { wo[0] = fmaf(dn[q], h0[q], wo[0]); wo[1] = fmaf(dn[q], h1[q], wo[1]); }
-            bo += sum4(dn);
+            for (int q = 0; q < 4; ++q) if (kOut && 4 * q + g >= nvalid) o.dn[q] = 0.f;
+        }
+        if (kMat) {
+            if (kBias) { vb[0] += sum4(o.a[0]); vb[1] += sum4(o.a[1]); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int To = 0; To < 2; ++To)
+#pragma unroll
+                    for (int Tk = 0; Tk < 2; ++Tk) w[To][Tk] = mfma16(o.a[To][q], o.x[Tk][q], w[To][Tk]);
+        }
+        if (kOut) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { wo[0] = fmaf(o.dn[q], o.x[0][q], wo[0]); wo[1] = fmaf(o.dn[q], o.x[1][q], wo[1]); bo += o.dn[q]; }
         }
     }
     NSR_DEV void flush(float *img, int lane) {
@@ -618,69 +674,71 @@ struct DwNoxWave {
     }
 };
 
+// control words behind the ring: landed[j] = tiles loader j has landed, prog[w] = tiles compute wave w is done with
 template <int KIND, class W>
-NSR_DEV void dw_wave(const RenderParams &P, W &Wv, float *ring, float *img, int wave, int lane) {
+NSR_DEV void dw_compute(const RenderParams &P, W &Wv, float *ring, int *ctl, float *img, int wave, int lane) {
     typedef DwLay<KIND> Y;
     Wv.init(P, lane & 15);
     const long long ntiles = (P.n_points_total + kTile - 1) / kTile;
     const long long last = ntiles - 1, step = nblk_x();
-    long long t = bid_x();
-    // ring: tile t in slot (it % 3); two tiles requested ahead.  Every wave always issues its CNT pieces per tile (requests
-    // beyond the block's last tile repeat that tile into a slot nobody reads), so "all but the newest CNT * k requests have
-    // landed" is a constant wait count.
-    auto clampt = [&](long long x) { return x < ntiles ? x : last; };
-    dw_issue<KIND>(P, clampt(t), ring, wave, lane);
-    dw_issue<KIND>(P, clampt(t + step), ring + Y::kSlot, wave, lane);
-    int it = 0;
-    for (; t < ntiles; t += step, ++it) {
+    const int ragged = (int)(P.n_points_total & (kTile - 1));
+    typename W::Ops ops;
+    int k = 0;
+    for (long long t = bid_x(); t < ntiles; t += step, ++k) {
         loop_fence();
-        float *s = ring + (it % kDwRing) * Y::kSlot;
-        dma_wait<Y::CNT>();                          // this wave's pieces of tile t have landed ...
-        block_sync();                                // ... and everybody else's; everyone is done with the previous tile's slot
-        dw_issue<KIND>(P, clampt(t + 2 * step), ring + ((it + 2) % kDwRing) * Y::kSlot, wave, lane);
-        if (t == last && (P.n_points_total & (kTile - 1))) {
-            // ragged last tile: rows beyond the last point hold whatever the padding holds -- zero them (every wave of the block)
-            const int nvalid = (int)(P.n_points_total & (kTile - 1));
-            for (int idx = tid(); idx < Y::kSlot; idx += nthreads()) {
-                const int row = idx < Y::oPD ? ((idx & 255) >> 4) : (idx < Y::oDR ? (idx - Y::oPD) >> 3 : (idx - Y::oDR) >> 2);
-                if (row >= nvalid) s[idx] = 0.f;
+        while (flag_load(ctl + (k & 1)) <= (k >> 1)) spin_pause();          // the loader of this tile has landed it
+        Wv.fetch(dw_src<KIND>(ring + (k % kDwRing) * Y::kSlot), lane, ops);
+        Wv.consume(ops, lane, (t == last && ragged) ? ragged : kTile);
+        flag_store(ctl + kDwLoaders + wave, k + 1);                          // (release: the slot's reads have returned)
+    }
+    Wv.flush(img, lane);
+}
+
+template <int KIND>
+NSR_DEV void dw_loader(const RenderParams &P, float *ring, int *ctl, int j, int lane) {
+    typedef DwLay<KIND> Y;
+    const long long ntiles = (P.n_points_total + kTile - 1) / kTile;
+    const long long step = nblk_x();
+    int m = 0;                                                               // this loader's m-th tile is the block's tile 2 m + j
+    for (long long t = bid_x() + j * step; t < ntiles; t += kDwLoaders * step, ++m) {
+        loop_fence();
+        const int k = kDwLoaders * m + j;
+        if (k >= kDwRing) {                                                  // the slot still holds tile k - kDwRing
+            for (;;) {
+                int lo = flag_load(ctl + kDwLoaders);
+#pragma unroll
+                for (int w = 1; w < kDwCompute; ++w) { const int v = flag_load(ctl + kDwLoaders + w); lo = v < lo ? v : lo; }
+                if (lo > k - kDwRing) break;
+                spin_pause();
             }
-            block_sync();
         }
-        Wv.tile(s, lane);
+        dw_issue<KIND>(P, t, ring + (k % kDwRing) * Y::kSlot, lane);
+        if (m >= 1) { dma_wait<Y::NOPS>(); flag_store(ctl + j, m); }          // all but the newest tile's pieces have landed
     }
     dma_wait<0>();
-    Wv.flush(img, lane);
+    flag_store(ctl + j, m);
 }
 
 template <int KIND>
 NSR_DEV void dw_pass(const RenderParams &P) {
     float *ring = reinterpret_cast<float *>(lds_base());
+    int *ctl = reinterpret_cast<int *>(ring + kDwRing * DwLay<KIND>::kSlot);
     const int lane = tid() & 63, wave = uniform(tid() >> 6);
+    if (tid() < 16) ctl[tid()] = 0;
+    block_sync();
     float *img = P.partials + ((long long)bid_y() * nblk_x() + bid_x()) * P.partial_stride;
-    if constexpr (KIND == NSR_COARSE) {
-        switch (wave) {
-            case 0: { DwNoxWave<0> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
-            case 1: { DwNoxWave<1> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
-            case 2: { DwNoxWave<2> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
-            case 3: { DwNoxWave<3> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
-            case 4: { DwNoxWave<4> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
-            case 5: { DwNoxWave<5> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
-            case 6: { DwNoxWave<6> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
-            default: { DwNoxWave<7> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
-        }
-    } else {
-        switch (wave) {
-            case 0: { DwXyzWave<KIND, 0> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
-            case 1: { DwXyzWave<KIND, 1> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
-            case 2: { DwXyzWave<KIND, 2> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
-            case 3: { DwXyzWave<KIND, 3> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
-            case 4: { DwXyzWave<KIND, 4> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
-            case 5: { DwXyzWave<KIND, 5> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
-            case 6: { DwXyzWave<KIND, 6> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
-            default: { DwXyzWave<KIND, 7> W; dw_wave<KIND>(P, W, ring, img, wave, lane); break; }
-        }
+    // one specialisation per compute wave: its role's output tiles and operand reads are compile-time constants
+#define NSR_DW_CASE(WV)                                                                                         \
+    case WV: {                                                                                                  \
+        if constexpr (KIND == NSR_COARSE) { DwNoxWave<WV> W; dw_compute<KIND>(P, W, ring, ctl, img, WV, lane); } \
+        else { DwXyzWave<KIND, WV> W; dw_compute<KIND>(P, W, ring, ctl, img, WV, lane); }                        \
+        break;                                                                                                  \
     }
+    switch (wave) {
+        NSR_DW_CASE(0) NSR_DW_CASE(1) NSR_DW_CASE(2) NSR_DW_CASE(3) NSR_DW_CASE(4) NSR_DW_CASE(5) NSR_DW_CASE(6) NSR_DW_CASE(7)
+        default: dw_loader<KIND>(P, ring, ctl, wave - kDwCompute, lane); break;
+    }
+#undef NSR_DW_CASE
 }
 
 // grid = (partial images per pass, decoder passes of the stage); passes without parameter gradients exit at once
@@ -700,7 +758,7 @@ NSR_KERNEL NSR_BOUNDS(64 * kDwWaves) void render_bwd_dw_kernel(const RenderParam
 // finalize: dparams (+)= f(sum of the partial images).  grid = (blocks, decoders with gradients), 1024 threads.
 //   blocks [0, nd):        64 directly accumulated parameters each (pts_linears, output_linear; everything for MLP_no_xyz)
 //   blocks [nd, nd + 5):   d embedder._B from the dX kernel's partials (64 each)
-//   blocks [nd + 5, + 5 c_dim / 8):  fc_c.i, eight feature columns each: dU_i = W_{i+1}^T G_{i+1} (G summed from the images,
+//   blocks [nd + 5, + 5 c_dim / 4):  fc_c.i, four feature columns each: dU_i = W_{i+1}^T G_{i+1} (G summed from the images,
 //                          where it sits in dU_i's place), dv_i = W_{i+1}^T db_{i+1};  i = 4: Wo^T g_out, Wo^T d bo
 // ------------------------------------------------------------------------------------------------
 struct FinalJob {
@@ -737,6 +795,7 @@ NSR_KERNEL void bwd_finalize_kernel(const FinalParams R) {
                 const int d = e / kE, ch = e - d * kE;
                 for (int k = slice; k < J.ndx; k += nslice) s += J.dbpart[(long long)k * kDbPart + d * 96 + ch];
             } else {
+#pragma unroll 4
                 for (int k = slice; k < J.nimg; k += nslice) s += J.images[(long long)k * R.stride + dbeg + e];
             }
         }
@@ -749,17 +808,19 @@ NSR_KERNEL void bwd_finalize_kernel(const FinalParams R) {
         return;
     }
     if (!xyz) return;
-    // fc_c layer i, feature columns [8 chunk, 8 chunk + 8): S[o][c] = sum over the images of G (rows o < nrow of dU_i's place),
-    // 256 elements x 4 slices of the image list; chunk 0 also forms the bias sums db (32 slices) and dv_i
-    const int per = cd / 8, i = (b - nd - 5) / per, chunk = (b - nd - 5) % per;
+    // fc_c layer i, feature columns [4 chunk, 4 chunk + 4): S[o][c] = sum over the images of G (rows o < nrow of dU_i's place),
+    // 128 elements x 8 slices of the image list; chunk 0 also forms the bias sums db (32 slices) and dv_i
+    const int per = cd / 4, i = (b - nd - 5) / per, chunk = (b - nd - 5) % per;
     if (i > 4) return;                                              // (grid sized for the largest decoder of the stage)
     // the colour decoder's 4th output is discarded (decoder.py:341): three rows
     const int nrow = i < 4 ? 32 : (nout == 1 ? 1 : 3), goff = xyz_fcw(cd, i);
-    const int e = t & 255, o = e >> 3, c = 8 * chunk + (e & 7), sl = t >> 8;
+    const int e = t & 127, o = e >> 2, c = 4 * chunk + (e & 3), sl = t >> 7;
     {
         float sg = 0.f;
-        if (o < nrow)
-            for (int k = sl; k < J.nimg; k += 4) sg += J.images[(long long)k * R.stride + goff + o * cd + c];
+        if (o < nrow) {
+#pragma unroll 4
+            for (int k = sl; k < J.nimg; k += 8) sg += J.images[(long long)k * R.stride + goff + o * cd + c];
+        }
         red[t] = sg;
     }
     if (chunk == 0) {
@@ -771,7 +832,12 @@ NSR_KERNEL void bwd_finalize_kernel(const FinalParams R) {
         red[1024 + t] = sbv;
     }
     block_sync();
-    if (t < 256) red[t] = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
+    if (t < 128) {
+        float sg = red[t];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) sg += red[k * 128 + t];
+        red[t] = sg;
+    }
     if (chunk == 0 && t >= 256 && t < 288) {
         float sbv = 0.f;
         for (int k = 0; k < 32; ++k) sbv += red[1024 + k * 32 + (t - 256)];
@@ -781,12 +847,12 @@ NSR_KERNEL void bwd_finalize_kernel(const FinalParams R) {
     // W[o][k]: pts_linears.(i+1).weight (hidden-state columns) or output_linear.weight
     const int woff = i < 4 ? xyz_w(cd, i + 1) + (i == 2 ? kE : 0) : xyz_wo(cd);
     const int wstr = i < 4 ? xyz_in(i + 1) : 32;
-    if (t < 256) {
-        const int k = t >> 3, cc = t & 7;
+    if (t < 128) {
+        const int k = t >> 2, cc = t & 3;
         float sv = 0.f;
-        for (int oo = 0; oo < nrow; ++oo) sv = fmaf(J.params[woff + oo * wstr + k], red[oo * 8 + cc], sv);
-        final_store(R, J.dparams + goff + k * cd + 8 * chunk + cc, sv);
-    } else if (chunk == 0 && t < 288) {
+        for (int oo = 0; oo < nrow; ++oo) sv = fmaf(J.params[woff + oo * wstr + k], red[oo * 4 + cc], sv);
+        final_store(R, J.dparams + goff + k * cd + 4 * chunk + cc, sv);
+    } else if (chunk == 0 && t >= 256 && t < 288) {
         const int k = t - 256;
         float sv = 0.f;
         for (int oo = 0; oo < nrow; ++oo) sv = fmaf(J.params[woff + oo * wstr + k], red[2048 + oo], sv);

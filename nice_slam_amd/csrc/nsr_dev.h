@@ -104,6 +104,19 @@ NSR_DEV void dma16(const float *gsrc, float *lds_base, int /*lane*/) {
 }
 // wait until at most N of this wave's vector-memory requests are outstanding (they complete in order)
 template <int N> NSR_DEV void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// LDS flag words between the waves of a block (producer / consumer hand-offs without a block barrier): a store that orders
+// the wave's earlier LDS traffic before it, a load that orders the later traffic after it, and the pause of a polling loop.
+// (The asm "memory" clobbers keep the compiler from moving LDS accesses across; LDS operations of one wave execute in order.)
+NSR_DEV void flag_store(int *p, int v) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    *reinterpret_cast<volatile int *>(p) = v;
+}
+NSR_DEV int flag_load(const int *p) {
+    const int v = *reinterpret_cast<const volatile int *>(p);
+    asm volatile("" ::: "memory");
+    return v;
+}
+NSR_DEV void spin_pause() { __builtin_amdgcn_s_sleep(1); }
 NSR_DEV void atomic_add_global(float *p, float v) { unsafeAtomicAdd(p, v); }
 NSR_DEV void atomic_add_lds(float *p, float v) { atomicAdd(p, v); }
 NSR_DEV void atomic_add_lds_i(int *p, int v) { atomicAdd(p, v); }

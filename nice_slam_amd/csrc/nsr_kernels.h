@@ -71,7 +71,7 @@ struct RenderParams {
     double *zvals;            // [N][S] saved sample depths (optional)
     float *acts;              // saved decoder activations (optional, see ActSink): the backward then loads h_i / relu masks
     long long n_points_total; // n_rays * S
-    long long act_stride;     // floats between two activation slots: 16 * (n_points_total rounded up to whole 16-point tiles)
+    long long act_tiles;      // 16-point tiles of the sample-point list (n_points_total rounded up): tile stride of `acts` / `dy`
     // backward only
     const double *d_depth, *d_var, *g_depth;
     const float *d_rgb;
@@ -88,9 +88,10 @@ struct RenderParams {
     float w_color;            // weight of the colour term (colour stage only)
     long long *dbg;           // profiling stamps (NSR_TS builds only), else NULL
     // split backward (nsr_bwd2.h): scratch behind the saved activations in `acts`
-    float *dy;                // [passes][kDySlots][n_points][16]  dY_i of every decoder pass (same slot form as `acts`)
+    float *dy;                // [passes][tiles][kDySlots][16][16]  dY_i of every decoder pass (same slot form as `acts`)
     float *draw;              // [n_points][4]  d raw per sample (compositor backward)
     double *pd;               // [n_points][4]  sample position (fp64) and depth: px, py, pz, z
+    float *pf;                // [n_points][4]  the position rounded to fp32 (embedding argument)
     float *dbpart;            // [passes][dx blocks][288]  per-block partial sums of d embedder._B
     int dw_blocks;            // blocks per pass of the dW kernel = partial images per pass
     int xflags;               // measurement switches (NSR_X environment variable; 0 in normal operation)
@@ -618,24 +619,24 @@ struct Kept {
     unsigned mask[5];
 };
 
-// Saved activations (288 GB of HBM buy the backward its forward re-run): per xyz decoder pass p (middle 0, fine 1, colour 2)
-// and sample point, the five hidden states h_i (what the next layer reads) and the five relu masks -- exactly the `Kept`
-// registers of the lane that computed them.  Slot j (16 bytes per lane) of lane (pt, g) working on global point gp:
-//     acts + (((p * kActSlots + j) * n_points_total + gp) * 4 + g) * 4          j = 2 i + T: h_i k-tile T;  j = 10: masks;
-//                                                                               j = 11 + T: the decoder's own grid features c
-// i.e. a wave's 64 lanes write / read 1 KB contiguous per slot, whatever the tile / ray-group geometry of the kernel; a slot
-// is a row-major [n_points][16] matrix (16 consecutive channels of one activation), which is how the dW kernel (nsr_bwd2.h)
-// reads it.  The coarse decoder (MLP_no_xyz) uses pass 0 with the same slots.
+// Saved activations (288 GB of HBM buy the backward its forward re-run): per decoder pass p (middle 0, fine 1, colour 2; the
+// coarse decoder uses pass 0) and 16-point tile T of the flat sample-point list, 13 slots of 1 KB:
+//     acts + ((p * n_tiles + T) * kActSlots + j) * 256 + ((gp & 15) * 4 + g) * 4        (T = gp >> 4)
+//     j = 2 i + k: hidden state h_i (what the next layer reads), channels 16 k .. 16 k + 15;  j = 10 + k: the decoder's own
+//     grid features c;  j = 12: the five relu masks of the lane
+// A slot is a row-major [16 points][16 channels] matrix: a wave's 64 lanes (pt, g) write 1 KB contiguous per slot whatever
+// the tile / ray-group geometry of the kernel, and the 12 KB the dW kernel (nsr_bwd2.h) streams per tile and decoder are
+// ONE contiguous span (with slot-major arrays the same bytes were 12 scattered 1 KB pieces, 3 MB apart: 3 TB/s instead of
+// the HBM rate).
 constexpr int kActSlots = 13;
-constexpr int kActMask = 10, kActC = 11;
+constexpr int kActC = 10, kActMask = 12;
 struct ActSink {
     float *p;                // slot 0 of this lane, NULL for a lane without a point
-    long long stride;        // floats between two slots (n_points_total * 16)
+    static constexpr long long stride = 256;        // floats between two slots
 };
 NSR_DEV ActSink act_sink(const RenderParams &P, int pass, long long gp, int g) {
     ActSink a;
-    a.stride = P.act_stride;
-    a.p = (P.acts && gp >= 0) ? P.acts + (long long)pass * kActSlots * a.stride + (gp * 4 + g) * 4 : nullptr;
+    a.p = (P.acts && gp >= 0) ? P.acts + (((long long)pass * P.act_tiles + (gp >> 4)) * kActSlots) * 256 + ((gp & 15) * 4 + g) * 4 : nullptr;
     return a;
 }
 NSR_DEV int act_pass(int kind) { return kind == NSR_COARSE ? 0 : kind - NSR_MIDDLE; }
@@ -692,27 +693,6 @@ NSR_DEV void mlp_xyz_fwd(const float *pk, const float *aux, float px, float py, 
         s = fmaf(w1.x, h.t[1][0], s); s = fmaf(w1.y, h.t[1][1], s); s = fmaf(w1.z, h.t[1][2], s); s = fmaf(w1.w, h.t[1][3], s);
         out[n] = red_g(s) + aux[AUX_BO + n];
     }
-}
-
-// the backward's view of the same slots (zero for a lane without a point): the relu masks up front, one hidden state at a
-// time right where it is needed -- loading all 40 registers at the head of the tile gets them spilled, and every spill
-// waits for its load
-template <int KIND>
-NSR_DEV void load_masks(Kept<KIND> &K, const ActSink &a) {
-    unsigned m0 = 0u, m1 = 0u;
-    if (a.p) {
-        const F4 mm = ld4(a.p + 10 * a.stride);
-        m0 = __builtin_bit_cast(unsigned, mm.x); m1 = __builtin_bit_cast(unsigned, mm.y);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) K.mask[i] = (m0 >> (8 * i)) & 255u;
-    K.mask[4] = m1 & 255u;
-}
-NSR_DEV Act<2> load_hidden(const ActSink &a, int i) {
-    Act<2> h;
-    if (a.p) { h.t[0] = to_v(ld4(a.p + (2 * i) * a.stride)); h.t[1] = to_v(ld4(a.p + (2 * i + 1) * a.stride)); }
-    else { h.t[0] = f4zero(); h.t[1] = f4zero(); }
-    return h;
 }
 
 // MLP_no_xyz (decoder.py:262-274): h = c; h = relu(W_i h + b_i); after i == 2: h = [c | h]

@@ -142,6 +142,7 @@ inline T shfl_any(T v, int src) {
     const emu::Slot *buf = emu::exchange(&v, sizeof(T));
     return emu::slot_get<T>(buf, src & 63);
 }
+NSR_DEV int flag_load(const int *p) { return shfl_any(*p, 0); }
 NSR_DEV float shfl(float v, int src) { return shfl_any(v, src); }
 NSR_DEV int shfl_i(int v, int src) { return shfl_any(v, src); }
 NSR_DEV double shfl_d(double v, int src) { return shfl_any(v, src); }
@@ -168,6 +169,9 @@ NSR_DEV void block_sync() { emu::block_sync_impl(); }
 NSR_DEV void prefetch_line(const float *, float *) {}
 NSR_DEV void dma16(const float *gsrc, float *lds_base, int lane) { std::memcpy(lds_base + lane * 4, gsrc, 16); }
 template <int N> NSR_DEV void dma_wait() {}
+NSR_DEV void flag_store(int *p, int v) { *p = v; }
+NSR_DEV int flag_load(const int *p);                  // (below shfl_any: every lane of the wave sees lane 0's reading)
+NSR_DEV void spin_pause() { emu::wave_sync(); }       // a polling wave lets the block's other waves run
 NSR_DEV void atomic_add_global(float *p, float v) {
     // blocks may run on different OS threads: real atomic read-modify-write
     uint32_t *u = reinterpret_cast<uint32_t *>(p);

@@ -606,9 +606,9 @@ def test_saved_activations_equal_the_forward_rerun(emu, stage):
             npts = fwd["raw"].shape[0] * fwd["raw"].shape[1]
             npad = (npts + 15) // 16 * 16
             passes = max(1, ["coarse", "middle", "fine", "color"].index(stage))
-            slots = fwd["acts"][:passes * 13 * npad * 16].reshape(passes, 13, npad, 16)   # [pass][slot][point][lane group, 4]
-            assert not np.isnan(slots[:, :10, :npts]).any()     # every hidden-state slot of every point was written (slot 10: mask bits)
-            assert not np.isnan(slots[:, 11:, :npts]).any()     # ... and its grid features
+            slots = fwd["acts"][:passes * 13 * npad * 16].reshape(passes, npad // 16, 13, 16, 16)   # [pass][tile][slot][point][lane group, 4]
+            slots = slots.transpose(0, 2, 1, 3, 4).reshape(passes, 13, npad, 16)
+            assert not np.isnan(slots[:, :12, :npts]).any()     # every hidden-state / feature slot of every point was written (slot 12: mask bits)
         res[mode] = (fwd, sc.backward(stage, fwd, s["w"]["depth"].numpy(), s["w"]["var"].numpy(), s["w"]["rgb"].numpy(), max_blocks=2))
     for k in ("depth", "var", "rgb", "raw"):
         assert np.array_equal(res[True][0][k], res[False][0][k]), k
