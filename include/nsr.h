@@ -123,8 +123,11 @@ typedef struct nsr_bwd_args {
     int32_t max_blocks;       /* persistent-grid cap used to size the workspace (0 = library default) */
     int32_t overwrite_dparams; /* 0: every nsr_decoder.dparams is ACCUMULATED into (autograd semantics, caller-zeroed for a
                                  fresh gradient); 1: it is OVERWRITTEN (saves the caller the zero fill) */
-    void *ev_start;           /* optional hipEvent_t pair recorded on `stream` right before / after the main   */
-    void *ev_stop;            /* backward kernel (excludes the small partial-sum kernels); NULL = no timing      */
+    void *ev_start;           /* optional hipEvent_t pair recorded on `stream` right before the first / after the last */
+    void *ev_stop;            /* kernel of the backward; NULL = no timing                                               */
+    const double *grad_scale; /* optional DEVICE scalar every output gradient (d_depth, d_var, d_rgb) is multiplied by -- the
+                                 incoming gradient of a loss node fused around the render (no host sync, no extra launch);
+                                 NULL = 1 */
 } nsr_bwd_args;
 
 int nsr_version(void);

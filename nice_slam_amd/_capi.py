@@ -48,7 +48,7 @@ class NsrBwdArgs(C.Structure):
                 ("d_rays_o", C.c_void_p), ("d_rays_d", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
                 ("max_blocks", C.c_int32), ("overwrite_dparams", C.c_int32),
-                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p)]
+                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p), ("grad_scale", C.c_void_p)]
 
 
 class NsrFrame(C.Structure):
@@ -110,6 +110,11 @@ class NsrError(RuntimeError):
     pass
 
 
+import threading
+
+restore_device = threading.local()      # .idx: the device common._stream() switched away from for the launch in flight
+
+
 class Lib:
     """A loaded libnsr with typed entry points; ``check`` turns error codes into exceptions."""
 
@@ -129,6 +134,10 @@ class Lib:
             raise NsrError(f"{path}: ABI version {self.nsr_version()} != {ABI_VERSION}")
 
     def check(self, rc: int, what: str = "nsr"):
+        prev = getattr(restore_device, "idx", None)
+        if prev is not None:                 # the launch is enqueued: back to the caller's current device (common._stream)
+            restore_device.idx = None
+            torch.cuda.set_device(prev)
         if rc != 0:
             msg = self.nsr_last_error()
             raise NsrError(f"{what} failed: {msg.decode() if msg else rc}")

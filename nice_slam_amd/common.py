@@ -23,7 +23,12 @@ def _stream(device) -> int:
     operator does for the duration of its launch."""
     device = torch.device(device)
     idx = device.index
-    if idx is not None and idx != torch.cuda.current_device():
+    cur = torch.cuda.current_device()
+    if idx is not None and idx != cur:
+        # restored by Lib.check(), which every launch site calls right after the library call (`lib.check(lib.nsr_x(...,
+        # _stream(dev)), ...)`): the caller's current device is the same before and after, like around a torch operator
+        if getattr(_capi.restore_device, "idx", None) is None:
+            _capi.restore_device.idx = cur
         torch.cuda.set_device(idx)
     return torch.cuda.current_stream(device).cuda_stream
 

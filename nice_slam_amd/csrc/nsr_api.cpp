@@ -246,6 +246,11 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
             const int need = (nsr::AUX_FLOATS + nsr::packedT_total(kind) + G.waves * nsr::kDxStg) * 4;
             lds = need > lds ? need : lds;
         }
+        P.lds_grid_floats = 0;
+        if (P.stage == NSR_STAGE_COARSE && P.grid[NSR_COARSE].dfeat) {       // a coarse gradient grid that fits next to the rest
+            const long long gf = (long long)P.grid[NSR_COARSE].X * P.grid[NSR_COARSE].Y * P.grid[NSR_COARSE].Z * nsr::kC;
+            if (lds + gf * 4 <= kLdsLimit) { P.lds_grid_floats = (int)gf; lds += (int)gf * 4; }
+        }
         const dim3 grid(G.nb, passes), block(64 * G.waves);
 #define NSR_DX(ST, RY)                                                                                  \
     if (int rc = launch_cfg(nsr::render_bwd_dx_kernel<ST, RY>, lds, "nsr_render_bwd(dx)")) return rc;   \
@@ -366,7 +371,7 @@ int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream
     if (!b->depth) return fail("nsr_render_bwd: forward depth is required");
     if ((b->d_rays_o == nullptr) != (b->d_rays_d == nullptr)) return fail("nsr_render_bwd: d_rays_o / d_rays_d must be given together");
     if (P.n_rays == 0) return 0;
-    P.d_depth = b->d_depth; P.d_var = b->d_var; P.d_rgb = b->d_rgb; P.g_depth = b->depth;
+    P.d_depth = b->d_depth; P.d_var = b->d_var; P.d_rgb = b->d_rgb; P.g_depth = b->depth; P.g_scale = b->grad_scale;
     P.d_rays_o = b->d_rays_o; P.d_rays_d = b->d_rays_d;
 #ifdef NSR_TS
     if (const char *e = getenv("NSR_DBG_PTR")) P.dbg = reinterpret_cast<long long *>(strtoull(e, nullptr, 16));

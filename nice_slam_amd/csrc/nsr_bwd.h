@@ -687,11 +687,12 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
         F4 c_rw = F4{0.f, 0.f, 0.f, 0.f};
         double c_gD = 0.0, c_gV = 0.0, c_dep = 0.0;
         float c_gr = 0.f, c_gg = 0.f, c_gb = 0.f;
+        const double gsc = P.g_scale ? P.g_scale[0] : 1.0;      // incoming gradient of a fused loss node (nsr_bwd_args.grad_scale)
         if (c_ok) {
             if (c_act) c_rw = ld4(P.raw + (cray * S + lane) * 4);
-            if (P.d_depth) c_gD = P.d_depth[cray];
-            if (P.d_var) c_gV = P.d_var[cray];
-            if (P.d_rgb) { c_gr = P.d_rgb[cray * 3 + 0]; c_gg = P.d_rgb[cray * 3 + 1]; c_gb = P.d_rgb[cray * 3 + 2]; }
+            if (P.d_depth) c_gD = P.d_depth[cray] * gsc;
+            if (P.d_var) c_gV = P.d_var[cray] * gsc;
+            if (P.d_rgb) { c_gr = P.d_rgb[cray * 3 + 0] * (float)gsc; c_gg = P.d_rgb[cray * 3 + 1] * (float)gsc; c_gb = P.d_rgb[cray * 3 + 2] * (float)gsc; }
             c_dep = P.g_depth[cray];
         }
 #ifdef NSR_X_EARLYWAIT
@@ -735,10 +736,10 @@ NSR_DEV void bwd_pass(const RenderParams &P) {
             float gr = c_gr, gg = c_gg, gb = c_gb;
             if (r != wave) {                                    // further rays of this wave (more rays than waves per group)
                 rw = act ? ld4(P.raw + (ray * S + lane) * 4) : F4{0.f, 0.f, 0.f, 0.f};
-                gD = P.d_depth ? P.d_depth[ray] : 0.0;
-                gV = P.d_var ? P.d_var[ray] : 0.0;
+                gD = P.d_depth ? P.d_depth[ray] * gsc : 0.0;
+                gV = P.d_var ? P.d_var[ray] * gsc : 0.0;
                 gr = gg = gb = 0.f;
-                if (P.d_rgb) { gr = P.d_rgb[ray * 3 + 0]; gg = P.d_rgb[ray * 3 + 1]; gb = P.d_rgb[ray * 3 + 2]; }
+                if (P.d_rgb) { gr = P.d_rgb[ray * 3 + 0] * (float)gsc; gg = P.d_rgb[ray * 3 + 1] * (float)gsc; gb = P.d_rgb[ray * 3 + 2] * (float)gsc; }
                 dep = P.g_depth[ray];
             }
             const double z = act ? zbuf[r * S + lane] : 0.0;

@@ -46,9 +46,10 @@ NSR_KERNEL void comp_bwd_kernel(const RenderParams P) {
     const bool act = lane < S;
     const long long gp = ray * S + (act ? lane : 0);
     const F4 rw = act ? ld4(P.raw + gp * 4) : F4{0.f, 0.f, 0.f, 0.f};
-    const double gD = P.d_depth ? P.d_depth[ray] : 0.0, gV = P.d_var ? P.d_var[ray] : 0.0, dep = P.g_depth[ray];
+    const double sc = P.g_scale ? P.g_scale[0] : 1.0;            // incoming gradient of a fused loss node
+    const double gD = P.d_depth ? P.d_depth[ray] * sc : 0.0, gV = P.d_var ? P.d_var[ray] * sc : 0.0, dep = P.g_depth[ray];
     float gr = 0.f, gg = 0.f, gb = 0.f;
-    if (P.d_rgb) { gr = P.d_rgb[ray * 3 + 0]; gg = P.d_rgb[ray * 3 + 1]; gb = P.d_rgb[ray * 3 + 2]; }
+    if (P.d_rgb) { gr = P.d_rgb[ray * 3 + 0] * (float)sc; gg = P.d_rgb[ray * 3 + 1] * (float)sc; gb = P.d_rgb[ray * 3 + 2] * (float)sc; }
     const double z = act ? P.zvals[gp] : 0.0;
     const Comp cw = comp_weights(rw.w, act, lane);
     const double dz = z - dep;
@@ -136,12 +137,17 @@ NSR_DEV void dx_pass(const RenderParams &P) {
     float *wt = aux + AUX_FLOATS;                            // transposed operand stream of this decoder
     float *stg = wt + packedT_total(KIND);
     float *Sw = stg + wave * kDxStg;
+    // A grid small enough for LDS (the coarse grid: 616 voxels = 79 KB at Replica) takes every block's contributions there
+    // (LDS atomics) and goes to memory once per block: all 32 k samples of a 1024-ray batch hit those 616 voxels, and
+    // same-line memory-side atomics serialise (coarse dX kernel 67 -> see profiles/r03*_c0).
+    float *gl = (KIND == NSR_COARSE && P.lds_grid_floats > 0) ? stg + nw * kDxStg : nullptr;
     const GridDev &G = P.grid[KIND];
     const DecDev &D = P.dec[KIND];
     const bool do_grid = G.dfeat != nullptr;
     if (!do_grid && !PARAMS && !RAYS) return;
     copy_f4<AUX_FLOATS / 4>(aux, D.packed);
     copy_f4<packedT_total(KIND) / 4>(wt, D.packed + AUX_FLOATS + packed_total(KIND));
+    if (gl) for (int i = tid(); i < P.lds_grid_floats; i += nthreads()) gl[i] = 0.f;
     block_sync();
 
     constexpr long long sstride = 256;                       // floats between two slots of a tile
@@ -279,7 +285,7 @@ NSR_DEV void dx_pass(const RenderParams &P) {
         if (RAYS) coord_grad(G, L, g, dc, dux, duy, duz);
         dx_keep(nx);
         if (do_grid && !(P.xflags & 1))
-            scatter_merged(G, L, lane, dc, active, Sw + kDxTx, Sw + kDxTab, (P.xflags & 8) ? (unsigned)(tile * 64 + (lane >> 5) + 1) : 0u);
+            scatter_merged(G, L, lane, dc, active, Sw + kDxTx, Sw + kDxTab, (P.xflags & 8) ? (unsigned)(tile * 64 + (lane >> 5) + 1) : 0u, gl);
         if (RAYS) {
             // d p = d u * (n-1)/2 * 2/(hi-lo) (+ embedding part), fp64 like autograd through Renderer.py:172;
             // d rays_o += d p, d rays_d += d p * z
@@ -312,6 +318,13 @@ NSR_DEV void dx_pass(const RenderParams &P) {
             }
         }
         cur = nx;
+    }
+    if (gl && do_grid) {
+        block_sync();
+        for (int i = tid(); i < P.lds_grid_floats; i += nthreads()) {
+            const float v = gl[i];
+            if (v != 0.f) atomic_add_global(G.dfeat + i, v);
+        }
     }
     if (XYZ && PARAMS) {
         // d _B of this block: sum over the lane groups, then over the waves through LDS (the staging regions are free)

@@ -74,6 +74,7 @@ struct RenderParams {
     long long act_tiles;      // 16-point tiles of the sample-point list (n_points_total rounded up): tile stride of `acts` / `dy`
     // backward only
     const double *d_depth, *d_var, *g_depth;
+    const double *g_scale;    // optional device scalar multiplying d_depth / d_var / d_rgb (nsr_bwd_args.grad_scale)
     const float *d_rgb;
     float *d_rays_o, *d_rays_d;
     float *partials;          // [passes][gridDim.x][max param count]
@@ -95,6 +96,7 @@ struct RenderParams {
     float *dbpart;            // [passes][dx blocks][288]  per-block partial sums of d embedder._B
     int dw_blocks;            // blocks per pass of the dW kernel = partial images per pass
     int xflags;               // measurement switches (NSR_X environment variable; 0 in normal operation)
+    int lds_grid_floats;      // > 0 (coarse stage): the gradient grid (this many floats) is accumulated in the dX block's LDS
     // eval_points only
     const double *points;
     long long n_points;
@@ -398,7 +400,8 @@ NSR_DEV void coord_grad(const GridDev &G, const Lvl &L, int g, const Act<2> &dc,
 //   Tx  : [16][kTxS] floats  dc of the tile, point-major
 //   tab : [16][8] ints (voxel of the class or -1) followed by [16][8] floats (its weight)
 NSR_DEV void scatter_merged(const GridDev &G, const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab,
-                            unsigned salt = 0u) {       // salt != 0: measurement only (NSR_X & 8): spread the voxels, same request count
+                            unsigned salt = 0u,         // salt != 0: measurement only (NSR_X & 8): spread the voxels, same request count
+                            float *lds_grid = nullptr) { // != NULL: the whole gradient grid sits in LDS (small grids, nsr_bwd2.h)
     const int pt = lane & 15, g = lane >> 4;
     int *vt = reinterpret_cast<int *>(tab);
     float *wt = tab + 128;
@@ -427,13 +430,15 @@ NSR_DEV void scatter_merged(const GridDev &G, const Lvl &L, int lane, const Act<
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             if (v[p] != cur) {
-                if (cur >= 0) atomic_add_global(G.dfeat + (long long)(salt ? (int)(((unsigned)cur * 2654435761u + salt * 40503u + (unsigned)(p * 8 + k)) % (unsigned)(G.X * G.Y * G.Z)) : cur) * kC + ch, acc);
+                if (cur >= 0 && lds_grid) atomic_add_lds(lds_grid + cur * kC + ch, acc);
+                else if (cur >= 0) atomic_add_global(G.dfeat + (long long)(salt ? (int)(((unsigned)cur * 2654435761u + salt * 40503u + (unsigned)(p * 8 + k)) % (unsigned)(G.X * G.Y * G.Z)) : cur) * kC + ch, acc);
                 acc = 0.f;
                 cur = v[p];
             }
             acc = fmaf(x[p], w[p], acc);
         }
-        if (cur >= 0) atomic_add_global(G.dfeat + (long long)(salt ? (int)(((unsigned)cur * 2654435761u + salt * 40503u + (unsigned)k) % (unsigned)(G.X * G.Y * G.Z)) : cur) * kC + ch, acc);
+        if (cur >= 0 && lds_grid) atomic_add_lds(lds_grid + cur * kC + ch, acc);
+        else if (cur >= 0) atomic_add_global(G.dfeat + (long long)(salt ? (int)(((unsigned)cur * 2654435761u + salt * 40503u + (unsigned)k) % (unsigned)(G.X * G.Y * G.Z)) : cur) * kC + ch, acc);
     }
     wave_fence();
 }

@@ -211,9 +211,12 @@ class _MappingLossFn(torch.autograd.Function):
             raise RuntimeError("nice_slam_amd: backward through mapping_loss / tracking_loss a second time is not supported (the "
                                "saved buffers are released after the first backward)")
         a, meta, kept, (need_pose, need_grid, need_par), dl_depth, dl_rgb, zero_buf, wm = ctx.state
-        # the loss is the root of the caller's graph (loss.backward(), Mapper.py:503): its incoming gradient is 1
+        # d loss / d outputs were written by the forward for an incoming gradient of 1 (loss.backward(), Mapper.py:503); whatever
+        # autograd hands over (loss * w, loss / n, a GradScaler ...) multiplies them inside the backward kernel: device scalar,
+        # no host sync, no extra launch
+        gs = g_loss.detach().to(device=dl_depth.device, dtype=torch.float64).reshape(1)
         d_o, d_d, d_grids = render_backward(a, meta, kept, (need_pose, need_pose, need_grid, need_par), dl_depth, None, dl_rgb,
-                                            zero_buf=zero_buf)
+                                            zero_buf=zero_buf, grad_scale=gs)
         indices, K, n, crop, intr, shapes, dtypes, devs = wm
         g_pose = [None] * K
         gp, pose_base = None, None
@@ -237,7 +240,7 @@ def mapping_loss(renderer, c, decoders, frames: Sequence[Tuple[torch.Tensor, tor
     ``frames``: ``(c2w, depth [H,W], color [H,W,3])`` per frame of the window, in the reference's order; a pose that requires
     grad gets its gradient (local BA).  Samples ``pixs_per_image`` pixels per frame, applies the bounding-box pre-filter as a
     mask, renders ``stage`` and returns ``sum_{kept, gt>0} |gt - depth| (+ w_color * sum_kept |gt_rgb - rgb|`` in the colour
-    stage) as an fp64 scalar -- call ``.backward()`` on it directly (it must be the root of the backward pass).
+    stage) as an fp64 scalar, an ordinary autograd node (an incoming gradient other than 1 scales every gradient, on the device).
     ``out`` (optional dict) receives the sampled rays, masks and rendered outputs.  ``sharder``: a
     ``nice_slam_amd.parallel.ShardedMapping`` (multi-GPU; use its ``mapping_loss`` method)."""
     if coarse_mapper and stage != "coarse":
@@ -263,7 +266,7 @@ def tracking_loss(renderer, c, decoders, c2w: torch.Tensor, depth: torch.Tensor,
     depth-guided samples, and ``sum_mask |gt - depth| / sqrt(var + 1e-10) (+ w_color * sum_mask |gt_rgb - rgb|)`` with
     ``mask = kept & (gt > 0) (& tmp < 10 * median(tmp))`` -- five launches (index draw, one zero-fill, window kernel, render
     forward, ``nsr_tracking_loss``) and three in the backward (render backward, pose gradient, + the partial sum only if a
-    decoder wants parameter gradients) instead of ~80.  Returns an fp64 scalar; call ``.backward()`` on it directly."""
+    decoder wants parameter gradients) instead of ~80.  Returns an fp64 scalar (an ordinary autograd node: an incoming gradient other than 1 scales the pose gradient)."""
     dev = torch.device(device) if device is not None else depth.device
     H0, H1, W0, W1 = int(ignore_edge_H), renderer.H - int(ignore_edge_H), int(ignore_edge_W), renderer.W - int(ignore_edge_W)
     wmeta, c2ws = _window_meta(H0, H1, W0, W1, n_pixels, renderer.W, renderer.fx, renderer.fy, renderer.cx, renderer.cy,

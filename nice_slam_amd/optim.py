@@ -43,22 +43,40 @@ class MaskedGridAdam:
                 if tuple(m.shape) != tuple(g.shape[2:]):
                     raise _capi.NsrError(f"{k}: voxel mask shape {tuple(m.shape)} != grid {tuple(g.shape[2:])}")
                 m = m.to(device=g.device, dtype=torch.uint8).contiguous()
+            elif capturable:                 # a mask buffer from the start ("every voxel" = all ones): a captured graph holds its
+                m = torch.ones(tuple(g.shape[2:]), dtype=torch.uint8, device=g.device)      # address, set_masks() only rewrites it
             self.masks[k] = m
             self.state[k] = {"step": 0, "exp_avg": torch.zeros_like(g, memory_format=torch.preserve_format),
                              "exp_avg_sq": torch.zeros_like(g, memory_format=torch.preserve_format)}
 
-    def set_masks(self, masks: Optional[Dict[str, Optional[torch.Tensor]]]):
-        """New voxel masks (a new frame's frustum, Mapper.py:315-318); the Adam state is kept."""
+    def reset_state(self):
+        """Zero the moments and the step counts in place (buffers and captured graphs stay valid)."""
+        for st in self.state.values():
+            st["step"] = 0
+            st["exp_avg"].zero_()
+            st["exp_avg_sq"].zero_()
+        if self._dev_steps is not None:
+            self._dev_steps.zero_()
+
+    def set_masks(self, masks: Optional[Dict[str, Optional[torch.Tensor]]], reset_state: bool = True):
+        """New voxel masks for a new mapping frame (its frustum, Mapper.py:315-318).  The reference builds a fresh
+        ``torch.optim.Adam`` inside every ``optimize_map`` call (Mapper.py:368-379), so the Adam state starts from zero with
+        every frame: ``reset_state=True`` (default) does the same in place; ``False`` keeps the moments.  A persistent
+        gradient buffer that is cleared by ``step(zero_grad=True)`` only inside the OLD mask must be zeroed by the caller when
+        the mask changes."""
         for k, g in self.grids.items():
             m = None if masks is None else masks.get(k)
-            if m is not None:
-                if tuple(m.shape) != tuple(g.shape[2:]):
-                    raise _capi.NsrError(f"{k}: voxel mask shape {tuple(m.shape)} != grid {tuple(g.shape[2:])}")
-                if self.masks.get(k) is not None and self.capturable:
-                    self.masks[k].copy_(m.to(device=g.device, dtype=torch.uint8))       # same buffer: captured graphs stay valid
-                    continue
-                m = m.to(device=g.device, dtype=torch.uint8).contiguous()
-            self.masks[k] = m
+            if m is not None and tuple(m.shape) != tuple(g.shape[2:]):
+                raise _capi.NsrError(f"{k}: voxel mask shape {tuple(m.shape)} != grid {tuple(g.shape[2:])}")
+            if self.capturable:                                                         # same buffer: captured graphs stay valid
+                if m is None:
+                    self.masks[k].fill_(1)
+                else:
+                    self.masks[k].copy_(m.to(device=g.device, dtype=torch.uint8))
+                continue
+            self.masks[k] = None if m is None else m.to(device=g.device, dtype=torch.uint8).contiguous()
+        if reset_state:
+            self.reset_state()
 
     def _step_multi(self, lrs, grads, zero_grad):
         lib = _capi.get_lib()

@@ -234,8 +234,9 @@ class ShardedRenderer:
 class ShardedMapping:
     """The mapping iteration sharded over the ranks of a process group (one process per GPU), built on ``mapping_loss``:
 
-    * every rank draws ITS OWN ``pixs_per_image`` pixels per keyframe (independent draws: the union over ranks is the
-      iteration's batch), renders them and forms its partial loss -- nothing is gathered, the loss is a sum over rays;
+    * every rank draws ITS OWN ``pixs_per_image`` pixels per keyframe from a generator seeded per rank (independent draws even
+      when every process seeds torch identically, as the reference does: the union over ranks is the iteration's batch),
+      renders them and forms its partial loss -- nothing is gathered, the loss is a sum over rays;
     * one MAX all-reduce of a single float between the sampling kernel and the render: the bounding-box pre-filter's kept
       rays' maximum depth is a scalar of the WHOLE batch (Renderer.py:109,144) and must agree on every rank;
     * ONE packed SUM all-reduce per iteration carries everything the backward produced: the frustum-selected voxel rows of
@@ -245,12 +246,23 @@ class ShardedMapping:
     The grids, decoders and poses are replicated; after ``loss.backward()`` every rank holds the full-batch gradients (inside
     the voxel masks for the grids), so the replicated optimiser steps stay identical."""
 
-    def __init__(self, renderer, group=None):
+    def __init__(self, renderer, group=None, seed: int = 0):
         self.renderer, self.group = renderer, group
         self._rows = {}
         self._pending = None
         self.last_exchange_floats = 0
         self.last_total_loss = None          # 1-element fp32 tensor: the all-rank loss of the last backward (logging)
+        # The reference seeds every process identically (setup_seed, run.py), so the global generators of all ranks would
+        # draw the SAME pixels and the "union over ranks" would be one batch repeated.  The shard draws therefore come from
+        # a generator of this object, seeded per rank.
+        self.seed = int(seed)
+        self._gen = None
+
+    def _draw(self, n_total: int, n_pixels_crop: int, dev) -> torch.Tensor:
+        if self._gen is None or self._gen.device != dev:
+            self._gen = torch.Generator(device=dev)
+            self._gen.manual_seed(self.seed * 1000003 + 7919 * (dist.get_rank(self.group) + 1))
+        return torch.randint(n_pixels_crop, (n_total,), device=dev, generator=self._gen)
 
     def set_voxel_masks(self, masks):
         """dict grid key -> bool/uint8 [Z,Y,X] voxel mask (``FrustumSelector.voxel_mask``), identical on every rank;
@@ -315,5 +327,8 @@ class ShardedMapping:
         """This rank's share of one mapping iteration (``pixs_per_image`` pixels per frame HERE); returns the rank's partial
         loss -- ``backward()`` leaves the all-rank gradients on every rank (and the all-rank loss in ``last_total_loss``)."""
         from .mapping import mapping_loss
+        if indices is None:                  # this rank's own draw (see __init__): never the global generator
+            dev = frames[0][1].device
+            indices = self._draw(len(frames) * int(pixs_per_image), self.renderer.H * self.renderer.W, dev)
         return mapping_loss(self.renderer, c, decoders, frames, pixs_per_image, stage, w_color=w_color, indices=indices,
                             coarse_mapper=(stage == "coarse"), out=out, sharder=self)

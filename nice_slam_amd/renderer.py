@@ -167,11 +167,13 @@ class _RenderFn(torch.autograd.Function):
         return (None, d_o, d_d, *d_grids, *([None] * len(slots)))
 
 
-def render_backward(a, meta, kept, need, g_depth, g_var, g_rgb, zero_buf=None):
+def render_backward(a, meta, kept, need, g_depth, g_var, g_rgb, zero_buf=None, grad_scale=None):
     """The backward launch of one render call (shared by ``_RenderFn`` and the fused mapping loss, mapping.py).
     ``a``: the forward's argument block; ``need`` = (rays_o, rays_d, per-grid, per-decoder) gradient requests;
     ``g_*``: gradients of the outputs (contiguous, fp64 / fp64 / fp32) or None; ``zero_buf``: an already zero-filled fp32
-    buffer of the size ``backward_buffer_floats`` returns (saves the fill launch).  -> (d_rays_o, d_rays_d, [d_grid ...])."""
+    buffer of the size ``backward_buffer_floats`` returns (saves the fill launch); ``grad_scale``: optional 1-element fp64 device
+    tensor every ``g_*`` is multiplied by inside the kernel (the incoming gradient of a fused loss node).
+    -> (d_rays_o, d_rays_d, [d_grid ...])."""
     lib = _capi.get_lib()
     renderer, decoders, stage, S, reduce_hook = meta
     keep, rays_o, rays_d, gt_depth, grids, flats, packed, raw, depth = kept
@@ -185,6 +187,7 @@ def render_backward(a, meta, kept, need, g_depth, g_var, g_rgb, zero_buf=None):
     b.d_var = g_var.data_ptr() if g_var is not None else None
     b.d_rgb = g_rgb.data_ptr() if g_rgb is not None else None
     b.depth = depth.data_ptr()
+    b.grad_scale = grad_scale.data_ptr() if grad_scale is not None else None
     # every gradient this call produces lives in ONE zero-filled buffer (a single fill kernel): channels-last views for
     # the dense grid gradients, then the ray gradients, then the flat decoder-gradient blob
     need_ray = need_o or need_d

@@ -215,6 +215,106 @@ def replay_mapper(gold, pre, ops):
     return out
 
 
+def replay_mapper_fused(gold, pre, ops):
+    """The same iterations through the entry point the bench times: ``nice_slam_amd.mapping_loss`` (window kernel + render +
+    loss as ONE autograd node, the bounding-box pre-filter as a mask) fed with the RECORDED pixel draws -- compared with what
+    the real Mapper.optimize_map produced (src/Mapper.py:437-503)."""
+    nsa, dev = ops.nsa, ops.dev
+    coarse, ba = pre == "coarse/", pre == "ba/"
+    n_iters = int(gold[pre + "n_iters"])
+    frames = {}
+    i = 0
+    while f"frame/{i}/depth" in gold:
+        frames[i] = (_t(gold[f"frame/{i}/depth"], dev), _t(gold[f"frame/{i}/color"], dev))
+        i += 1
+    order = [int(v) for v in gold[pre + "draw_frames"]]
+    n_sel = 0 if coarse else 1
+    per_iter = (len(order) - n_sel) // n_iters
+    it_frames = order[n_sel:n_sel + per_iter]
+    est = {0: _t(gold[pre + "cur_c2w"], dev)}
+    j = 0
+    while f"{pre}kf/{j}/frame" in gold:
+        est[int(gold[f"{pre}kf/{j}/frame"])] = _t(gold[f"{pre}kf/{j}/est_c2w_in"], dev)
+        j += 1
+    cam_of = {}
+    if ba:
+        kf_ids = [f for f in it_frames if f != 0]
+        oldest = min(kf_ids)
+        cam_of = {f: n for n, f in enumerate([f for f in it_frames if f != oldest])}
+    keys = ("grid_coarse",) if coarse else ("grid_middle", "grid_fine", "grid_color")
+    c = ops.fresh_grids()
+    masks = {k: _t(gold[f"{pre}mask/{k}"], dev).bool()[None, None].expand(c[k].shape) for k in keys}
+    state = {k: c[k][masks[k]].clone() for k in keys}
+    for n_, f in enumerate(sorted(cam_of, key=cam_of.get)):
+        state[f"cam{n_}"] = _t(gold[f"{pre}init/cam{n_}"], dev)
+    dec_col = ops.decoder_tensors("color")
+    for k, p in dec_col.items():
+        state[k] = p.detach().clone()
+    draw = n_sel
+    out = []
+    for it in range(n_iters):
+        stage = stage_of(it, n_iters, coarse)
+        leaves = {}
+        for k in state:
+            if it > 0 and f"{pre}it{it - 1}/after/{k}" in gold:
+                state[k] = _t(gold[f"{pre}it{it - 1}/after/{k}"], dev, state[k].dtype)
+            if k in dec_col:
+                with torch.no_grad():
+                    dec_col[k].copy_(state[k])
+            else:
+                leaves[k] = state[k].clone().requires_grad_(True)
+        for k in keys:
+            val = c[k]
+            val[masks[k]] = leaves[k]
+            c[k] = val
+        ops.zero_decoder_grads()
+        fr, idx = [], []
+        for f in it_frames:
+            depth, color = frames[f]
+            c2w = get_camera_from_tensor(leaves[f"cam{cam_of[f]}"]) if f in cam_of else est[f]
+            fr.append((c2w, depth, color))
+            idx.append(_t(gold[f"{pre}draw/{draw}"], dev))
+            draw += 1
+        info = {}
+        loss = nsa.mapping_loss(ops.renderer, c, ops.dec, fr, int(idx[0].numel()), stage, w_color=0.2, indices=torch.cat(idx),
+                                coarse_mapper=coarse, out=info)
+        loss.backward()
+        grads = {k: v.grad.detach().clone() for k, v in leaves.items() if v.grad is not None}
+        for sub in ("color", "middle", "fine", "coarse"):
+            for k, p in ops.decoder_tensors(sub).items():
+                if p.grad is not None:
+                    grads[k] = p.grad.detach().clone()
+        out.append({"stage": stage, "loss": float(loss.detach()), "grads": grads, "n_rays": int(info["keep"].sum())})
+        for k in keys:
+            val = c[k].detach()
+            val[masks[k]] = leaves[k].clone().detach()
+            c[k] = val
+    return out
+
+
+def replay_tracker_fused(gold, ops):
+    """Tracker.optimize_cam_in_batch through ``nice_slam_amd.tracking_loss`` (one autograd node) with the recorded draws."""
+    nsa, dev = ops.nsa, ops.dev
+    pre = "track/"
+    H0, H1, W0, W1 = (int(v) for v in gold[pre + "crop"])
+    H, W = int(ops.intr[0]), int(ops.intr[1])
+    assert H1 == H - H0 and W1 == W - W0
+    depth_img, color_img = _t(gold["frame/0/depth"], dev), _t(gold["frame/0/color"], dev)
+    c = ops.fresh_grids()
+    out = []
+    for it in range(int(gold[pre + "n_iters"])):
+        cam0 = gold[pre + "init/cam"] if it == 0 else gold[f"{pre}it{it - 1}/after/cam"]
+        cam = _t(cam0, dev).requires_grad_(True)
+        ops.zero_decoder_grads()
+        idx = _t(gold[f"{pre}draw/{it}"], dev)
+        info = {}
+        loss = nsa.tracking_loss(ops.renderer, c, ops.dec, get_camera_from_tensor(cam), depth_img, color_img, int(idx.numel()), H0, W0,
+                                 w_color=0.5, handle_dynamic=True, use_color=True, indices=idx, out=info)
+        loss.backward()
+        out.append({"stage": "color", "loss": float(loss.detach()), "grads": {"cam": cam.grad.detach().clone()}, "n_rays": int(info["keep"].sum())})
+    return out
+
+
 def replay_tracker(gold, ops):
     """Tracker.optimize_cam_in_batch (src/Tracker.py:87-125), teacher-forced on the camera tensor."""
     dev = ops.dev

@@ -134,7 +134,7 @@ class HostScene:
         return out
 
     def backward(self, stage, fwd, d_depth, d_var, d_rgb, want_grid=True, want_params=True, want_rays=True, max_blocks=0,
-                 overwrite_dparams=False):
+                 overwrite_dparams=False, grad_scale=None):
         a, keep, rays_o, rays_d, gt, S = fwd["_ctx"]
         n = rays_o.shape[0]
         res = {}
@@ -161,6 +161,8 @@ class HostScene:
         ws = np.full(max(nws, 1), np.nan, dtype=np.float32)
         b.workspace, b.workspace_floats, b.max_blocks = ptr(ws), nws, max_blocks
         b.overwrite_dparams = 1 if overwrite_dparams else 0
+        gs = None if grad_scale is None else np.array([grad_scale], dtype=np.float64)
+        b.grad_scale = ptr(gs)
         self.lib.check(self.lib.nsr_render_bwd(C.byref(a), C.byref(b), None), "bwd")
         for s in stage_slots(stage):       # back to reference layouts
             if want_grid:

@@ -157,7 +157,26 @@ def ulp_perturbed(sc, seed=1234):
     return out
 
 
-def parity_failures(got, sc, stage, tol=1e-4, backward=True, with_depth=True, rays=None, ref=None, truth_fn=None):
+SECONDARY_LOG = []          # (tag, tensor, err vs fp32 oracle, err vs fp64 truth, reference noise): every tensor that needed the secondary gate
+PRIMARY_ONLY = ("depth", "var", "rgb")      # forward outputs: the 1e-4 gate against the fp32 oracle is mandatory
+_ALLOWED = None
+
+
+def secondary_allowed(tag, tensor):
+    """May `tensor` take the secondary gate in test case `tag`?  tests/golden/secondary_gate.json lists, per case pattern, the
+    tensor patterns that are known to need it (large-bound scenes: every gradient downstream of the fp32 sines; everywhere:
+    the two cancelling bias sums).  A tensor outside the list that misses the primary gate FAILS: a regression that pushes
+    more tensors into the noise-floor gate is not silently absorbed."""
+    global _ALLOWED
+    from fnmatch import fnmatch
+    if _ALLOWED is None:
+        import json
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "secondary_gate.json")
+        _ALLOWED = {k: v for k, v in json.load(open(path)).items() if not k.startswith("_")} if os.path.exists(path) else {}
+    return any(fnmatch(tag, case) and any(fnmatch(tensor, pat) for pat in pats) for case, pats in _ALLOWED.items())
+
+
+def parity_failures(got, sc, stage, tol=1e-4, backward=True, with_depth=True, rays=None, ref=None, truth_fn=None, tag=None):
     """Keys of ``got`` that are NOT at parity with the reference path.
 
     Primary gate, every tensor: max|a-b| / max|b| <= tol against the fp32 oracle (BASELINE.json north_star).
@@ -173,8 +192,12 @@ def parity_failures(got, sc, stage, tol=1e-4, backward=True, with_depth=True, ra
     The reference's noise on a tensor is measured, not assumed: the distance of the fp32 oracle's value to the fp64 truth,
     and the distance to the same truth of the fp32 oracle evaluated on inputs moved by ONE fp32 ulp (``ulp_perturbed``, up to
     three draws) -- whichever is larger (a single fp32 evaluation is one sample of that noise and can land close to the truth by luck).  A
-    tensor passes iff its distance to the truth is at most TWICE that noise: the product may not be noisier than 2x the
-    reference itself.  Where the reference is accurate and stable (noise << tol) this reduces to the primary gate."""
+    tensor passes iff its distance to the truth is at most TWICE that noise AND below 3e-2 outright (the reference's own fp32
+    values reach 1e-2 from the fp64 evaluation on ScanNet-sized scenes): the product may not be
+    noisier than 2x the reference itself.  Where the reference is accurate and stable (noise << tol) this reduces to the
+    primary gate.  The forward outputs (depth, var, rgb) never take the secondary gate.  Every tensor that does is recorded in
+    SECONDARY_LOG (tests/conftest.py writes the list out and prints it), and with a `tag` it must be on the committed list of
+    that test case (``secondary_allowed``) unless NSR_PARITY_COLLECT=1."""
     ref = ref or oracle_render(sc, stage, backward=backward, with_depth=with_depth, rays=rays)
     bad = [k for k in ref if rel_err(got[k], ref[k]) >= tol]
     if not bad:
@@ -183,6 +206,9 @@ def parity_failures(got, sc, stage, tol=1e-4, backward=True, with_depth=True, ra
         oracle_render(sc, stage, backward=backward, with_depth=with_depth, rays=rays, lo=torch.float64)
     out, pert = [], None
     for k in bad:
+        if k in PRIMARY_ONLY:
+            out.append((k, rel_err(got[k], ref[k]), "forward outputs must meet the primary gate"))
+            continue
         e_truth = rel_err(got[k], truth[k])
         e_ref = rel_err(ref[k], truth[k])                       # the reference's own fp32 noise on this tensor ...
         if e_truth > max(2.0 * e_ref, tol) and truth_fn is None:
@@ -191,8 +217,12 @@ def parity_failures(got, sc, stage, tol=1e-4, backward=True, with_depth=True, ra
                 pert = [oracle_render(ulp_perturbed(sc, 1234 + i), stage, backward=backward, with_depth=with_depth, rays=rays)
                         for i in range(n_pert)]
             e_ref = max([e_ref] + [rel_err(p_[k], truth[k]) for p_ in pert])
-        if e_truth > max(2.0 * e_ref, tol):
+        if e_truth > max(2.0 * e_ref, tol) or e_truth >= 3e-2:
             out.append((k, rel_err(got[k], ref[k]), e_truth, e_ref))
+            continue
+        SECONDARY_LOG.append((tag or "?", k, rel_err(got[k], ref[k]), e_truth, e_ref))
+        if tag is not None and os.environ.get("NSR_PARITY_COLLECT") != "1" and not secondary_allowed(tag, k):
+            out.append((k, rel_err(got[k], ref[k]), e_truth, e_ref, "needed the secondary gate but is not on the committed list of " + tag))
     return out
 
 

@@ -230,6 +230,33 @@ def test_frustum_mask(emu, seed):
     assert np.array_equal(out.astype(bool), ref.transpose(2, 1, 0))
 
 
+@pytest.mark.parametrize("pre", ["map/", "ba/"])
+def test_frustum_mask_against_the_real_mappers_masks(emu, pre):
+    """Half a pin for SURVEY §8(f) rank 3: the masks in caller_steps.npz were produced by the REAL Mapper.get_mask_from_c2w
+    (src/Mapper.py:93-164) -- its numpy ``w2c @ p``, projection, depth test and near-camera sphere -- with only ``cv2.remap``
+    replaced by the restatement (OpenCV is absent).  nsr_frustum_mask must reproduce them bit for bit."""
+    import ctypes as C
+    from emu_harness import ptr
+    from oracle import frustum_oracle as fo
+    import caller_replay as cr
+    gold = cr.load()
+    H, W, fx, fy, cx, cy = (float(v) for v in gold["intr"])
+    c2w = gold[pre + "cur_c2w"].astype(np.float64)
+    depth = np.ascontiguousarray(gold["frame/0/depth"], dtype=np.float32)
+    for key in ("grid_middle", "grid_fine", "grid_color"):
+        ref = gold[f"{pre}mask/{key}"].astype(bool)                      # [Z,Y,X]
+        nz, ny, nx = ref.shape
+        xs, ys, zs = fo.voxel_axes(gold["bound"], (nz, ny, nx))
+        w2c = np.ascontiguousarray(np.linalg.inv(c2w)[:3].astype(np.float32))
+        o = np.ascontiguousarray(c2w[:3, 3].astype(np.float32))
+        ws = np.zeros(emu.nsr_frustum_workspace_floats(nx * ny * nz), dtype=np.float32)
+        out = np.full((nz, ny, nx), 7, dtype=np.uint8)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        emu.check(emu.nsr_frustum_mask(fp(w2c), fp(o), fx, fy, cx, cy, int(H), int(W), ptr(depth), ptr(xs), ptr(ys), ptr(zs),
+                                       nx, ny, nz, ptr(ws), ptr(out), None))
+        assert 0 < ref.sum() < ref.size and np.array_equal(out.astype(bool), ref), (pre, key)
+
+
 def test_aabb_keep_matches_reference_expression(emu):
     """the callers' bounding-box pre-filter (Mapper.py:471-481) as a byte mask + kept-ray max depth"""
     import ctypes as C
@@ -620,3 +647,18 @@ def test_saved_activations_equal_the_forward_rerun(emu, stage):
     r2 = sc.backward(stage, fwd, s["w"]["depth"].numpy(), s["w"]["var"].numpy(), s["w"]["rgb"].numpy(), want_params=False, want_grid=False)
     for k in ("d_rays_o", "d_rays_d"):
         assert rel_err(r2[k], res[False][1][k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("stage,acts", [("color", True), ("fine", False), ("coarse", True)])
+def test_grad_scale_multiplies_every_gradient(emu, stage, acts):
+    """nsr_bwd_args.grad_scale (the incoming gradient of a fused loss node, a device scalar): every gradient of the backward
+    is the unscaled one times the scalar -- split kernels (saved activations) and the re-run kernel alike."""
+    s = make_scene(seed=121, n_rays=13, small=True)
+    res = {}
+    for sc_ in (None, -2.5):
+        sc = _host_scene(emu, s["grids"], s["params"], s["bound"].numpy())
+        sc.save_acts = acts
+        fwd = sc.forward(stage, s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy())
+        res[sc_] = sc.backward(stage, fwd, s["w"]["depth"].numpy(), s["w"]["var"].numpy(), s["w"]["rgb"].numpy(), grad_scale=sc_)
+    for k, v in res[None].items():
+        assert rel_err(res[-2.5][k], -2.5 * v) < 1e-5, (stage, k)

@@ -128,7 +128,7 @@ def _map_indices(sc):
     return torch.randint(H * W, (K_FR, 2 * M_PIX), generator=torch.Generator().manual_seed(34))
 
 
-def _map_worker(rank, world, port, masked, q):
+def _map_worker(rank, world, port, masked, q, own_draws=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -141,15 +141,18 @@ def _map_worker(rank, world, port, masked, q):
     sh = ShardedMapping(renderer)
     if masked:
         sh.set_voxel_masks({k: m.to(dev) for k, m in _masks(grids).items()})
-    idx = _map_indices(sc)[:, rank * M_PIX:(rank + 1) * M_PIX].reshape(-1)
+    idx = None if own_draws else _map_indices(sc)[:, rank * M_PIX:(rank + 1) * M_PIX].reshape(-1)
+    torch.manual_seed(1234)                      # every process seeds torch identically, like the reference's setup_seed
     out = {}
     for stage in ("color", "fine"):
         frames = _map_frames(sc, dev, grad=True)
         c = {k: v.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) for k, v in grids.items()}
         for p in dec.parameters():
             p.requires_grad_(True); p.grad = None
-        loss = sh.mapping_loss(c, dec, frames, M_PIX, stage, indices=idx)
+        info = {}
+        loss = sh.mapping_loss(c, dec, frames, M_PIX, stage, indices=idx, out=info)
         loss.backward()
+        out[f"{stage}/indices"] = info["indices"].cpu().numpy().copy()
         out[f"{stage}/loss_total"] = sh.last_total_loss.cpu().numpy().copy()
         out.update({f"{stage}/d_{k}": v.grad.cpu().numpy().copy() for k, v in c.items() if v.grad is not None})
         out.update({f"{stage}/dparam/{k}": p.grad.cpu().numpy().copy() for k, p in dec.named_parameters() if p.grad is not None})
@@ -160,14 +163,17 @@ def _map_worker(rank, world, port, masked, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("masked", [False, True])
-def test_two_ranks_sharded_fused_mapping(masked):
+@pytest.mark.parametrize("masked,own_draws", [(False, False), (True, False), (True, True)])
+def test_two_ranks_sharded_fused_mapping(masked, own_draws):
+    """own_draws: every rank draws its pixels itself (ShardedMapping's per-rank generator; all processes seed torch
+    identically) -- the draws must differ between the ranks, and the all-reduced loss / gradients must be those of ONE GPU
+    rendering the union of the two draws."""
     import nice_slam_amd as nsa
     from scene_util import make_scene, build_product, rel_err
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_map_worker, args=(r, 2, port, masked, q)) for r in range(2)]
+    procs = [ctx.Process(target=_map_worker, args=(r, 2, port, masked, q, own_draws)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in range(2))
@@ -177,8 +183,13 @@ def test_two_ranks_sharded_fused_mapping(masked):
     sc = make_scene(seed=5, n_rays=8, small=True)
     renderer, dec, grids = build_product(sc, "cuda:0")
     masks = _masks(grids)
-    idx = _map_indices(sc).reshape(-1)                               # both ranks' pixels, frame-major
     for stage in ("color", "fine"):
+        # both ranks' pixels, frame-major: [frame][rank 0's draw | rank 1's draw]
+        i0, i1 = (torch.from_numpy(res[r][f"{stage}/indices"]).reshape(K_FR, M_PIX) for r in (0, 1))
+        assert not torch.equal(i0, i1), "the ranks drew the same pixels"
+        idx = torch.cat([i0, i1], 1).reshape(-1)
+        if not own_draws:
+            assert torch.equal(idx, _map_indices(sc).reshape(-1))
         frames = _map_frames(sc, "cuda:0", grad=True)
         c = {k: v.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) for k, v in grids.items()}
         for p in dec.parameters():

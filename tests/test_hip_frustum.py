@@ -56,6 +56,23 @@ def test_frustum_mask_replica_fine_grid():
     assert np.array_equal(got.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("pre", ["map/", "ba/"])
+def test_frustum_mask_against_the_real_mappers_masks(pre):
+    """The masks recorded from the REAL Mapper.get_mask_from_c2w (src/Mapper.py:93-164; only ``cv2.remap`` stubbed by the
+    restatement when the fixture was minted): FrustumSelector must return the same voxels.  Pins numpy's ``w2c @ p``, the
+    projection, the depth test and the near-camera sphere; the row stays "partial" for cv2.remap itself."""
+    import caller_replay as cr
+    import nice_slam_amd as nsa
+    gold = cr.load()
+    H, W, fx, fy, cx, cy = (float(v) for v in gold["intr"])
+    sel = nsa.FrustumSelector(gold["bound"], int(H), int(W), fx, fy, cx, cy)
+    depth = torch.from_numpy(np.ascontiguousarray(gold["frame/0/depth"], dtype=np.float32)).to(DEV)
+    for key in ("grid_middle", "grid_fine", "grid_color"):
+        ref = gold[f"{pre}mask/{key}"].astype(bool)                      # [Z,Y,X]
+        vm = sel.voxel_mask(gold[pre + "cur_c2w"], key, ref.shape, depth)
+        assert np.array_equal(vm.cpu().numpy().astype(bool), ref), (pre, key)
+
+
 def test_frustum_mask_errors():
     from nice_slam_amd._capi import NsrError
     fc = frustum_case(0)

@@ -311,3 +311,99 @@ def test_captured_tracking_iteration_follows_repacked_decoders():
     assert abs(float(loss_g) - float(loss_e)) < 1e-7 * abs(float(loss_e)), (float(loss_g), float(loss_e))
     assert abs(float(loss_g) - before) > 1e-6 * abs(before)     # ... and the new weights really changed the render
     assert rel_err(cam_g, cam_e) < 1e-6
+
+
+@pytest.mark.parametrize("stage", ["coarse", "middle", "fine", "color"])
+def test_fused_mapping_loss_against_the_oracle_at_replica_shape(stage):
+    """The timed entry point itself, not a path equal to it: ``mapping_loss`` at the Replica room0 shape with 5 x 200 rays
+    (BASELINE configs[1]) against the CPU oracle running the reference's iteration -- per-frame ``get_samples``, ``torch.cat``,
+    bounding-box compaction, ``render_batch_ray``, the L1 losses, autograd (src/Mapper.py:437-503) -- on the same pixel
+    draws: the loss, every grid gradient, every decoder parameter gradient and the pose gradients at 1e-4 of the tensor's
+    maximum (a parameter tensor that misses gets the usual second chance against the fp64 evaluation of the same graph)."""
+    import nice_slam_amd as nsa
+    from oracle import nice_oracle as orc
+    sc = make_scene(seed=91, n_rays=8, scene="replica_room0", fine_scale=1.0)
+    H, W, fx, fy, cx, cy = sc["intr"]
+    renderer, dec, grids_dev = build_product(sc, DEV)
+    K, n = 5, 200
+    idx = torch.randint(H * W, (K * n,), generator=torch.Generator().manual_seed(7))
+    frames = _frames(sc, K, DEV, grad=True)
+    c = {k: v.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) for k, v in grids_dev.items()}
+    for p in dec.parameters():
+        p.requires_grad_(True); p.grad = None
+    loss = nsa.mapping_loss(renderer, c, dec, frames, n, stage, w_color=0.2, indices=idx, coarse_mapper=stage == "coarse")
+    loss.backward()
+    got = {"grid/" + k: v.grad for k, v in c.items() if v.grad is not None}
+    got.update({"param/" + k: p.grad for k, p in dec.named_parameters() if p.grad is not None})
+    got.update({f"pose/{k}": f[0].grad for k, f in enumerate(frames)})
+
+    def oracle(lo):
+        grids = {k: v.detach().clone().to(lo).requires_grad_(True) for k, v in sc["grids"].items()}
+        params = {k: v.detach().clone().to(lo).requires_grad_(True) for k, v in sc["params"].items()}
+        poses = [f[0].detach().cpu().clone().requires_grad_(True) for f in frames]
+        parts = [orc.pixel_rays(idx[k * n:(k + 1) * n], 0, H, 0, W, fx, fy, cx, cy, poses[k], frames[k][1].cpu(), frames[k][2].cpu())
+                 for k in range(K)]
+        ro, rd, gd, gc = (torch.cat([p[i] for p in parts]) for i in range(4))
+        with torch.no_grad():                                   # Mapper.py:471-481
+            t = (sc["bound"].unsqueeze(0) - ro.detach().unsqueeze(-1)) / rd.detach().unsqueeze(-1)
+            inside = torch.min(torch.max(t, dim=2)[0], dim=1)[0] >= gd
+        ro, rd, gd, gc = ro[inside], rd[inside], gd[inside], gc[inside]
+        depth, _, color = orc.render_batch_ray(grids, params, rd, ro, stage, None if stage == "coarse" else gd, sc["bound"], lo=lo)
+        dm = gd > 0
+        ls = torch.abs(gd[dm] - depth[dm]).sum()
+        if stage == "color":
+            ls = ls + 0.2 * torch.abs(gc - color).sum()
+        ls.backward()
+        res = {"grid/" + k: v.grad for k, v in grids.items() if v.grad is not None}
+        res.update({"param/" + k: v.grad for k, v in params.items() if v.grad is not None})
+        res.update({f"pose/{k}": p.grad for k, p in enumerate(poses)})
+        return float(ls.detach()), res
+
+    l_ref, ref = oracle(torch.float32)
+    assert abs(float(loss.detach()) - l_ref) < 1e-5 * abs(l_ref), (float(loss.detach()), l_ref)
+    assert set(ref) <= set(got), sorted(set(ref) - set(got))
+    truth = None
+    for k, v in ref.items():
+        e = rel_err(got[k], v)
+        if e < 1e-4:
+            continue
+        assert k.startswith("param/"), (stage, k, e)            # only cancelling parameter sums may need the fp64 evaluation
+        if truth is None:
+            truth = oracle(torch.float64)[1]
+        e_t, e_r = rel_err(got[k], truth[k]), rel_err(v, truth[k])
+        assert e_t <= max(2.0 * e_r, 1e-4), (stage, k, e, e_t, e_r)
+
+
+def test_fused_losses_are_ordinary_autograd_nodes():
+    """(loss * w).backward(), loss / n, a loss that is one term of a larger sum: the incoming gradient of the fused node
+    multiplies every gradient it produces (device scalar, no sync) -- the reference's loss is an ordinary autograd scalar."""
+    import nice_slam_amd as nsa
+    sc = make_scene(seed=83, n_rays=8, small=True)
+    H, W = sc["intr"][:2]
+    renderer, dec, grids_dev = build_product(sc, DEV)
+    K, n = 3, 120
+    idx = torch.randint(H * W, (K * n,), generator=torch.Generator().manual_seed(6))
+
+    def run(w):
+        frames = _frames(sc, K, DEV, grad=True)
+        c = {k: v.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) for k, v in grids_dev.items()}
+        for p in dec.parameters():
+            p.requires_grad_(True); p.grad = None
+        loss = nsa.mapping_loss(renderer, c, dec, frames, n, "color", w_color=0.2, indices=idx)
+        (loss if w is None else (loss * w + 1.0) / 2.0).backward()
+        g = {k: v.grad.clone() for k, v in c.items() if v.grad is not None}
+        g.update({k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None})
+        g.update({f"pose{k}": f[0].grad.clone() for k, f in enumerate(frames)})
+        assert len(g) >= 3 + 30 + K
+        return g
+
+    g1, g3 = run(None), run(-3.0)
+    for k in g1:
+        assert rel_err(g3[k], -1.5 * g1[k]) < 2e-5, k
+    c2w = sc["c2w"][:3].clone().to(DEV).requires_grad_(True)
+    lt = nsa.tracking_loss(renderer, grids_dev, dec, c2w, sc["depth_img"].to(DEV), sc["color_img"].to(DEV), 150, 4, 4, indices=idx[:150] % ((H - 8) * (W - 8)))
+    (0.25 * lt).backward()
+    ga = c2w.grad.clone()
+    c2w.grad = None
+    nsa.tracking_loss(renderer, grids_dev, dec, c2w, sc["depth_img"].to(DEV), sc["color_img"].to(DEV), 150, 4, 4, indices=idx[:150] % ((H - 8) * (W - 8))).backward()
+    assert rel_err(ga, 0.25 * c2w.grad) < 2e-5

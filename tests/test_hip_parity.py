@@ -9,13 +9,14 @@ from scene_util import build_product, hip_render, make_scene, oracle_render, par
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+SIGNATURES = scene_util_signatures = []      # (case, tensor, what): bounded-signature exemptions of the 100k-ray case (reported by conftest)
 STAGES = ("coarse", "middle", "fine", "color")
 
 
 def _compare(got, ref, tag, sc=None, stage=None, **kw):
     assert set(ref) <= set(got), (tag, sorted(set(ref) - set(got)))
     if sc is not None:
-        bad = parity_failures(got, sc, stage, tol=TOL, ref=ref, **kw)      # fp32 gate, then the reference's own noise floor
+        bad = parity_failures(got, sc, stage, tol=TOL, ref=ref, tag=tag, **kw)      # fp32 gate, then the reference's own noise floor
         assert not bad, (tag, bad)
     else:
         for k, v in ref.items():
@@ -145,17 +146,21 @@ def test_synthetic_stress_full_size_vs_oracle():
             n_out = int((err >= TOL).sum())
             print(f"{k}: {n_out} of {err.numel()} rays beyond {TOL}, max {float(err.max()):.2e}, median {float(err.median()):.2e}")
             if n_out <= err.numel() // 10_000 and float(err.max()) < 1e-2:
+                SIGNATURES.append(("stress100k", k, f"{n_out} rays beyond the gate, max {float(err.max()):.2e}"))
                 continue
         elif k.startswith("dparam/") and (k.endswith(".weight") or k.endswith(".bias")):
             err = ((a - b).abs() / b.abs().max()).reshape(a.shape[0], -1).max(1)[0]
             rows = [int(i) for i in torch.nonzero(err >= TOL).flatten()]
             print(f"{k}: output rows beyond {TOL}: {rows}, max {float(err.max()):.2e}, median row {float(err.median()):.2e}")
             if len(rows) <= 1 and float(err.max()) < 1e-3:
+                SIGNATURES.append(("stress100k", k, f"row {rows} beyond the gate, max {float(err.max()):.2e}"))
                 continue
         still.append(k)
+    # the bounded signatures are a budget, not a blank cheque: at most 2 ray tensors and 4 parameter tensors may use them
+    assert sum(1 for s_ in SIGNATURES if s_[1].startswith("d_rays")) <= 2 and sum(1 for s_ in SIGNATURES if s_[1].startswith("dparam/")) <= 4, SIGNATURES
     if still:
         bad = parity_failures({k: got[k] for k in still}, sc, "color", tol=TOL, ref={k: ref[k] for k in still},
-                              truth_fn=lambda: oracle_render_chunked(sc, "color", lo=torch.float64))
+                              truth_fn=lambda: oracle_render_chunked(sc, "color", lo=torch.float64), tag="stress100k")
         assert not bad, bad
 
 

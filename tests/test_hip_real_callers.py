@@ -32,3 +32,26 @@ def test_product_reproduces_real_optimize_cam_in_batch(gold):
     got = cr.replay_tracker(gold, cr.ProductOps(gold))
     bad, n = cr.compare(gold, "track/", got, TOL)
     assert not bad and n == 3, bad
+
+
+@pytest.mark.parametrize("pre", ["map/", "ba/", "coarse/"])
+def test_fused_mapping_loss_reproduces_real_optimize_map(gold, pre):
+    """The entry point bench.py times -- ``mapping_loss``: window kernel, bounding-box MASK instead of compaction, loss and its
+    derivative in the forward epilogue, split backward -- against the same fixtures, fed with the recorded draws."""
+    ops = cr.ProductOps(gold)
+    for p in ops.dec.parameters():
+        p.requires_grad_(True)
+    got = cr.replay_mapper_fused(gold, pre, ops)
+    truth = cr.replay_mapper(gold, pre, cr.OracleOps(gold, lo=torch.float64))
+    bad, n = cr.compare(gold, pre, got, TOL, truth=truth)
+    assert not bad, bad
+    assert n >= {"map/": 30, "ba/": 45, "coarse/": 3}[pre]
+
+
+def test_fused_tracking_loss_reproduces_real_optimize_cam_in_batch(gold):
+    ops = cr.ProductOps(gold)
+    for p in ops.dec.parameters():                  # the tracker works on detached decoders (src/Tracker.py:138)
+        p.requires_grad_(False)
+    got = cr.replay_tracker_fused(gold, ops)
+    bad, n = cr.compare(gold, "track/", got, TOL)
+    assert not bad and n == 3, bad
