@@ -189,15 +189,70 @@ def cpu_baseline(sc, n_rays, stages, weights, track_crop=None):
         loss.backward()
 
     t = {}
+    reps = 3
     for stage in stages:
         once(stage, 64)                                        # warm-up
-        t0 = time.perf_counter()
-        once(stage, n)
-        t[stage] = time.perf_counter() - t0
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            once(stage, n)
+            ts.append(time.perf_counter() - t0)
+        t[stage] = sorted(ts)[reps // 2]
     mix = sum(weights[s] * t[s] for s in stages) / sum(weights.values())
     return {"value": n / mix, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": "oracle (grid_sampler_3d mode) fwd+bwd, %d rays, 1 iteration per stage (%s), weighted like the GPU run"
-                      % (n, ", ".join(f"{s} {t[s]*1e3:.0f} ms" for s in stages))}
+            "sample": "oracle (grid_sampler_3d mode) fwd+bwd, %d rays, median of %d iterations per stage (%s), weighted like the GPU run"
+                      % (n, reps, ", ".join(f"{s} {t[s]*1e3:.0f} ms" for s in stages)),
+            "port_vs_reference": "calibrated in the build container, where both run (tools/calibrate_cpu_baseline.py, "
+                                 "profiles/README.md, 1000 rays at Replica shapes): this port takes 0.87 / 0.72 / 0.97 x the time of "
+                                 "the reference's own Renderer + NICE modules (middle / fine / colour stage), i.e. the reference "
+                                 "itself is up to 1.4x slower than this baseline"}
+
+
+def verify_shards(nsa, shard, renderer, grids, dec, frames, per_frame, stage, H, W, world, rank, dev):
+    """One iteration with pixel draws every rank knows (generator seeded identically, rank r takes columns [r, r+1) * per_frame
+    of a [K, world * per_frame] draw): the sharded result (loss, grid / decoder / pose gradients after the all-reduce) against
+    a single-GPU evaluation of the UNION batch computed redundantly on every rank.  -> {"max_rel_err", "ok", ...}; the worst
+    rank's value is reported (MAX all-reduce)."""
+    K = len(frames)
+    idx = torch.randint(H * W, (K, world * per_frame), generator=torch.Generator().manual_seed(4242))
+
+    def run(fn, indices, n):
+        for g in grids.values():
+            g.grad = None
+        for p in dec.parameters():
+            p.grad = None
+        fr = [(f[0].detach().clone().requires_grad_(True), f[1], f[2]) for f in frames]
+        loss = fn(fr, indices, n)
+        loss.backward()
+        torch.cuda.synchronize()
+        out = {"grid/" + k: g.grad.detach().clone() for k, g in grids.items() if g.grad is not None}
+        out.update({"param/" + k: p.grad.detach().clone() for k, p in dec.named_parameters() if p.grad is not None})
+        out.update({f"pose/{k}": f[0].grad.detach().clone() for k, f in enumerate(fr) if f[0].grad is not None})
+        return loss, out
+
+    _, got = run(lambda fr, i, n: shard.mapping_loss(grids, dec, fr, n, stage, indices=i),
+                 idx[:, rank * per_frame:(rank + 1) * per_frame].reshape(-1).to(dev), per_frame)
+    got_loss = float(shard.last_total_loss.item())
+    masks = dict(shard._rows)                                   # frustum-selected rows: only those are exchanged (and compared)
+    l_ref, ref = run(lambda fr, i, n: nsa.mapping_loss(renderer, grids, dec, fr, n, stage, indices=i),
+                     idx.reshape(-1).to(dev), world * per_frame)
+    worst, worst_key = abs(got_loss - float(l_ref)) / max(abs(float(l_ref)), 1e-30), "loss"
+    for k, v in ref.items():
+        a, b = got[k], v
+        if k.startswith("grid/") and k[5:] in masks:            # voxel rows inside the mask (channels-last: [voxel][32])
+            rows = masks[k[5:]].to(dev)
+            a = a.permute(0, 2, 3, 4, 1).reshape(-1, a.shape[1])[rows]
+            b = b.permute(0, 2, 3, 4, 1).reshape(-1, b.shape[1])[rows]
+        den = float(b.abs().max())
+        e = float((a - b).abs().max()) / den if den > 0 else float(a.abs().max())
+        if e > worst:
+            worst, worst_key = e, k
+    t = torch.tensor([worst], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return {"max_rel_err": float(t.item()), "ok": bool(float(t.item()) < 1e-4), "worst_tensor_on_rank0": worst_key, "stage": stage,
+            "compared": "all-reduced loss + grid (frustum rows) / decoder / pose gradients of the sharded iteration vs one GPU "
+                        "rendering the union batch, tensors: %d" % (len(ref) + 1)}
 
 
 def main():
@@ -210,6 +265,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage", default=None, help="pin every step to one stage (profiling)")
     ap.add_argument("--rays", type=int, default=None, help="rays per iteration (default: the configuration's)")
+    ap.add_argument("--verify-shards", action="store_true",
+                    help="multi-GPU self check after the timed region: one iteration with shared fixed pixel draws, the all-reduced "
+                         "loss / grid / decoder / pose gradients against a single-GPU evaluation of the union batch on every rank")
     ap.add_argument("--eager", action="store_true", help="do not capture the iteration in a hipGraph")
     ap.add_argument("--unfused", action="store_true", help="the drop-in call sequence (get_samples per frame, render_batch_ray, torch loss) instead of mapping_loss")
     ap.add_argument("--stepped-grads-only", action="store_true",
@@ -388,6 +446,8 @@ def main():
         try:
             for st_i in reps:
                 gph = torch.cuda.CUDAGraph()
+                if shard is not None:                            # the ranks' own pixel generator takes part in the capture
+                    gph.register_generator_state(shard.generator(dev))
                 renderer.profile_events = ev_graph.pair_for      # event-record nodes around the backward kernels
                 with torch.cuda.graph(gph):
                     st_name = step(st_i, False)
@@ -431,6 +491,9 @@ def main():
         windows.append(dt)
     dt = sorted(windows)[len(windows) // 2]
     rays_iter = rays_rank * world
+    shard_check = None
+    if args.verify_shards and shard is not None:
+        shard_check = verify_shards(nsa, shard, renderer, grids, dec, frames, per_frame, stages_cfg[-1], H, W, world, rank, dev)
 
     if rank == 0:
         ksum = ev.summary()
@@ -459,9 +522,9 @@ def main():
                                         " (all grid + all decoder grads, like the reference autograd), no optimiser"),
                        "decoder_grads": "none (tracking)" if tracking else ("colour decoder only (what Mapper's optimiser steps)" if args.stepped_grads_only else "all decoders (reference autograd semantics)"),
                        "launch": "hipGraph replay (one captured graph per stage)" if use_graph else "eager",
-                       "activations": ("saved by the forward (704 B per point and decoder) and loaded by the backward where the buffer "
-                                       "stays below %d MB, else the decoder forward is re-run in the backward"
-                                       % (renderer.max_saved_activation_bytes >> 20))
+                       "activations": ("saved by the forward (832 B per point and decoder + 640 B of dY scratch) and consumed by the split "
+                                       "backward (dX + dW kernels) where the buffer stays below %d MB, else the decoder forward is "
+                                       "re-run in the backward" % (renderer.max_saved_activation_bytes >> 20))
                                       if renderer.save_activations else "decoder forward re-run in the backward",
                        "timed_windows_ms": [round(w_ * 1e3, 3) for w_ in windows], "reported": "median window",
                        "parallelism": exchange},
@@ -472,14 +535,20 @@ def main():
             nec = pts * (NEC_MAC[dom] - FWD_MAC[dom]) * 2
             ach = nec / (ms * 1e-3)
             traffic, tsrc = None, None
-            tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")      # from a separate rocprofv3 --pmc run (tools/pmc_summary.py)
-            if os.path.exists(tpath) and args.config == "1" and rays_rank == 1000:
-                tall = json.load(open(tpath))                 # one entry per kernel variant: "<3>" / "<3, false>" re-run, "<3, true>" saved
-                tj = tall.get("nsr::render_bwd_kernel<3, true>", {}) if acts_saved(dom, rays_rank) else \
-                    tall.get("nsr::render_bwd_kernel<3, false>", tall.get("nsr::render_bwd_kernel<3>", {}))
-                traffic, tsrc = tj.get("hbm_bytes_per_launch"), "profiles/r02_traffic.json: " + tj.get("note", "")
-            res["roofline"] = {"bound": "mfma", "kernel": f"render_bwd_kernel<{dom}>", "achieved": ach / 1e12, "peak": FP32_PEAK / 1e12,
+            split = acts_saved(dom, rays_rank)                 # the backward ran as comp_bwd + dX + dW + finalize over saved activations
+            tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")      # from a separate rocprofv3 --pmc run (tools/pmc_bench.sh)
+            if os.path.exists(tpath) and args.config == "1" and rays_rank == 1000 and dom == "color" and split:
+                tall = json.load(open(tpath))                 # one entry per kernel: the backward = the sum over its kernels
+                ks = [k for k in tall if any(n_ in k for n_ in ("render_bwd_dx_kernel<3", "render_bwd_dw_kernel<3", "bwd_finalize", "comp_bwd"))]
+                if ks:
+                    traffic = sum(tall[k]["hbm_bytes_per_launch"] for k in ks)
+                    tsrc = "profiles/r03_traffic.json (" + " + ".join(k.replace("nsr::", "") for k in ks) + "): " + tall[ks[0]].get("note", "")
+            res["roofline"] = {"bound": "mfma",
+                               "kernel": (f"render backward, stage {dom}: comp_bwd + render_bwd_dx_kernel + render_bwd_dw_kernel + "
+                                          "bwd_finalize (split backward over saved activations)") if split else f"render_bwd_kernel<{dom}> (re-run)",
+                               "achieved": ach / 1e12, "peak": FP32_PEAK / 1e12,
                                "unit": "TFLOP/s", "frac": ach / FP32_PEAK, "traffic": traffic, "traffic_source": tsrc,
+                               "traffic_measured_in_this_run": False,
                                "avg_kernel_ms": ms, "launches": cnt,
                                "measured": "HIP events recorded inside nsr_render_bwd on the launch stream around its kernels "
                                            "(compositor backward, dX, dW, finalize; or the one re-run kernel): " + events_from,
@@ -487,11 +556,15 @@ def main():
                                "executed_frac": (pts * (EXEC_BWD_MAC[dom] - (FWD_MAC[dom] if acts_saved(dom, rays_rank) else 0)) * 2
                                                  / (ms * 1e-3)) / FP32_PEAK
                                if not (args.stepped_grads_only or tracking) else None,
-                               "executed_note": "MFMA work the kernel actually issues (dX + dW for every decoder -- the reference "
+                               "executed_note": "MFMA work the backward actually issues (dX + dW for every decoder -- the reference "
                                                 "autograd's semantics -- plus the decoder forward re-run where the activations were not "
                                                 "saved) over the same peak; `frac` counts only the necessary part"}
         if shard is not None:
             res["config"]["grad_exchange_MB_last_iter"] = round(shard.last_exchange_floats * 4 / 1e6, 2)
+            res["rccl_ranks"] = world
+            res["graph_capture"] = "ok" if use_graph else ("off (--eager / NSR_DIST_GRAPH=0)" if args.eager or os.environ.get("NSR_DIST_GRAPH", "1") != "1" else "fell_back")
+        if shard_check is not None:
+            res["shard_check"] = shard_check
         res["kernel_ms"] = {f"render_bwd<{s}>": round(v[0], 4) for s, v in ksum.items()}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(sc, rays_rank, stages_cfg, mix, crop if tracking else None)

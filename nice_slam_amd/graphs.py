@@ -22,7 +22,9 @@ import torch
 
 
 class CapturedStep:
-    def __init__(self, fn: Callable[[], object], warmup: int = 2, device=None):
+    def __init__(self, fn: Callable[[], object], warmup: int = 2, device=None, generators=()):
+        """``generators``: torch.Generator objects ``fn`` draws from besides the device's default one (e.g.
+        ``ShardedMapping.generator(device)``): they are registered with the graph so that every replay draws afresh."""
         self.fn = fn
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         side = torch.cuda.Stream(device=dev)
@@ -33,6 +35,8 @@ class CapturedStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
+        for g in generators:
+            self.graph.register_generator_state(g)
         with torch.cuda.graph(self.graph):
             self.result = fn()                              # static output tensors of the captured iteration
 

@@ -258,11 +258,17 @@ class ShardedMapping:
         self.seed = int(seed)
         self._gen = None
 
-    def _draw(self, n_total: int, n_pixels_crop: int, dev) -> torch.Tensor:
+    def generator(self, dev) -> torch.Generator:
+        """This rank's pixel generator.  A hipGraph that captures ``mapping_loss`` must know it:
+        ``graph.register_generator_state(sharder.generator(device))`` before the capture (every replay then draws afresh)."""
+        dev = torch.device(dev)
         if self._gen is None or self._gen.device != dev:
             self._gen = torch.Generator(device=dev)
             self._gen.manual_seed(self.seed * 1000003 + 7919 * (dist.get_rank(self.group) + 1))
-        return torch.randint(n_pixels_crop, (n_total,), device=dev, generator=self._gen)
+        return self._gen
+
+    def _draw(self, n_total: int, n_pixels_crop: int, dev) -> torch.Tensor:
+        return torch.randint(n_pixels_crop, (n_total,), device=dev, generator=self.generator(dev))
 
     def set_voxel_masks(self, masks):
         """dict grid key -> bool/uint8 [Z,Y,X] voxel mask (``FrustumSelector.voxel_mask``), identical on every rank;
