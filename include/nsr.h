@@ -101,7 +101,8 @@ typedef struct nsr_render_args {
     double *dl_depth;         /* [N]    out, optional */
     float *dl_rgb;            /* [N][3] out, optional */
     float w_color;            /* cfg mapping.w_color_loss */
-    int32_t pad2_;
+    int32_t acts_masks_only;  /* with `acts`: 1 = the backward will want no parameter gradients (tracking), the forward only
+                                 writes the relu masks (1 of the 13 KB per tile and decoder); 0 = everything */
     /* --- optional (ABI 3): saved decoder activations ---------------------------------------------------------------------
      * NULL: nsr_render_bwd re-runs the forward of the decoder it differentiates (24 B/point of saved state).  Non-NULL
      * (nsr_acts_floats(stage, n_rays, n_samples + n_surface) floats, device, uninitialised): nsr_render_fwd also writes the

@@ -140,6 +140,14 @@ int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays,
     P.rays_o = a->rays_o;
     P.rays_d = a->rays_d;
     P.acts = a->acts;
+    P.acts_masks_only = a->acts_masks_only ? 1 : 0;
+    if (!bwd && a->acts && a->loss && a->dl_depth && a->zvals) {
+        // fused mapping loss + activation buffer: the forward's loss epilogue also leaves d raw / positions for the split backward
+        const SplitLayout L = split_layout(P.stage, P.n_rays, P.S);
+        P.draw = a->acts + L.o_draw;
+        P.pf = a->acts + L.o_pf;
+        P.pd = reinterpret_cast<double *>(a->acts + L.o_pd);
+    }
     P.n_points_total = (long long)P.n_rays * P.S;
     P.act_tiles = split_layout(P.stage, P.n_rays, P.S).npad / nsr::kTile;
     P.gt_depth = guided ? a->gt_depth : nullptr;
@@ -225,6 +233,7 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
     P.pf = P.acts + L.o_pf;
     P.pd = reinterpret_cast<double *>(P.acts + L.o_pd);
     P.dw_blocks = G.nimg;
+    if (any_params && P.acts_masks_only) return fail("nsr_render_bwd: the forward saved relu masks only (acts_masks_only); parameter gradients need the full activations");
     static const int xflags = env_int("NSR_X", 0);
     P.xflags = xflags;
     if (any_params) {
@@ -234,7 +243,12 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
         P.dbpart = b->workspace + (long long)passes * G.nimg * P.partial_stride;
     }
     if (b->ev_start) nsr::rt_record(b->ev_start, stream);
-    {
+    // the forward's loss epilogue already wrote d raw (for an incoming gradient of 1) when the caller hands back exactly the
+    // derivative arrays that forward produced; else the compositor backward runs here
+    const bool draw_ready = a->loss && a->dl_depth && b->d_depth == a->dl_depth && !b->d_var &&
+                            (b->d_rgb == nullptr || b->d_rgb == a->dl_rgb) && (P.stage != NSR_STAGE_COLOR || b->d_rgb == a->dl_rgb || !a->gt_color);
+    P.draw_scaled = draw_ready ? 0 : 1;
+    if (!draw_ready) {
         const int tb = 256, rays_per_block = tb / 64;
         NSR_LAUNCH(nsr::comp_bwd_kernel, dim3((unsigned)((P.n_rays + rays_per_block - 1) / rays_per_block)), dim3(tb), 0, stream, P);
     }
@@ -293,7 +307,7 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
             nblocks = nb > nblocks ? nb : nblocks;
         }
         for (int r = rows; r < 3; ++r) R.job[r] = nsr::FinalJob{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
-        NSR_LAUNCH(nsr::bwd_finalize_kernel, dim3(nblocks, rows), dim3(1024), (2048 + 32) * 4, stream, R);
+        NSR_LAUNCH(nsr::bwd_finalize_kernel, dim3(nblocks, rows), dim3(1024), (2048 + 32 + 1024) * 4, stream, R);
     }
     if (b->ev_stop) nsr::rt_record(b->ev_stop, stream);
     return finish("nsr_render_bwd(split)");

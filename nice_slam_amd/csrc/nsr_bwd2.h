@@ -116,6 +116,10 @@ NSR_DEV DxIn dx_load(const RenderParams &P, const float *acts_pass, long long ti
     const double *pp = P.pd + q * 4;
     I.px = pp[0]; I.py = pp[1]; I.pz = pp[2]; I.z = pp[3];
     I.dr = ld4(P.draw + q * 4);
+    if (!P.draw_scaled && P.g_scale) {             // d raw written by the forward's loss epilogue: the incoming gradient applies here
+        const float sc = (float)P.g_scale[0];
+        I.dr.x *= sc; I.dr.y *= sc; I.dr.z *= sc; I.dr.w *= sc;
+    }
     const float *mp = acts_pass + ((q >> 4) * kActSlots + kActMask) * 256 + ((q & 15) * 4 + g) * 4;
     I.m0 = __builtin_bit_cast(unsigned, mp[0]);
     I.m1 = __builtin_bit_cast(unsigned, mp[1]);
@@ -469,8 +473,10 @@ struct DwXyzWave {
     float vb, vb2, vb0[2];     // bias sums: layer WJ, layer W2J (row ROW); layer 0 (kB0)
     float wo[3][2], bo[3], go[3][4];
     float bx, by, bz;          // Fourier matrix column of channel 16 WAVE + i
+    float dscale;              // incoming gradient still to be applied to d raw (see RenderParams.draw_scaled)
 
     NSR_DEV void init(const RenderParams &P, int i) {
+        dscale = (!P.draw_scaled && P.g_scale) ? (float)P.g_scale[0] : 1.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { we[k] = f4zero(); gg[k] = f4zero(); }
         wh[0] = wh[1] = w2[0] = w2[1] = f4zero();
@@ -513,7 +519,7 @@ struct DwXyzWave {
 #pragma unroll
             for (int n = 0; n < NO; ++n)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) o.dn[n][q] = s.dr[(4 * q + g) * 4 + (NOUT == 1 ? 3 : n)];
+                for (int q = 0; q < 4; ++q) o.dn[n][q] = s.dr[(4 * q + g) * 4 + (NOUT == 1 ? 3 : n)] * dscale;
         }
     }
     // the tile's sums; nvalid < 16: the ragged last tile (rows beyond the last point hold whatever the padding holds)
@@ -622,8 +628,9 @@ struct DwNoxWave {
     static constexpr int LJ = WAVE == NW3C ? 3 : (WAVE == NW3H ? 3 : (WAVE == NW4 ? 4 : WAVE));       // layer whose dY this matrix contracts
     static constexpr bool kMat = WAVE < 6, kBias = kMat && WAVE != NW3H, kOut = WAVE == 6;
     f32x4 w[2][2];
-    float vb[2], wo[2], bo;
-    NSR_DEV void init(const RenderParams &, int) {
+    float vb[2], wo[2], bo, dscale;
+    NSR_DEV void init(const RenderParams &P, int) {
+        dscale = (!P.draw_scaled && P.g_scale) ? (float)P.g_scale[0] : 1.f;
 #pragma unroll
         for (int a = 0; a < 2; ++a) { vb[a] = 0.f; wo[a] = 0.f; w[a][0] = f4zero(); w[a][1] = f4zero(); }
         bo = 0.f;
@@ -640,7 +647,7 @@ struct DwNoxWave {
         if (kOut) {
             o.x[0] = gop(s.act + 8 * 256, lane); o.x[1] = gop(s.act + 9 * 256, lane);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o.dn[q] = s.dr[(4 * q + g) * 4 + 3];
+            for (int q = 0; q < 4; ++q) o.dn[q] = s.dr[(4 * q + g) * 4 + 3] * dscale;
         }
     }
     NSR_DEV void consume(Ops &o, int lane, int nvalid) {
@@ -789,7 +796,7 @@ NSR_DEV void final_store(const FinalParams &R, float *p, float v) { *p = R.overw
 
 NSR_KERNEL void bwd_finalize_kernel(const FinalParams R) {
     const FinalJob J = R.job[bid_y()];
-    float *red = reinterpret_cast<float *>(lds_base());            // [2048 + 32] floats
+    float *red = reinterpret_cast<float *>(lds_base());            // [2048 + 32 + 1024] floats
     const int kind = J.kind, cd = cdim_of(kind), nout = nout_of(kind);
     const bool xyz = kind != NSR_COARSE;
     const int dbeg = xyz ? xyz_w(cd, 0) : 0, total = param_total(kind);
@@ -828,6 +835,12 @@ NSR_KERNEL void bwd_finalize_kernel(const FinalParams R) {
     // the colour decoder's 4th output is discarded (decoder.py:341): three rows
     const int nrow = i < 4 ? 32 : (nout == 1 ? 1 : 3), goff = xyz_fcw(cd, i);
     const int e = t & 127, o = e >> 2, c = 4 * chunk + (e & 3), sl = t >> 7;
+    // W[o][k]: pts_linears.(i+1).weight (hidden-state columns) or output_linear.weight -- staged in LDS while the image sums
+    // are in flight (read straight from memory inside the 32-step product it was 32 dependent L2 round trips: ~10 us)
+    const int woff = i < 4 ? xyz_w(cd, i + 1) + (i == 2 ? kE : 0) : xyz_wo(cd);
+    const int wstr = i < 4 ? xyz_in(i + 1) : 32;
+    float *wl = red + 2048 + 32;                                    // [32][32]
+    wl[t] = (t >> 5) < nrow ? J.params[woff + (t >> 5) * wstr + (t & 31)] : 0.f;
     {
         float sg = 0.f;
         if (o < nrow) {
@@ -857,18 +870,15 @@ NSR_KERNEL void bwd_finalize_kernel(const FinalParams R) {
         red[2048 + (t - 256)] = sbv;
     }
     block_sync();
-    // W[o][k]: pts_linears.(i+1).weight (hidden-state columns) or output_linear.weight
-    const int woff = i < 4 ? xyz_w(cd, i + 1) + (i == 2 ? kE : 0) : xyz_wo(cd);
-    const int wstr = i < 4 ? xyz_in(i + 1) : 32;
     if (t < 128) {
         const int k = t >> 2, cc = t & 3;
         float sv = 0.f;
-        for (int oo = 0; oo < nrow; ++oo) sv = fmaf(J.params[woff + oo * wstr + k], red[oo * 4 + cc], sv);
+        for (int oo = 0; oo < nrow; ++oo) sv = fmaf(wl[oo * 32 + k], red[oo * 4 + cc], sv);
         final_store(R, J.dparams + goff + k * cd + 4 * chunk + cc, sv);
     } else if (chunk == 0 && t >= 256 && t < 288) {
         const int k = t - 256;
         float sv = 0.f;
-        for (int oo = 0; oo < nrow; ++oo) sv = fmaf(J.params[woff + oo * wstr + k], red[2048 + oo], sv);
+        for (int oo = 0; oo < nrow; ++oo) sv = fmaf(wl[oo * 32 + k], red[2048 + oo], sv);
         final_store(R, J.dparams + xyz_fcb(cd, i) + k, sv);
     }
 }

@@ -70,6 +70,7 @@ struct RenderParams {
     float *rgb, *raw;
     double *zvals;            // [N][S] saved sample depths (optional)
     float *acts;              // saved decoder activations (optional, see ActSink): the backward then loads h_i / relu masks
+    int acts_masks_only;      // 1: only the relu masks are saved (no parameter gradients will be asked for)
     long long n_points_total; // n_rays * S
     long long act_tiles;      // 16-point tiles of the sample-point list (n_points_total rounded up): tile stride of `acts` / `dy`
     // backward only
@@ -95,6 +96,7 @@ struct RenderParams {
     float *pf;                // [n_points][4]  the position rounded to fp32 (embedding argument)
     float *dbpart;            // [passes][dx blocks][288]  per-block partial sums of d embedder._B
     int dw_blocks;            // blocks per pass of the dW kernel = partial images per pass
+    int draw_scaled;          // 1: `draw` already carries nsr_bwd_args.grad_scale (comp_bwd_kernel ran); 0: the forward wrote it
     int xflags;               // measurement switches (NSR_X environment variable; 0 in normal operation)
     int lds_grid_floats;      // > 0 (coarse stage): the gradient grid (this many floats) is accumulated in the dX block's LDS
     // eval_points only
@@ -637,10 +639,12 @@ constexpr int kActSlots = 13;
 constexpr int kActC = 10, kActMask = 12;
 struct ActSink {
     float *p;                // slot 0 of this lane, NULL for a lane without a point
+    bool full;               // hidden states and features too (false: relu masks only)
     static constexpr long long stride = 256;        // floats between two slots
 };
 NSR_DEV ActSink act_sink(const RenderParams &P, int pass, long long gp, int g) {
     ActSink a;
+    a.full = !P.acts_masks_only;
     a.p = (P.acts && gp >= 0) ? P.acts + (((long long)pass * P.act_tiles + (gp >> 4)) * kActSlots) * 256 + ((gp & 15) * 4 + g) * 4 : nullptr;
     return a;
 }
@@ -681,14 +685,16 @@ NSR_DEV void mlp_xyz_fwd(const float *pk, const float *aux, float px, float py, 
         h.t[1] = acc[1];
         if (KEEP) { kept->h[i] = h; kept->mask[i] = m; }
         if (SAVE) {
-            if (save->p) { st4(save->p + (2 * i) * save->stride, to_F4(h.t[0])); st4(save->p + (2 * i + 1) * save->stride, to_F4(h.t[1])); }
+            if (save->p && save->full) { st4(save->p + (2 * i) * save->stride, to_F4(h.t[0])); st4(save->p + (2 * i + 1) * save->stride, to_F4(h.t[1])); }
             if (i < 4) mpack0 |= m << (8 * i); else mpack1 = m;
         }
     }
     if (SAVE && save->p) {
         st4(save->p + kActMask * save->stride, F4{__builtin_bit_cast(float, mpack0), __builtin_bit_cast(float, mpack1), 0.f, 0.f});
-        st4(save->p + kActC * save->stride, to_F4(c.t[0]));
-        st4(save->p + (kActC + 1) * save->stride, to_F4(c.t[1]));
+        if (save->full) {
+            st4(save->p + kActC * save->stride, to_F4(c.t[0]));
+            st4(save->p + (kActC + 1) * save->stride, to_F4(c.t[1]));
+        }
     }
 #pragma unroll
     for (int n = 0; n < NOUT; ++n) {
@@ -724,14 +730,16 @@ NSR_DEV void mlp_nox_fwd(const float *pk, const float *aux, const Act<2> &c, int
         h.t[1] = acc[1];
         if (KEEP) { kept->h[i] = h; kept->mask[i] = m; }
         if (SAVE) {
-            if (save->p) { st4(save->p + (2 * i) * save->stride, to_F4(h.t[0])); st4(save->p + (2 * i + 1) * save->stride, to_F4(h.t[1])); }
+            if (save->p && save->full) { st4(save->p + (2 * i) * save->stride, to_F4(h.t[0])); st4(save->p + (2 * i + 1) * save->stride, to_F4(h.t[1])); }
             if (i < 4) mpack0 |= m << (8 * i); else mpack1 = m;
         }
     }
     if (SAVE && save->p) {
         st4(save->p + kActMask * save->stride, F4{__builtin_bit_cast(float, mpack0), __builtin_bit_cast(float, mpack1), 0.f, 0.f});
-        st4(save->p + kActC * save->stride, to_F4(c.t[0]));
-        st4(save->p + (kActC + 1) * save->stride, to_F4(c.t[1]));
+        if (save->full) {
+            st4(save->p + kActC * save->stride, to_F4(c.t[0]));
+            st4(save->p + (kActC + 1) * save->stride, to_F4(c.t[1]));
+        }
     }
     const F4 w0 = ld4(aux + AUX_WO + 4 * g), w1 = ld4(aux + AUX_WO + 16 + 4 * g);
     float s = w0.x * h.t[0][0];
@@ -899,26 +907,61 @@ NSR_KERNEL NSR_BOUNDS(768) void render_fwd_kernel(const RenderParams P) {
                 P.depth[rayq] = depth;
                 P.var[rayq] = var;
                 P.rgb[rayq * 3 + 0] = cr; P.rgb[rayq * 3 + 1] = cg; P.rgb[rayq * 3 + 2] = cb;
-                if (P.loss) {
-                    // Mapper.py:487-493 on the rays the pre-filter keeps, and its derivative w.r.t. this ray's outputs:
-                    // d|gt - depth| = sign(depth - gt) where gt > 0, w_color * sign(rgb - gt_rgb) in the colour stage
-                    const bool kp = !P.keep || P.keep[rayq];
-                    const float gd = P.loss_depth ? P.loss_depth[rayq] : 0.f;
-                    double gD = 0.0;
-                    float g3[3] = {0.f, 0.f, 0.f};
-                    if (kp && gd > 0.f) {
-                        const double df = depth - (double)gd;
-                        loss_acc += fabs(df);
-                        gD = df > 0.0 ? 1.0 : (df < 0.0 ? -1.0 : 0.0);
-                    }
-                    if (kp && STAGE == NSR_STAGE_COLOR && P.gt_color) {
-                        const float e[3] = {cr - P.gt_color[rayq * 3 + 0], cg - P.gt_color[rayq * 3 + 1], cb - P.gt_color[rayq * 3 + 2]};
-                        loss_acc += (double)(P.w_color * ((fabsf(e[0]) + fabsf(e[1])) + fabsf(e[2])));
+            }
+            if (P.loss) {
+                // Mapper.py:487-493 on the rays the pre-filter keeps, and its derivative w.r.t. this ray's outputs:
+                // d|gt - depth| = sign(depth - gt) where gt > 0, w_color * sign(rgb - gt_rgb) in the colour stage
+                // (every lane of the wave evaluates the same scalars; lane 0 publishes them)
+                const bool kp = !P.keep || P.keep[rayq];
+                const float gd = P.loss_depth ? P.loss_depth[rayq] : 0.f;
+                double gD = 0.0, lterm = 0.0;
+                float g3[3] = {0.f, 0.f, 0.f};
+                if (kp && gd > 0.f) {
+                    const double df = depth - (double)gd;
+                    lterm += fabs(df);
+                    gD = df > 0.0 ? 1.0 : (df < 0.0 ? -1.0 : 0.0);
+                }
+                if (kp && STAGE == NSR_STAGE_COLOR && P.gt_color) {
+                    const float e[3] = {cr - P.gt_color[rayq * 3 + 0], cg - P.gt_color[rayq * 3 + 1], cb - P.gt_color[rayq * 3 + 2]};
+                    lterm += (double)(P.w_color * ((fabsf(e[0]) + fabsf(e[1])) + fabsf(e[2])));
 #pragma unroll
-                        for (int q = 0; q < 3; ++q) g3[q] = e[q] > 0.f ? P.w_color : (e[q] < 0.f ? -P.w_color : 0.f);
-                    }
+                    for (int q = 0; q < 3; ++q) g3[q] = e[q] > 0.f ? P.w_color : (e[q] < 0.f ? -P.w_color : 0.f);
+                }
+                if (lane == 0) {
+                    loss_acc += lterm;
                     if (P.dl_depth) P.dl_depth[rayq] = gD;
                     if (P.dl_rgb) { P.dl_rgb[rayq * 3 + 0] = g3[0]; P.dl_rgb[rayq * 3 + 1] = g3[1]; P.dl_rgb[rayq * 3 + 2] = g3[2]; }
+                }
+                if (P.draw) {
+                    // ... and, for the split backward (nsr_bwd2.h), what its compositor-backward kernel would compute from
+                    // them: d raw per sample, the sample's position and bound test -- one launch fewer per iteration.  Same
+                    // expressions as comp_bwd_kernel (d var = 0).
+                    const double dzc = zq - depth;
+                    const double s1 = wave_sum_d((double)c.w * dzc);
+                    const float Gz = (float)(gD * zq + 0.0 * (dzc * dzc - 2.0 * s1 * zq));
+                    const float Gw = Gz + fmaf(g3[2], rw.z, fmaf(g3[1], rw.y, g3[0] * rw.x));
+                    float v = act ? Gw * c.w : 0.f;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const float o_ = shfl_down(v, d);
+                        if (lane + d < 64) v += o_;
+                    }
+                    float suffix = shfl_down(v, 1);
+                    if (lane == 63) suffix = 0.f;
+                    const float dalpha = Gw * c.T - suffix / c.t;
+                    float docc = 10.f * (dalpha * ((1.f - c.alpha) * c.alpha));
+                    const double qx = (double)P.rays_o[rayq * 3 + 0] + (double)P.rays_d[rayq * 3 + 0] * zq;
+                    const double qy = (double)P.rays_o[rayq * 3 + 1] + (double)P.rays_d[rayq * 3 + 1] * zq;
+                    const double qz = (double)P.rays_o[rayq * 3 + 2] + (double)P.rays_d[rayq * 3 + 2] * zq;
+                    const bool ins = (qx > P.blo[0]) && (qx < P.bhi[0]) && (qy > P.blo[1]) && (qy < P.bhi[1]) && (qz > P.blo[2]) && (qz < P.bhi[2]);
+                    if (!ins) docc = 0.f;
+                    if (act) {
+                        const long long gq = rayq * S + lane;
+                        st4(P.draw + gq * 4, F4{c.w * g3[0], c.w * g3[1], c.w * g3[2], docc});
+                        double *pq = P.pd + gq * 4;
+                        pq[0] = qx; pq[1] = qy; pq[2] = qz; pq[3] = zq;
+                        st4(P.pf + gq * 4, F4{(float)qx, (float)qy, (float)qz, 0.f});
+                    }
                 }
             }
         }

@@ -186,7 +186,7 @@ class _MappingLossFn(torch.autograd.Function):
         if track is None:                                       # the mapper's L1 loss is accumulated by the forward kernel itself
             a.gt_color, a.keep, a.loss, a.w_color = gt_color.data_ptr(), keep.data_ptr(), loss.data_ptr(), float(w_color)
             a.dl_depth, a.dl_rgb = dl_depth.data_ptr(), dl_rgb.data_ptr()
-        acts = renderer._attach_acts(a, stage, N, S, dev) if need_bwd else None
+        acts = renderer._attach_acts(a, stage, N, S, dev, masks_only=not any(need_par)) if need_bwd else None
         lib.check(lib.nsr_render_fwd(C.byref(a), stream), "nsr_render_fwd")
         if track is not None:                                   # the tracker's loss needs the batch median of the rendered outputs
             lib.check(lib.nsr_tracking_loss(N, gt_depth.data_ptr(), gt_color.data_ptr(), keep.data_ptr(), depth.data_ptr(), var.data_ptr(),

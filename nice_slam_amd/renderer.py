@@ -141,7 +141,8 @@ class _RenderFn(torch.autograd.Function):
         a.zvals = zsave.data_ptr() if zsave is not None else None
         keep.append(zsave)
         if need_bwd:
-            keep.append(renderer._attach_acts(a, stage, n, S, dev))
+            n_sl = len(slots)
+            keep.append(renderer._attach_acts(a, stage, n, S, dev, masks_only=not any(ctx.needs_input_grad[3 + n_sl:3 + 2 * n_sl])))
         lib.check(lib.nsr_render_fwd(C.byref(a), stream), "nsr_render_fwd")
         if need_bwd:
             # `depth` is an OUTPUT: kept as a detached alias (same storage, different tensor object), so that no reference
@@ -373,8 +374,9 @@ class Renderer(object):
                 self._gt_max = None
         return _RenderFn.apply(meta, rays_o, rays_d, *[grids[s] for s in slots], *gates)
 
-    def _attach_acts(self, a, stage, n, S, dev):
-        """allocate the activation buffer of a differentiable forward and point the argument block at it (None: re-run)"""
+    def _attach_acts(self, a, stage, n, S, dev, masks_only=False):
+        """allocate the activation buffer of a differentiable forward and point the argument block at it (None: re-run);
+        ``masks_only``: no decoder will want parameter gradients (tracking) -- the forward then only writes the relu masks"""
         if not self.save_activations:
             return None
         nfl = _capi.get_lib().nsr_acts_floats(_capi.STAGE_ID[stage], n, S)
@@ -382,6 +384,7 @@ class Renderer(object):
             return None
         acts = torch.empty((nfl,), dtype=torch.float32, device=dev)
         a.acts = acts.data_ptr()
+        a.acts_masks_only = 1 if masks_only else 0
         return acts
 
     def render_img(self, c, decoders, c2w, device, stage, gt_depth=None):

@@ -110,7 +110,10 @@ class HostScene:
             a.dec[i].params, a.dec[i].packed = ptr(self.flat[s]), ptr(self.packed[s])
         return a
 
-    def forward(self, stage, rays_o, rays_d, gt_depth):
+    def forward(self, stage, rays_o, rays_d, gt_depth, fused_loss=None):
+        """fused_loss: None or {"gt_color": [n,3], "keep": uint8 [n] or None, "w_color": float}: the mapper's L1 loss in the
+        forward (out["loss"], out["dl_depth"], out["dl_rgb"]); with an activation buffer the forward then also leaves d raw for
+        the split backward (backward(..., from_forward=True) hands the same arrays back)."""
         keep = []
         rays_o = np.ascontiguousarray(rays_o, dtype=np.float32)
         rays_d = np.ascontiguousarray(rays_d, dtype=np.float32)
@@ -129,12 +132,20 @@ class HostScene:
             nfl = self.lib.nsr_acts_floats(_capi.STAGE_ID[stage], n, S)
             out["acts"] = np.full((max(1, nfl),), np.nan, dtype=np.float32)
             a.acts = ptr(out["acts"])
+            a.acts_masks_only = 1 if getattr(self, "acts_masks_only", False) else 0
+        if fused_loss is not None:
+            out["loss"], out["dl_depth"], out["dl_rgb"] = np.zeros(1), np.full(n, np.nan), np.full((n, 3), np.nan, dtype=np.float32)
+            gcol = np.ascontiguousarray(fused_loss["gt_color"], dtype=np.float32)
+            kp = None if fused_loss.get("keep") is None else np.ascontiguousarray(fused_loss["keep"], dtype=np.uint8)
+            keep += [gcol, kp]
+            a.gt_color, a.keep, a.loss, a.w_color = ptr(gcol), ptr(kp), ptr(out["loss"]), float(fused_loss.get("w_color", 0.2))
+            a.dl_depth, a.dl_rgb = ptr(out["dl_depth"]), ptr(out["dl_rgb"])
         self.lib.check(self.lib.nsr_render_fwd(C.byref(a), None), "fwd")
         out["_ctx"] = (a, keep, rays_o, rays_d, gt, S)
         return out
 
     def backward(self, stage, fwd, d_depth, d_var, d_rgb, want_grid=True, want_params=True, want_rays=True, max_blocks=0,
-                 overwrite_dparams=False, grad_scale=None):
+                 overwrite_dparams=False, grad_scale=None, from_forward=False):
         a, keep, rays_o, rays_d, gt, S = fwd["_ctx"]
         n = rays_o.shape[0]
         res = {}
@@ -149,9 +160,12 @@ class HostScene:
                 res["d_flat_" + s] = np.full_like(self.flat[s], np.nan) if overwrite_dparams else np.zeros_like(self.flat[s])
                 a.dec[i].dparams = ptr(res["d_flat_" + s])
         b = _capi.NsrBwdArgs()
-        dd = np.ascontiguousarray(d_depth, dtype=np.float64)
-        dv = None if d_var is None else np.ascontiguousarray(d_var, dtype=np.float64)
-        dr = None if d_rgb is None else np.ascontiguousarray(d_rgb, dtype=np.float32)
+        if from_forward:            # exactly the derivative arrays the fused forward wrote (same pointers: no comp_bwd launch)
+            dd, dv, dr = fwd["dl_depth"], None, (fwd["dl_rgb"] if stage == "color" else None)
+        else:
+            dd = np.ascontiguousarray(d_depth, dtype=np.float64)
+            dv = None if d_var is None else np.ascontiguousarray(d_var, dtype=np.float64)
+            dr = None if d_rgb is None else np.ascontiguousarray(d_rgb, dtype=np.float32)
         b.d_depth, b.d_var, b.d_rgb, b.depth = ptr(dd), ptr(dv), ptr(dr), ptr(fwd["depth"])
         if want_rays:
             res["d_rays_o"] = np.zeros((n, 3), dtype=np.float32)

@@ -647,6 +647,15 @@ def test_saved_activations_equal_the_forward_rerun(emu, stage):
     r2 = sc.backward(stage, fwd, s["w"]["depth"].numpy(), s["w"]["var"].numpy(), s["w"]["rgb"].numpy(), want_params=False, want_grid=False)
     for k in ("d_rays_o", "d_rays_d"):
         assert rel_err(r2[k], res[False][1][k]) < 1e-5, k
+    # ... and needs the relu masks only (nsr_render_args.acts_masks_only: 1 of the 13 KB per tile and decoder is written)
+    sc = _host_scene(emu, s["grids"], s["params"], s["bound"].numpy())
+    sc.acts_masks_only = True
+    fwd = sc.forward(stage, s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy())
+    r3 = sc.backward(stage, fwd, s["w"]["depth"].numpy(), s["w"]["var"].numpy(), s["w"]["rgb"].numpy(), want_params=False, want_grid=True)
+    for k, v in r3.items():
+        assert rel_err(v, res[False][1][k]) < 1e-5, k
+    with pytest.raises(Exception, match="masks only"):
+        sc.backward(stage, fwd, s["w"]["depth"].numpy(), s["w"]["var"].numpy(), s["w"]["rgb"].numpy(), want_params=True)
 
 
 @pytest.mark.parametrize("stage,acts", [("color", True), ("fine", False), ("coarse", True)])
@@ -662,3 +671,26 @@ def test_grad_scale_multiplies_every_gradient(emu, stage, acts):
         res[sc_] = sc.backward(stage, fwd, s["w"]["depth"].numpy(), s["w"]["var"].numpy(), s["w"]["rgb"].numpy(), grad_scale=sc_)
     for k, v in res[None].items():
         assert rel_err(res[-2.5][k], -2.5 * v) < 1e-5, (stage, k)
+
+
+@pytest.mark.parametrize("stage", ["coarse", "fine", "color"])
+def test_fused_forward_leaves_d_raw_for_the_split_backward(emu, stage):
+    """Fused mapping loss + activation buffer: the forward's loss epilogue writes d raw / positions itself and nsr_render_bwd,
+    handed back the very derivative arrays of that forward, skips its compositor-backward kernel -- same gradients as the
+    backward that is given copies of those arrays (and therefore runs comp_bwd_kernel), also under a grad_scale."""
+    s = make_scene(seed=122, n_rays=21, small=True)
+    g = torch.Generator().manual_seed(5)
+    keep = (torch.rand((21,), generator=g) < 0.8).numpy().astype(np.uint8)
+    fl = {"gt_color": s["gt_color"].numpy(), "keep": keep, "w_color": 0.2}
+    res = {}
+    for mode in ("forward", "comp_bwd"):
+        sc = _host_scene(emu, s["grids"], s["params"], s["bound"].numpy())
+        fwd = sc.forward(stage, s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy(), fused_loss=fl)
+        assert np.isfinite(fwd["dl_depth"]).all() and fwd["loss"][0] > 0
+        if mode == "forward":
+            res[mode] = sc.backward(stage, fwd, None, None, None, from_forward=True, grad_scale=1.75)
+        else:
+            res[mode] = sc.backward(stage, fwd, fwd["dl_depth"].copy(), None, fwd["dl_rgb"].copy() if stage == "color" else None, grad_scale=1.75)
+    assert set(res["forward"]) == set(res["comp_bwd"])
+    for k, v in res["comp_bwd"].items():
+        assert rel_err(res["forward"][k], v) < 1e-5, (stage, k)
