@@ -125,4 +125,4 @@ def test_kernel_register_budget():
     for k, v in dw.items():
         assert v["occupancy_waves_per_simd"] >= 3 and v["scratch_bytes_per_lane"] == 0, (k, v)
     for k, v in fwd.items():
-        assert v["occupancy_waves_per_simd"] >= 3 and v["scratch_bytes_per_lane"] <= 64, (k, v)
+        assert v["occupancy_waves_per_simd"] >= 3 and v["scratch_bytes_per_lane"] <= 96, (k, v)
