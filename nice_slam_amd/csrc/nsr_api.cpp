@@ -82,7 +82,7 @@ SplitLayout split_layout(int stage, long long n_rays, int S) {
 // launch geometry: the dX kernel runs `nb` blocks of `waves` waves per decoder pass (one block per CU over all passes,
 // fewer waves per block when the batch is small: every CU gets work); the dW kernel `nimg` blocks per pass, each of which
 // leaves one partial image of the gradient blob.
-struct SplitGeo { int nb, waves, nimg; };
+struct SplitGeo { int nb, waves, nimg; };             // dX: blocks per pass, waves per block; dW: images per pass
 int env_int(const char *name, int dflt) {
     const char *e = getenv(name);
     return (e && e[0]) ? atoi(e) : dflt;
@@ -357,6 +357,9 @@ int nsr_pack_params(int slot, const float *params, float *packed, void *stream) 
 int nsr_render_fwd(const nsr_render_args *a, void *stream) {
     nsr::RenderParams P;
     if (int rc = build_params(a, P, true)) return rc;
+#ifdef NSR_TS
+    if (const char *e = getenv("NSR_DBG_FWD_PTR")) P.dbg = reinterpret_cast<long long *>(strtoull(e, nullptr, 16));
+#endif
     if (!a->depth || !a->var || !a->rgb) return fail("nsr_render_fwd: null output pointer");
     if (P.n_rays == 0) return 0;
     const int npts = P.rays_per_block * P.S;

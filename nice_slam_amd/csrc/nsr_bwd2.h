@@ -34,7 +34,6 @@ constexpr int kDxMaxWaves = 12;
 constexpr int kDxTx = 0, kDxTab = kTile * kTxS, kDxP = kDxTab + 256, kDxDP = kDxP + 48, kDxStg = kDxDP + 48;
 static_assert(kDxStg % 4 == 0, "staging regions must stay 16-byte aligned");
 constexpr int kDbPart = 288;                  // d _B partial image of a dX block: [3][96]
-
 // ------------------------------------------------------------------------------------------------
 // compositor backward, one wave per ray (lane = sample): d raw, fp64 sample position, bound test
 // ------------------------------------------------------------------------------------------------
@@ -135,7 +134,7 @@ NSR_DEV void dx_pass(const RenderParams &P) {
     constexpr bool XYZ = KIND != NSR_COARSE;
     constexpr int NOUT = nout_of(KIND);
     char *lds = lds_base();
-    const int lane = tid() & 63, wave = tid() >> 6, nw = nthreads() >> 6;
+    const int lane = tid() & 63, wave = uniform(tid() >> 6), nw = nthreads() >> 6;
     const int pt = lane & 15, g = lane >> 4;
     float *aux = reinterpret_cast<float *>(lds);
     float *wt = aux + AUX_FLOATS;                            // transposed operand stream of this decoder
@@ -149,10 +148,13 @@ NSR_DEV void dx_pass(const RenderParams &P) {
     const DecDev &D = P.dec[KIND];
     const bool do_grid = G.dfeat != nullptr;
     if (!do_grid && !PARAMS && !RAYS) return;
+    const Dbg dbg{P.dbg ? P.dbg + (((long long)bid_y() * nblk_x() + bid_x()) * kDxMaxWaves + wave) * 64 : nullptr};
+    dbg.stamp(0);
     copy_f4<AUX_FLOATS / 4>(aux, D.packed);
     copy_f4<packedT_total(KIND) / 4>(wt, D.packed + AUX_FLOATS + packed_total(KIND));
     if (gl) for (int i = tid(); i < P.lds_grid_floats; i += nthreads()) gl[i] = 0.f;
     block_sync();
+    dbg.stamp(1);
 
     constexpr long long sstride = 256;                       // floats between two slots of a tile
     const float *acts_pass = P.acts + (long long)act_pass(KIND) * P.act_tiles * kActSlots * 256;
@@ -174,6 +176,7 @@ NSR_DEV void dx_pass(const RenderParams &P) {
         const bool has_next = tile + tstep < ntiles;
         DxIn nx = cur;
         if (has_next) nx = dx_load(P, acts_pass, tile + tstep, pt, g);
+        dbg.stamp(2);
         const long long gp = tile * kTile + pt;
         const bool active = cur.act;
         const float px = (float)cur.px, py = (float)cur.py, pz = (float)cur.pz;       // decoder.py:189
@@ -223,6 +226,7 @@ NSR_DEV void dx_pass(const RenderParams &P) {
             }
         }
         // ---- embedding backward: dE = W0^T dY0 + W3e^T dY3, d arg = dE cos(arg); d p (rays) and d _B (parameters)
+        dbg.stamp(3);
         float dpe[3] = {0.f, 0.f, 0.f};
         if (XYZ && PARAMS && !(P.xflags & 4)) {
             // "lane = channel" form: swapping the MFMA operands (A = dY registers, B = transposed stream) yields
@@ -283,13 +287,15 @@ NSR_DEV void dx_pass(const RenderParams &P) {
             dpe[0] = red_g(ax); dpe[1] = red_g(ay); dpe[2] = red_g(az);
         }
         // ---- grid: coordinate gradient, scatter; ray gradients
+        dbg.stamp(4);
         Lvl L;
         if (need_dc) L = make_level(G, cur.px, cur.py, cur.pz);
         float dux = 0.f, duy = 0.f, duz = 0.f;
         if (RAYS) coord_grad(G, L, g, dc, dux, duy, duz);
         dx_keep(nx);
-        if (do_grid && !(P.xflags & 1))
-            scatter_merged(G, L, lane, dc, active, Sw + kDxTx, Sw + kDxTab, (P.xflags & 8) ? (unsigned)(tile * 64 + (lane >> 5) + 1) : 0u, gl);
+        dbg.stamp(5);
+        if (do_grid && !(P.xflags & 1)) scatter_merged(G, L, lane, dc, active, Sw + kDxTx, Sw + kDxTab, gl);
+        dbg.stamp(6);
         if (RAYS) {
             // d p = d u * (n-1)/2 * 2/(hi-lo) (+ embedding part), fp64 like autograd through Renderer.py:172;
             // d rays_o += d p, d rays_d += d p * z
@@ -322,7 +328,9 @@ NSR_DEV void dx_pass(const RenderParams &P) {
             }
         }
         cur = nx;
+        dbg.stamp(7);
     }
+    dbg.stamp(8);
     if (gl && do_grid) {
         block_sync();
         for (int i = tid(); i < P.lds_grid_floats; i += nthreads()) {
@@ -349,6 +357,7 @@ NSR_DEV void dx_pass(const RenderParams &P) {
             part[t] = s;
         }
     }
+    dbg.stamp(9);
 }
 
 // grid = (blocks per pass, decoder passes of the stage); a block stages ONE decoder's transposed stream and walks the tiles
@@ -413,6 +422,7 @@ NSR_DEV DwSrc dw_src(const float *slot) {
 template <int KIND>
 NSR_DEV void dw_issue(const RenderParams &P, long long tile, float *slot, int lane) {
     typedef DwLay<KIND> Y;
+    if (P.xflags & 16) tile &= 3;                                 // measurement: operands from cache-resident tiles
     // a tile's dY (10 KB) and its hidden states + features (12 KB) are contiguous spans in memory: piece n = the n-th KB
     const float *dt = P.dy + ((long long)act_pass(KIND) * P.act_tiles + tile) * (kDySlots * 256);
     const float *at = P.acts + ((long long)act_pass(KIND) * P.act_tiles + tile) * (kActSlots * 256);

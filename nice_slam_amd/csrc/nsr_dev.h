@@ -107,12 +107,15 @@ template <int N> NSR_DEV void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::
 // LDS flag words between the waves of a block (producer / consumer hand-offs without a block barrier): a store that orders
 // the wave's earlier LDS traffic before it, a load that orders the later traffic after it, and the pause of a polling loop.
 // (The asm "memory" clobbers keep the compiler from moving LDS accesses across; LDS operations of one wave execute in order.)
+// The words live in LDS and are accessed as such (ds_write_b32 / ds_read_b32): through a generic pointer the compiler emits
+// flat accesses, whose completion is counted by vmcnt -- a polling loader would drain its own DMA queue on every poll.
+typedef __attribute__((address_space(3))) int lds_int;
 NSR_DEV void flag_store(int *p, int v) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    *reinterpret_cast<volatile int *>(p) = v;
+    *(volatile lds_int *)p = v;
 }
 NSR_DEV int flag_load(const int *p) {
-    const int v = *reinterpret_cast<const volatile int *>(p);
+    const int v = *(const volatile lds_int *)p;
     asm volatile("" ::: "memory");
     return v;
 }

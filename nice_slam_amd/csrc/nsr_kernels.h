@@ -401,9 +401,8 @@ NSR_DEV void coord_grad(const GridDev &G, const Lvl &L, int g, const Act<2> &dc,
 // of 396 k voxel updates per 1000 colour-stage rays of the bench scene).
 //   Tx  : [16][kTxS] floats  dc of the tile, point-major
 //   tab : [16][8] ints (voxel of the class or -1) followed by [16][8] floats (its weight)
-NSR_DEV void scatter_merged(const GridDev &G, const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab,
-                            unsigned salt = 0u,         // salt != 0: measurement only (NSR_X & 8): spread the voxels, same request count
-                            float *lds_grid = nullptr) { // != NULL: the whole gradient grid sits in LDS (small grids, nsr_bwd2.h)
+// part 1 (the wave that owns the tile): dc point-major into Tx, the class table into tab
+NSR_DEV void scatter_stage(const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab) {
     const int pt = lane & 15, g = lane >> 4;
     int *vt = reinterpret_cast<int *>(tab);
     float *wt = tab + 128;
@@ -414,34 +413,47 @@ NSR_DEV void scatter_merged(const GridDev &G, const Lvl &L, int lane, const Act<
         vt[pt * 8 + cls] = active ? corner_vox(L, k) : -1;
         wt[pt * 8 + cls] = corner_w(L, k);
     }
-    wave_fence();
+}
+// part 2 (any wave, after a fence / flag hand-off): the walks and the atomics.  Branch-light: the run sums are a segmented
+// scan with selects (the same fma chain per run as a sequential walk: acc = x*w at a run's first point, fma afterwards), and
+// the only divergent code is one predicated atomic per point -- the first version walked with a data-dependent branch nest
+// per point (~25 instructions and three branches, ~380 cycles per atomic: the walk, not the atomic unit, set the pace).
+NSR_DEV void scatter_walk(const GridDev &G, int lane, const float *Tx, const float *tab,
+                          float *lds_grid = nullptr) { // != NULL: the whole gradient grid sits in LDS (small grids, nsr_bwd2.h)
+    const int *vt = reinterpret_cast<const int *>(tab);
+    const float *wt = tab + 128;
     const int h = lane >> 5, ch = lane & 31;
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
         const int k = 2 * q + h;
         int v[16];
-        float w[16], x[16];
+        float s[16];
 #pragma unroll
         for (int p = 0; p < 16; ++p) {        // all LDS reads of the round in flight at once
             v[p] = vt[p * 8 + k];
-            w[p] = wt[p * 8 + k];
-            x[p] = Tx[p * kTxS + ch];
+            s[p] = wt[p * 8 + k];
         }
-        float acc = 0.f;
-        int cur = -1;
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
-            if (v[p] != cur) {
-                if (cur >= 0 && lds_grid) atomic_add_lds(lds_grid + cur * kC + ch, acc);
-                else if (cur >= 0) atomic_add_global(G.dfeat + (long long)(salt ? (int)(((unsigned)cur * 2654435761u + salt * 40503u + (unsigned)(p * 8 + k)) % (unsigned)(G.X * G.Y * G.Z)) : cur) * kC + ch, acc);
-                acc = 0.f;
-                cur = v[p];
-            }
-            acc = fmaf(x[p], w[p], acc);
+            const float x = Tx[p * kTxS + ch];
+            const float first = x * s[p];
+            s[p] = (p > 0 && v[p] == v[p - 1]) ? fmaf(x, s[p], s[p - 1]) : first;
         }
-        if (cur >= 0 && lds_grid) atomic_add_lds(lds_grid + cur * kC + ch, acc);
-        else if (cur >= 0) atomic_add_global(G.dfeat + (long long)(salt ? (int)(((unsigned)cur * 2654435761u + salt * 40503u + (unsigned)k) % (unsigned)(G.X * G.Y * G.Z)) : cur) * kC + ch, acc);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const bool end = p == 15 || v[p] != v[p + 1];
+            if (end && v[p] >= 0) {
+                if (lds_grid) atomic_add_lds(lds_grid + v[p] * kC + ch, s[p]);
+                else atomic_add_global(G.dfeat + (long long)v[p] * kC + ch, s[p]);
+            }
+        }
     }
+}
+NSR_DEV void scatter_merged(const GridDev &G, const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab,
+                            float *lds_grid = nullptr) {
+    scatter_stage(L, lane, dc, active, Tx, tab);
+    wave_fence();
+    scatter_walk(G, lane, Tx, tab, lds_grid);
     wave_fence();
 }
 
@@ -813,7 +825,10 @@ NSR_DEV F4 decode_tile_lds(const RenderParams &P, const float *aux, float *wl, d
         const Act<2> cm = gather_feat(P.grid[NSR_MIDDLE], Lm, g);
         float om[1];
         const ActSink sm = act_sink(P, 0, gp, g);
+        const Dbg dbg{P.dbg ? P.dbg + ((long long)bid_x() * 12 + (tid() >> 6)) * 64 : nullptr};
+        dbg.stamp(10);                                                  // features gathered (issued), before the middle decoder
         mlp_xyz_fwd<NSR_MIDDLE, false, SAVE>(wl, aux, fx, fy, fz, cm, lane, om, nullptr, &sm);
+        dbg.stamp(3);
         float occ = om[0];
         if (STAGE >= NSR_STAGE_FINE) {
             const Lvl Lf = make_level(P.grid[NSR_FINE], px, py, pz);
@@ -821,12 +836,14 @@ NSR_DEV F4 decode_tile_lds(const RenderParams &P, const float *aux, float *wl, d
             block_sync();                                               // everyone is done with the middle weights
             load_packed<NSR_FINE>(wl, P.dec[NSR_FINE].packed);
             block_sync();
+            dbg.stamp(4);
             Act<4> cc;
             cc.t[0] = cf.t[0]; cc.t[1] = cf.t[1]; cc.t[2] = cm.t[0]; cc.t[3] = cm.t[1];    // decoder.py:182-187
             float of[1];
             const ActSink sf = act_sink(P, 1, gp, g);
             mlp_xyz_fwd<NSR_FINE, false, SAVE>(wl, aux + AUX_FLOATS, fx, fy, fz, cc, lane, of, nullptr, &sf);
             occ = of[0] + om[0];                                                            // decoder.py:333,341
+            dbg.stamp(5);
         }
         if (STAGE == NSR_STAGE_COLOR) {
             const Lvl Lc = make_level(P.grid[NSR_COLOR], px, py, pz);
@@ -834,6 +851,7 @@ NSR_DEV F4 decode_tile_lds(const RenderParams &P, const float *aux, float *wl, d
             block_sync();
             load_packed<NSR_COLOR>(wl, P.dec[NSR_COLOR].packed);
             block_sync();
+            dbg.stamp(11);
             float oc[4];
             const ActSink sc = act_sink(P, 2, gp, g);
             mlp_xyz_fwd<NSR_COLOR, false, SAVE>(wl, aux + 2 * AUX_FLOATS, fx, fy, fz, ccol, lane, oc, nullptr, &sc);
@@ -862,6 +880,8 @@ NSR_KERNEL NSR_BOUNDS(768) void render_fwd_kernel(const RenderParams P) {
     float *wl = reinterpret_cast<float *>(rawbuf + npts);
     const int lane = tid() & 63, wave = tid() >> 6, nwaves = nthreads() >> 6, g = lane >> 4;
     const int S = P.S;
+    const Dbg dbg{P.dbg ? P.dbg + ((long long)bid_x() * 12 + wave) * 64 : nullptr};
+    dbg.stamp(0);
 
     load_stage_aux<STAGE>(P, aux);
     if (STAGE == NSR_STAGE_COARSE) load_packed<NSR_COARSE>(wl, P.dec[NSR_COARSE].packed);     // only one decoder: staged once
@@ -871,7 +891,9 @@ NSR_KERNEL NSR_BOUNDS(768) void render_fwd_kernel(const RenderParams P) {
         loop_fence();
         const long long ray0 = grp * P.rays_per_block;
         if (STAGE > NSR_STAGE_MIDDLE) load_packed<NSR_MIDDLE>(wl, P.dec[NSR_MIDDLE].packed);   // fine / colour overwrote it
+        dbg.stamp(1);
         compute_z(P, ray0, ztmp, zbuf);            // ends with block_sync (also covers the aux / weight staging)
+        dbg.stamp(2);
         const int pidx = wave * kTile + (lane & 15);
         const int r = pidx / S, k = pidx - r * S;
         const long long ray = ray0 + r;
@@ -885,6 +907,7 @@ NSR_KERNEL NSR_BOUNDS(768) void render_fwd_kernel(const RenderParams P) {
         const bool inside = (px > P.blo[0]) && (px < P.bhi[0]) && (py > P.blo[1]) && (py < P.bhi[1]) &&
                             (pz > P.blo[2]) && (pz < P.bhi[2]);
         F4 raw = decode_tile_lds<STAGE, SAVE>(P, aux, wl, px, py, pz, lane, active ? ray * S + k : -1);
+        dbg.stamp(6);
         if (!inside) raw.w = 100.f;                                         // Renderer.py:57
         if (active && g == 0) {
             rawbuf[pidx] = raw;
@@ -892,6 +915,7 @@ NSR_KERNEL NSR_BOUNDS(768) void render_fwd_kernel(const RenderParams P) {
             if (P.zvals) P.zvals[ray * S + k] = z;
         }
         block_sync();
+        dbg.stamp(7);
         for (int rq = wave; rq < P.rays_per_block; rq += nwaves) {
             const long long rayq = ray0 + rq;
             if (rayq >= P.n_rays) break;
@@ -965,9 +989,11 @@ NSR_KERNEL NSR_BOUNDS(768) void render_fwd_kernel(const RenderParams P) {
                 }
             }
         }
+        dbg.stamp(8);
         block_sync();
     }
     if (P.loss && lane == 0 && loss_acc != 0.0) atomic_add_global_d(P.loss, loss_acc);
+    dbg.stamp(9);
 }
 
 // Renderer.eval_points forward over a flat list of points (Renderer.py:23-61).  Same decoder phases as the render

@@ -79,6 +79,19 @@ def get_tensor_from_camera(c2w: torch.Tensor) -> torch.Tensor:
     return torch.tensor([w, x, y, z, m[0, 3], m[1, 3], m[2, 3]], dtype=torch.float32, device=c2w.device)
 
 
+def _pose_np(t7) -> torch.Tensor:
+    """get_camera_from_tensor + to44 for a pose on the host, in numpy (one frame's result; common.py:137-176)."""
+    q = np.asarray(t7[:4], dtype=np.float64)
+    w, x, y, z = q
+    s = 2.0 / float(q @ q)
+    m = np.eye(4)
+    m[:3, :3] = [[1 - s * (y * y + z * z), s * (x * y - z * w), s * (x * z + y * w)],
+                 [s * (x * y + z * w), 1 - s * (x * x + z * z), s * (y * z - x * w)],
+                 [s * (x * z - y * w), s * (y * z + x * w), 1 - s * (x * x + y * y)]]
+    m[:3, 3] = t7[4:7]
+    return torch.from_numpy(m.astype(np.float32))
+
+
 def to44(c2w: torch.Tensor) -> torch.Tensor:
     if c2w.shape[0] == 4:
         return c2w
@@ -192,11 +205,13 @@ class ProductOps:
             for p in self.decoders_track.parameters():
                 p.requires_grad_(False)                         # nothing steps them; the reference leaves requires_grad on and discards the grads
             return
-        with torch.no_grad():
-            for k, v in self.c.items():
-                self.c_track[k].copy_(v)
-            for m_t, m_m in zip(self.decoders_track.children(), self.decoders.children()):
-                m_t.flat_params().copy_(m_m.flat_params())      # one copy per decoder (every Parameter is a view of the flat blob)
+        if getattr(self, "_track_copy_version", None) == getattr(self, "map_version", 0):
+            return                                              # the mapper did not run since the last refresh
+        self._track_copy_version = getattr(self, "map_version", 0)
+        with torch.no_grad():                                   # grids and decoder blobs in ONE multi-tensor copy
+            dst = list(self.c_track.values()) + [m.flat_params() for m in self.decoders_track.children()]
+            src = list(self.c.values()) + [m.flat_params() for m in self.decoders.children()]
+            torch._foreach_copy_(dst, src)
         self.decoders_track.repack()                            # same packed buffers: the captured iteration reads the new weights
 
     def get_samples(self, H0, H1, W0, W1, n, c2w, depth, color):
@@ -247,7 +262,7 @@ class MiniSLAM:
         self.keyframe_list, self.keyframe_dict = [], []
         self.np_rng = np.random.RandomState(seed)
         self.counters = {"tracking_iters": 0, "mapping_iters": 0, "tracking_rays": 0, "mapping_rays": 0, "coarse_iters": 0}
-        self.timers = {"tracking_s": 0.0, "mapping_s": 0.0, "coarse_s": 0.0}
+        self.timers = {"tracking_s": 0.0, "mapping_s": 0.0, "coarse_s": 0.0, "tracking_capture_s": 0.0}
 
     # The reference drops the rays whose depth lies outside the bound by boolean-mask compaction (Tracker.py:95-104,
     # Mapper.py:471-481) and indexes its loss terms with further masks -- a host synchronisation each.  Here the batch
@@ -285,22 +300,28 @@ class MiniSLAM:
     # into a hipGraph; every later iteration of every frame is a replay (the frame, the pose and the optimiser state live in
     # static buffers that are refilled / zeroed per frame; per-iteration losses and poses go to device-side history slots).
     def _track_fused(self, init_cam, color, depth):
+        """``init_cam``: the 7 pose parameters on the HOST.  Per frame: one small H2D copy, two image copies, two multi-tensor
+        zero fills, ``iters`` graph replays, one D2H read of the history (the only synchronisation of the frame)."""
         tc, ops, nsa = self.cfg["tracking"], self.ops, self.ops.nsa
         n_it = tc["iters"]
         ft = getattr(self, "_ft", None)
         if ft is None:
-            ft = self._ft = {"cam": init_cam.clone().requires_grad_(True), "depth": depth.clone(), "color": color.clone(),
+            t_cap = time.perf_counter()
+            ft = self._ft = {"cam": torch.zeros(7, device=self.device).requires_grad_(True), "depth": depth.clone(), "color": color.clone(),
                              "i": torch.zeros(1, dtype=torch.long, device=self.device),
-                             "loss": torch.zeros(n_it, dtype=torch.float64, device=self.device),
-                             "cams": torch.zeros((n_it, init_cam.numel()), dtype=torch.float32, device=self.device), "graph": None}
+                             "hist": torch.zeros((n_it, 8), dtype=torch.float32, device=self.device),    # loss | pose per iteration
+                             "host": torch.zeros(7, dtype=torch.float32).pin_memory(),
+                             "hist_host": torch.zeros((n_it, 8), dtype=torch.float32).pin_memory(), "graph": None}
             ft["opt"] = torch.optim.Adam([ft["cam"]], lr=tc["lr"], capturable=True)
         cam, opt = ft["cam"], ft["opt"]
-        with torch.no_grad():
-            cam.copy_(init_cam); ft["depth"].copy_(depth); ft["color"].copy_(color); ft["i"].zero_()
-            for st in opt.state.values():                       # a fresh optimiser per frame (Tracker.py:214-222)
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
+
+        def reset():
+            ft["host"].copy_(init_cam)
+            with torch.no_grad():
+                cam.copy_(ft["host"], non_blocking=True); ft["depth"].copy_(depth); ft["color"].copy_(color); ft["i"].zero_()
+                st = [v for s in opt.state.values() for v in s.values() if torch.is_tensor(v)]
+                if st:
+                    torch._foreach_zero_(st)                    # a fresh optimiser per frame (Tracker.py:214-222)
 
         def iteration():
             opt.zero_grad(set_to_none=True)
@@ -311,38 +332,48 @@ class MiniSLAM:
             loss.backward()
             opt.step()
             with torch.no_grad():
-                ft["loss"].index_copy_(0, ft["i"], loss.detach().reshape(1))
-                ft["cams"].index_copy_(0, ft["i"], cam.detach().reshape(1, -1))
+                ft["hist"].index_copy_(0, ft["i"], torch.cat([loss.detach().reshape(1).float(), cam.detach()]).reshape(1, 8))
                 ft["i"] += 1
 
-        done = 0
-        if ft["graph"] is None:
-            iteration(); done = 1                               # eager once: optimiser state, code load
-            if n_it > 1:
-                torch.cuda.synchronize()
-                ft["graph"] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ft["graph"]):
+        reset()
+        if ft["graph"] is None:                                 # once per run: an eager iteration (optimiser state, code load), the
+            iteration()                                         # capture; timed apart (timers["tracking_capture_s"])
+            torch.cuda.synchronize()
+            ft["graph"] = torch.cuda.CUDAGraph()                # all iterations of a frame in ONE graph: one launch per frame
+            with torch.cuda.graph(ft["graph"]):
+                for _ in range(n_it):
                     iteration()
-        for _ in range(n_it - done):
-            ft["graph"].replay()
+            reset()
+            torch.cuda.synchronize()
+            self.timers["tracking_capture_s"] = time.perf_counter() - t_cap
+        tp = self.timers
+        t_a = time.perf_counter()
+        ft["graph"].replay()
+        t_b = time.perf_counter()
         self.counters["tracking_iters"] += n_it
         self.counters["tracking_rays"] += n_it * tc["pixels"]
-        k = int(torch.argmin(ft["loss"]))                       # Tracker.py:236-246, the one host read of the frame
-        return ft["cams"][k].clone(), float(ft["loss"][k])
+        ft["hist_host"].copy_(ft["hist"], non_blocking=True)
+        torch.cuda.current_stream().synchronize()               # Tracker.py:236-246, the one host read of the frame
+        tp["tracking_launch_s"] = tp.get("tracking_launch_s", 0.0) + t_b - t_a              # host time of the graph launch
+        tp["tracking_wait_s"] = tp.get("tracking_wait_s", 0.0) + time.perf_counter() - t_b   # the GPU running the iterations
+        h = ft["hist_host"].numpy()
+        k = int(np.argmin(h[:, 0]))
+        return h[k, 1:].copy(), float(h[k, 0])
 
     # -- Tracker.run, one frame (Tracker.py:176-256)
     def track(self, idx, color, depth):
         tc = self.cfg["tracking"]
-        pre = self.est[idx - 1].to(self.device).float()
+        pdev = torch.device("cpu") if getattr(self.ops, "fused", False) else self.device    # 4x4 pose algebra: on the host when
+        pre = self.est[idx - 1].to(pdev).float()                                             # the iterations are graph replays
         if tc["const_speed_assumption"] and idx - 2 >= 0:
-            delta = pre @ self.est[idx - 2].to(self.device).float().inverse()
+            delta = pre @ self.est[idx - 2].to(pdev).float().inverse()
             init = delta @ pre
         else:
             init = pre
         if getattr(self.ops, "fused", False) and tc["iters"] > 0:
             self.ops.update_tracker_copy()                       # Tracker.update_para_from_mapping (Tracker.py:130-142)
-            best, self.last_track_loss = self._track_fused(get_tensor_from_camera(init.detach()).to(self.device), color, depth)
-            return to44(get_camera_from_tensor(best)), init
+            best, self.last_track_loss = self._track_fused(get_tensor_from_camera(init), color, depth)
+            return _pose_np(best), init                          # 4x4 on the host
         cam = get_tensor_from_camera(init.detach()).to(self.device).requires_grad_(True)
         opt = torch.optim.Adam([cam], lr=tc["lr"])
         best, self.last_track_loss = cam.clone().detach(), float("nan")          # iters == 0: the motion-model prediction alone
@@ -605,12 +636,14 @@ class MiniSLAM:
             if self.device.type == "cuda":
                 torch.cuda.synchronize()
             t1 = time.perf_counter()
-            self.timers["tracking_s"] += t1 - t0
+            cap, self._cap_seen = self.timers["tracking_capture_s"] - getattr(self, "_cap_seen", 0.0), self.timers["tracking_capture_s"]
+            self.timers["tracking_s"] += t1 - t0 - cap         # the one-time capture of the tracker's graph is reported apart
             if idx % mc["every_frame"] == 0 or idx == n - 1:
                 first = idx == 0
                 cur = (gt_c2w if self.gt_mapping_pose else self.est[idx]).to(self.device)
                 new = self.optimize_map(mc["iters_first"] if first else mc["iters"],
                                         mc["lr_first_factor"] if first else mc["lr_factor"], idx, color, depth, cur)
+                self.ops.map_version = getattr(self.ops, "map_version", 0) + 1
                 if new is not None:
                     self.est[idx] = new.detach()
                 if self.device.type == "cuda":
