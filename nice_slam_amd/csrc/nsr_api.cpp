@@ -141,8 +141,9 @@ int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays,
     P.rays_d = a->rays_d;
     P.acts = a->acts;
     P.acts_masks_only = a->acts_masks_only ? 1 : 0;
-    if (!bwd && a->acts && a->loss && a->dl_depth && a->zvals) {
-        // fused mapping loss + activation buffer: the forward's loss epilogue also leaves d raw / positions for the split backward
+    if (!bwd && a->acts && a->zvals) {
+        // activation buffer: the forward leaves the sample positions (and, with the fused loss, d raw) for the split backward;
+        // the three-launch forward (nsr_fwd2.h) keeps its per-sample scratch there
         const SplitLayout L = split_layout(P.stage, P.n_rays, P.S);
         P.draw = a->acts + L.o_draw;
         P.pf = a->acts + L.o_pf;
@@ -232,7 +233,6 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
     P.draw = P.acts + L.o_draw;
     P.pf = P.acts + L.o_pf;
     P.pd = reinterpret_cast<double *>(P.acts + L.o_pd);
-    P.dw_blocks = G.nimg;
     if (any_params && P.acts_masks_only) return fail("nsr_render_bwd: the forward saved relu masks only (acts_masks_only); parameter gradients need the full activations");
     static const int xflags = env_int("NSR_X", 0);
     P.xflags = xflags;
@@ -279,7 +279,24 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
     }
     if (any_params) {
         const int lds = nsr::dw_lds_bytes(P.stage >= NSR_STAGE_FINE ? NSR_FINE : NSR_MIDDLE);
-        const dim3 grid(G.nimg, passes), block(64 * nsr::kDwWaves);
+        // the passes * nimg blocks (= partial images, the workspace's size) dealt over the decoders that want parameter gradients,
+        // in proportion to a tile's MFMA count
+        const long long tiles = (P.n_points_total + nsr::kTile - 1) / nsr::kTile;
+        int wgt[3] = {0, 0, 0}, wsum = 0;
+        for (int p = 0; p < passes; ++p) {
+            const int s = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE + p;
+            wgt[p] = P.dec[s].dparams ? (s == NSR_FINE ? 288 : 224) : 0;
+            wsum += wgt[p];
+        }
+        const int total = passes * G.nimg;
+        P.dw_beg[0] = 0;
+        for (int p = 0; p < 3; ++p) {
+            long long n = (p < passes && wgt[p]) ? (long long)total * wgt[p] / wsum : 0;
+            if (p < passes && wgt[p] && n < 1) n = 1;
+            if (n > tiles) n = tiles;
+            P.dw_beg[p + 1] = P.dw_beg[p] + (int)n;
+        }
+        const dim3 grid(P.dw_beg[3]), block(64 * nsr::kDwWaves);
 #define NSR_DW(ST)                                                                                  \
     if (int rc = launch_cfg(nsr::render_bwd_dw_kernel<ST>, lds, "nsr_render_bwd(dw)")) return rc;   \
     NSR_LAUNCH((nsr::render_bwd_dw_kernel<ST>), grid, block, lds, stream, P);
@@ -298,10 +315,10 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
             if (!P.dec[s].dparams) continue;
             const int pass = P.stage == NSR_STAGE_COARSE ? 0 : s - NSR_MIDDLE;
             nsr::FinalJob &J = R.job[rows++];
-            J.images = P.partials + (long long)pass * G.nimg * P.partial_stride;
+            J.images = P.partials + (long long)P.dw_beg[pass] * P.partial_stride;
             J.dbpart = P.dbpart + (long long)pass * G.nb * nsr::kDbPart;
             J.params = P.dec[s].params; J.dparams = P.dec[s].dparams;
-            J.kind = s; J.nimg = G.nimg; J.ndx = G.nb;
+            J.kind = s; J.nimg = P.dw_beg[pass + 1] - P.dw_beg[pass]; J.ndx = G.nb;
             const int dbeg = s == NSR_COARSE ? 0 : nsr::xyz_w(nsr::cdim_of(s), 0);
             const int nb = (nsr::param_total(s) - dbeg + 63) / 64 + 5 + (s == NSR_COARSE ? 0 : 5 * nsr::cdim_of(s) / 4);
             nblocks = nb > nblocks ? nb : nblocks;
@@ -362,6 +379,50 @@ int nsr_render_fwd(const nsr_render_args *a, void *stream) {
 #endif
     if (!a->depth || !a->var || !a->rgb) return fail("nsr_render_fwd: null output pointer");
     if (P.n_rays == 0) return 0;
+    static const int fwd_split = env_int("NSR_FWD_SPLIT", 1);      // 0: always the one-launch kernel (measurement)
+    if (fwd_split && P.acts && P.zvals && P.raw && P.draw) {
+        // a differentiated call with an activation buffer: sample placement -> decoder passes -> compositor (nsr_fwd2.h)
+        const int passes = bwd_passes(P.stage), rpb = 4;
+        // blocks per decoder pass in proportion to the measured cost of a tile (the fine decoder: 288 MFMAs and two feature
+        // gathers against 240 and one), one block per CU over all passes; waves per block from the largest tile share
+        static const int w_fine = env_int("NSR_FWD_FINE_WEIGHT", 14);
+        const long long tiles = (P.n_points_total + nsr::kTile - 1) / nsr::kTile;
+        const int wsum = passes == 1 ? 10 : (passes == 2 ? 10 + w_fine : 20 + w_fine);
+        long long most = 1;
+        P.pass_beg[0] = 0;
+        for (int p = 0; p < 3; ++p) {
+            int nbp = 0;
+            if (p < passes) {
+                nbp = (int)((long long)kDefaultBwdBlocks * (p == 1 ? w_fine : 10) / wsum);
+                if (nbp > tiles) nbp = (int)tiles;
+                if (nbp < 1) nbp = 1;
+                const long long share = (tiles + nbp - 1) / nbp;
+                most = share > most ? share : most;
+            }
+            P.pass_beg[p + 1] = P.pass_beg[p] + nbp;
+        }
+        const int waves = (int)(most > nsr::kDxMaxWaves ? nsr::kDxMaxWaves : most);
+        const dim3 rgrid((unsigned)((P.n_rays + rpb - 1) / rpb)), rblock(64 * rpb);
+        NSR_LAUNCH(nsr::fwd_sample_kernel, rgrid, rblock, rpb * 64 * 8, stream, P);
+        int lds = 0;
+        const int first = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE, last = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : P.stage;
+        for (int kind = first; kind <= last; ++kind) {
+            const int need = (nsr::AUX_FLOATS + nsr::packed_total(kind) + 4) * 4;
+            lds = need > lds ? need : lds;
+        }
+        const dim3 grid(P.pass_beg[3]), block(64 * waves);
+#define NSR_FWP(ST, SV)                                                                                      \
+    if (int rc = launch_cfg(nsr::render_fwd_pass_kernel<ST, SV>, lds, "nsr_render_fwd(pass)")) return rc;    \
+    NSR_LAUNCH((nsr::render_fwd_pass_kernel<ST, SV>), grid, block, lds, stream, P);
+        switch (P.stage) {
+            case 0: NSR_FWP(0, true) NSR_LAUNCH(nsr::fwd_composite_kernel<0>, rgrid, rblock, rpb * 8, stream, P); break;
+            case 1: NSR_FWP(1, true) NSR_LAUNCH(nsr::fwd_composite_kernel<1>, rgrid, rblock, rpb * 8, stream, P); break;
+            case 2: NSR_FWP(2, true) NSR_LAUNCH(nsr::fwd_composite_kernel<2>, rgrid, rblock, rpb * 8, stream, P); break;
+            default: NSR_FWP(3, true) NSR_LAUNCH(nsr::fwd_composite_kernel<3>, rgrid, rblock, rpb * 8, stream, P); break;
+        }
+#undef NSR_FWP
+        return finish("nsr_render_fwd(split)");
+    }
     const int npts = P.rays_per_block * P.S;
     const int lds = fwd_lds_bytes(P.stage, npts);
     const dim3 grid((unsigned)(P.n_groups < (1 << 20) ? P.n_groups : (1 << 20))), block(64 * P.tiles_per_block);

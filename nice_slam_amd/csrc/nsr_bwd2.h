@@ -706,15 +706,15 @@ struct DwNoxWave {
 
 // control words behind the ring: landed[j] = tiles loader j has landed, prog[w] = tiles compute wave w is done with
 template <int KIND, class W>
-NSR_DEV void dw_compute(const RenderParams &P, W &Wv, float *ring, int *ctl, float *img, int wave, int lane) {
+NSR_DEV void dw_compute(const RenderParams &P, W &Wv, float *ring, int *ctl, float *img, int wave, int lane, int bi, int nbp) {
     typedef DwLay<KIND> Y;
     Wv.init(P, lane & 15);
     const long long ntiles = (P.n_points_total + kTile - 1) / kTile;
-    const long long last = ntiles - 1, step = nblk_x();
+    const long long last = ntiles - 1, step = nbp;
     const int ragged = (int)(P.n_points_total & (kTile - 1));
     typename W::Ops ops;
     int k = 0;
-    for (long long t = bid_x(); t < ntiles; t += step, ++k) {
+    for (long long t = bi; t < ntiles; t += step, ++k) {
         loop_fence();
         while (flag_load(ctl + (k & 1)) <= (k >> 1)) spin_pause();          // the loader of this tile has landed it
         Wv.fetch(dw_src<KIND>(ring + (k % kDwRing) * Y::kSlot), lane, ops);
@@ -725,12 +725,12 @@ NSR_DEV void dw_compute(const RenderParams &P, W &Wv, float *ring, int *ctl, flo
 }
 
 template <int KIND>
-NSR_DEV void dw_loader(const RenderParams &P, float *ring, int *ctl, int j, int lane) {
+NSR_DEV void dw_loader(const RenderParams &P, float *ring, int *ctl, int j, int lane, int bi, int nbp) {
     typedef DwLay<KIND> Y;
     const long long ntiles = (P.n_points_total + kTile - 1) / kTile;
-    const long long step = nblk_x();
+    const long long step = nbp;
     int m = 0;                                                               // this loader's m-th tile is the block's tile 2 m + j
-    for (long long t = bid_x() + j * step; t < ntiles; t += kDwLoaders * step, ++m) {
+    for (long long t = bi + j * step; t < ntiles; t += kDwLoaders * step, ++m) {
         loop_fence();
         const int k = kDwLoaders * m + j;
         if (k >= kDwRing) {                                                  // the slot still holds tile k - kDwRing
@@ -750,37 +750,39 @@ NSR_DEV void dw_loader(const RenderParams &P, float *ring, int *ctl, int j, int 
 }
 
 template <int KIND>
-NSR_DEV void dw_pass(const RenderParams &P) {
+NSR_DEV void dw_pass(const RenderParams &P, int bi, int nbp) {      // block bi of the nbp blocks of this decoder pass
     float *ring = reinterpret_cast<float *>(lds_base());
     int *ctl = reinterpret_cast<int *>(ring + kDwRing * DwLay<KIND>::kSlot);
     const int lane = tid() & 63, wave = uniform(tid() >> 6);
     if (tid() < 16) ctl[tid()] = 0;
     block_sync();
-    float *img = P.partials + ((long long)bid_y() * nblk_x() + bid_x()) * P.partial_stride;
+    float *img = P.partials + (long long)bid_x() * P.partial_stride;
     // one specialisation per compute wave: its role's output tiles and operand reads are compile-time constants
 #define NSR_DW_CASE(WV)                                                                                         \
     case WV: {                                                                                                  \
-        if constexpr (KIND == NSR_COARSE) { DwNoxWave<WV> W; dw_compute<KIND>(P, W, ring, ctl, img, WV, lane); } \
-        else { DwXyzWave<KIND, WV> W; dw_compute<KIND>(P, W, ring, ctl, img, WV, lane); }                        \
+        if constexpr (KIND == NSR_COARSE) { DwNoxWave<WV> W; dw_compute<KIND>(P, W, ring, ctl, img, WV, lane, bi, nbp); } \
+        else { DwXyzWave<KIND, WV> W; dw_compute<KIND>(P, W, ring, ctl, img, WV, lane, bi, nbp); }                        \
         break;                                                                                                  \
     }
     switch (wave) {
         NSR_DW_CASE(0) NSR_DW_CASE(1) NSR_DW_CASE(2) NSR_DW_CASE(3) NSR_DW_CASE(4) NSR_DW_CASE(5) NSR_DW_CASE(6) NSR_DW_CASE(7)
-        default: dw_loader<KIND>(P, ring, ctl, wave - kDwCompute, lane); break;
+        default: dw_loader<KIND>(P, ring, ctl, wave - kDwCompute, lane, bi, nbp); break;
     }
 #undef NSR_DW_CASE
 }
 
-// grid = (partial images per pass, decoder passes of the stage); passes without parameter gradients exit at once
+// grid = blocks of all decoder passes: [dw_beg[p], dw_beg[p + 1]) work on pass p and leave one partial image each (image =
+// block index).  The host deals the blocks in proportion to a tile's MFMA count (288 for the fine decoder, 224 for the others)
+// and gives none to a decoder whose parameter gradients nobody asked for.
 template <int STAGE>
 NSR_KERNEL NSR_BOUNDS(64 * kDwWaves) void render_bwd_dw_kernel(const RenderParams P) {
+    const int b = bid_x();
     if (STAGE == NSR_STAGE_COARSE) {
-        if (P.dec[NSR_COARSE].dparams) dw_pass<NSR_COARSE>(P);
+        dw_pass<NSR_COARSE>(P, b, nblk_x());
     } else {
-        const int pass = bid_y();
-        if (pass == 0) { if (P.dec[NSR_MIDDLE].dparams) dw_pass<NSR_MIDDLE>(P); }
-        else if (pass == 1) { if (STAGE >= NSR_STAGE_FINE && P.dec[NSR_FINE].dparams) dw_pass<NSR_FINE>(P); }
-        else { if (STAGE == NSR_STAGE_COLOR && P.dec[NSR_COLOR].dparams) dw_pass<NSR_COLOR>(P); }
+        if (b < P.dw_beg[1]) dw_pass<NSR_MIDDLE>(P, b, P.dw_beg[1]);
+        else if (b < P.dw_beg[2]) { if (STAGE >= NSR_STAGE_FINE) dw_pass<NSR_FINE>(P, b - P.dw_beg[1], P.dw_beg[2] - P.dw_beg[1]); }
+        else { if (STAGE == NSR_STAGE_COLOR) dw_pass<NSR_COLOR>(P, b - P.dw_beg[2], P.dw_beg[3] - P.dw_beg[2]); }
     }
 }
 
@@ -803,6 +805,19 @@ struct FinalParams {
     int stride, overwrite;
 };
 NSR_DEV void final_store(const FinalParams &R, float *p, float v) { *p = R.overwrite ? v : *p + v; }
+// sum of p[k * stride] over k = first, first + step, ... < n, in that order, with sixteen loads in flight at a time (the kernel
+// is a chain of memory round trips: with four in flight the 255 images of a one-decoder stage took eight of them)
+NSR_DEV float strided_sum(const float *p, long long stride, int first, int step, int n) {
+    float s = 0.f;
+    for (int k0 = first; k0 < n; k0 += 16 * step) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const int k = k0 + j * step; v[j] = k < n ? p[(long long)k * stride] : 0.f; }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if (k0 + j * step < n) s += v[j];
+    }
+    return s;
+}
 
 NSR_KERNEL void bwd_finalize_kernel(const FinalParams R) {
     const FinalJob J = R.job[bid_y()];
@@ -823,10 +838,9 @@ NSR_KERNEL void bwd_finalize_kernel(const FinalParams R) {
         if (e < n) {
             if (isB) {
                 const int d = e / kE, ch = e - d * kE;
-                for (int k = slice; k < J.ndx; k += nslice) s += J.dbpart[(long long)k * kDbPart + d * 96 + ch];
+                s = strided_sum(J.dbpart + d * 96 + ch, kDbPart, slice, nslice, J.ndx);
             } else {
-#pragma unroll 4
-                for (int k = slice; k < J.nimg; k += nslice) s += J.images[(long long)k * R.stride + dbeg + e];
+                s = strided_sum(J.images + dbeg + e, R.stride, slice, nslice, J.nimg);
             }
         }
         red[t] = s;
@@ -853,18 +867,14 @@ NSR_KERNEL void bwd_finalize_kernel(const FinalParams R) {
     wl[t] = (t >> 5) < nrow ? J.params[woff + (t >> 5) * wstr + (t & 31)] : 0.f;
     {
         float sg = 0.f;
-        if (o < nrow) {
-#pragma unroll 4
-            for (int k = sl; k < J.nimg; k += 8) sg += J.images[(long long)k * R.stride + goff + o * cd + c];
-        }
+        if (o < nrow) sg = strided_sum(J.images + goff + o * cd + c, R.stride, sl, 8, J.nimg);
         red[t] = sg;
     }
     if (chunk == 0) {
         const int ob = t & 31, sb = t >> 5;
         const int boff = i < 4 ? xyz_b(cd, i + 1) : xyz_bo(cd, nout);
         float sbv = 0.f;
-        if (ob < nrow)
-            for (int k = sb; k < J.nimg; k += 32) sbv += J.images[(long long)k * R.stride + boff + ob];
+        if (ob < nrow) sbv = strided_sum(J.images + boff + ob, R.stride, sb, 32, J.nimg);
         red[1024 + t] = sbv;
     }
     block_sync();

@@ -95,10 +95,11 @@ struct RenderParams {
     double *pd;               // [n_points][4]  sample position (fp64) and depth: px, py, pz, z
     float *pf;                // [n_points][4]  the position rounded to fp32 (embedding argument)
     float *dbpart;            // [passes][dx blocks][288]  per-block partial sums of d embedder._B
-    int dw_blocks;            // blocks per pass of the dW kernel = partial images per pass
+    int dw_beg[4];            // dW kernel: blocks [dw_beg[p], dw_beg[p + 1]) = partial images of decoder pass p
     int draw_scaled;          // 1: `draw` already carries nsr_bwd_args.grad_scale (comp_bwd_kernel ran); 0: the forward wrote it
     int xflags;               // measurement switches (NSR_X environment variable; 0 in normal operation)
     int lds_grid_floats;      // > 0 (coarse stage): the gradient grid (this many floats) is accumulated in the dX block's LDS
+    int pass_beg[4];          // pass kernels (nsr_fwd2.h): blocks [pass_beg[p], pass_beg[p + 1]) of the launch work on decoder pass p
     // eval_points only
     const double *points;
     long long n_points;
@@ -1635,3 +1636,4 @@ NSR_KERNEL void camera_from_tensor_kernel(const CamParams P) {
 
 #include "nsr_bwd.h"
 #include "nsr_bwd2.h"
+#include "nsr_fwd2.h"

@@ -20,7 +20,7 @@ EMU_LIB = os.path.join(EMU_DIR, "libnsr_emu.so")
 
 
 def build_emu(force=False):
-    srcs = [os.path.join(ROOT, "nice_slam_amd", "csrc", f) for f in ("nsr_api.cpp", "nsr_kernels.h", "nsr_bwd.h", "nsr_bwd2.h", "nsr_layout.h")]
+    srcs = [os.path.join(ROOT, "nice_slam_amd", "csrc", f) for f in ("nsr_api.cpp", "nsr_kernels.h", "nsr_bwd.h", "nsr_bwd2.h", "nsr_fwd2.h", "nsr_layout.h")]
     srcs += [os.path.join(EMU_DIR, f) for f in ("nsr_dev.h", "nsr_rt.h", "emu_runtime.cpp", "build_emu.sh")]
     srcs += [os.path.join(ROOT, "include", "nsr.h")]
     if not force and os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(s) for s in srcs):

@@ -39,5 +39,12 @@ for s in range(1, 10):
     d = (t[:, :, s] - t[:, :, s - 1])[ok & (t[:, :, s] > 0) & (t[:, :, s - 1] > 0)]
     if d.size:
         print("   %-48s %8.2f %8.2f %8.2f   (mean / p10 / p90 us)" % (names[s], d.mean(), np.percentile(d, 10), np.percentile(d, 90)))
+npass = {"coarse": 1, "middle": 1, "fine": 2, "color": 3}[stage]
+per = int(ok.any(1).sum()) // npass
+for p_ in range(npass):                                      # blocks [p * per, (p + 1) * per): decoder pass p (grid.y)
+    sl = slice(p_ * per, (p_ + 1) * per)
+    o2 = ok[sl]
+    lf = (t[sl, :, 9] - t[sl, :, 0])[o2]
+    print(f"   pass {p_}: {per} blocks, wave lifetime mean {lf.mean():.1f} max {lf.max():.1f} us; last exit after kernel start {(t[sl, :, 9][o2] - t0).max():.1f} us")
 life = (t[:, :, 9] - t[:, :, 0])[ok]
 print(f"   wave lifetime mean {life.mean():.1f} us, max {life.max():.1f}; exit after kernel start mean {(t[:, :, 9][ok] - t0).mean():.1f}, max {(t[:, :, 9][ok] - t0).max():.1f}")

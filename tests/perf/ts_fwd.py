@@ -17,6 +17,7 @@ renderer, dec, grids = build_product(sc, dev)
 grids = {k: v.requires_grad_(True) for k, v in grids.items()}
 for p in dec.parameters(): p.requires_grad_(True)
 NB, NW, NS = 1024, 12, 64
+SPLIT = os.environ.get("NSR_FWD_SPLIT", "1") != "0"         # the three-launch forward (nsr_fwd2.h): stamps of its pass kernel
 buf = torch.zeros((NB * NW * NS,), dtype=torch.int64, device=dev)
 frames = [(sc["c2w"].to(dev), sc["depth_img"].to(dev), sc["color_img"].to(dev)) for _ in range(5)]
 for it in range(3):
@@ -30,6 +31,24 @@ ok = (t[:, :, 0] > 0) & (t[:, :, 9] > 0)
 t0 = t[:, :, 0][ok].min()
 print(f"{n_rays} rays, stage {stage}: {int(ok.any(1).sum())} blocks, {int(ok.sum())} waves; kernel span {t[:, :, 9][ok].max() - t0:.1f} us; "
       f"wave entry after kernel start mean {(t[:, :, 0][ok] - t0).mean():.1f} us (p90 {np.percentile(t[:, :, 0][ok] - t0, 90):.1f})")
+if SPLIT:
+    for a, b, nm in ((0, 1, "entry -> aux + stream staged (barrier)"), (1, 2, "-> last tile: position loaded"), (2, 3, "   gather + decoder + stores"), (3, 9, "-> exit")):
+        m = ok & (t[:, :, a] > 0) & (t[:, :, b] > 0)
+        d = (t[:, :, b] - t[:, :, a])[m]
+        print("   %-52s %7.2f %7.2f %7.2f   (mean / p10 / p90 us)" % (nm, d.mean(), np.percentile(d, 10), np.percentile(d, 90)))
+    life = (t[:, :, 9] - t[:, :, 0])[ok]
+    print(f"   wave lifetime mean {life.mean():.1f} us, max {life.max():.1f}")
+    nblk = int(ok.any(1).sum())
+    npass = {"coarse": 1, "middle": 1, "fine": 2, "color": 3}[stage]
+    per = nblk // npass
+    for p_ in range(npass):                                  # blocks [p * per, (p + 1) * per) belong to decoder pass p
+        sl = slice(p_ * per, (p_ + 1) * per)
+        o2 = ok[sl]
+        lf = (t[sl, :, 9] - t[sl, :, 0])[o2]
+        tl = (t[sl, :, 3] - t[sl, :, 2])[o2 & (t[sl, :, 3] > 0)]
+        print(f"   pass {p_}: {per} blocks, wave lifetime mean {lf.mean():.1f} max {lf.max():.1f} us; last tile (gather + decoder + stores) mean {tl.mean():.1f} p90 {np.percentile(tl, 90):.1f} us; "
+              f"exit after kernel start max {(t[sl, :, 9][o2] - t0).max():.1f} us")
+    sys.exit(0)
 seq = [(0, 1, "entry -> aux / stream staging issued"), (1, 2, "sample placement (compute_z, barrier)"), (2, 10, "positions, feature gathers issued"),
        (10, 3, "middle decoder"), (3, 4, "fine: gather + barrier + stream staging + barrier"), (4, 5, "fine decoder"),
        (5, 11, "colour: gather + barrier + stream staging + barrier"), (11, 6, "colour decoder"), (3, 6, "(middle stage: -> decode done)"),
