@@ -257,8 +257,18 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
         int lds = 0;
         const int first = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE, last = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : P.stage;
         for (int kind = first; kind <= last; ++kind) {
-            const int need = (nsr::AUX_FLOATS + nsr::packedT_total(kind) + G.waves * nsr::kDxStg) * 4;
+            const int need = (nsr::AUX_FLOATS + nsr::packedT_total(kind) + G.waves * nsr::kDxStg + (kind == NSR_COARSE ? 0 : nsr::kHotFloats)) * 4;
             lds = need > lds ? need : lds;
+        }
+        // hot-voxel table of a dX block: samples within `hot_cells` cells of their ray's origin (NSR_DX_HOT_CELLS, 0: off)
+        static const int hot_cells = env_int("NSR_DX_HOT_CELLS", 2);
+        for (int s = 0; s < 4; ++s) {
+            P.hot_z[s] = 0.f;
+            if (s == NSR_COARSE || hot_cells <= 0 || !P.grid[s].dfeat) continue;
+            double cell = 0.0;
+            const int nn[3] = {P.grid[s].X, P.grid[s].Y, P.grid[s].Z};
+            for (int ax = 0; ax < 3; ++ax) { const double c = nn[ax] > 1 ? P.grid[s].ext[ax] / (nn[ax] - 1) : 0.0; cell = c > cell ? c : cell; }
+            P.hot_z[s] = (float)(hot_cells * cell);
         }
         P.lds_grid_floats = 0;
         if (P.stage == NSR_STAGE_COARSE && P.grid[NSR_COARSE].dfeat) {       // a coarse gradient grid that fits next to the rest

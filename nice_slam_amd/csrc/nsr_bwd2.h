@@ -144,6 +144,8 @@ NSR_DEV void dx_pass(const RenderParams &P) {
     // (LDS atomics) and goes to memory once per block: all 32 k samples of a 1024-ray batch hit those 616 voxels, and
     // same-line memory-side atomics serialise (coarse dX kernel 67 -> see profiles/r03*_c0).
     float *gl = (KIND == NSR_COARSE && P.lds_grid_floats > 0) ? stg + nw * kDxStg : nullptr;
+    const bool use_hot = KIND != NSR_COARSE && P.hot_z[KIND] > 0.f && P.grid[KIND].dfeat != nullptr;
+    const HotTab hot = hot_tab(stg + nw * kDxStg);
     const GridDev &G = P.grid[KIND];
     const DecDev &D = P.dec[KIND];
     const bool do_grid = G.dfeat != nullptr;
@@ -153,6 +155,7 @@ NSR_DEV void dx_pass(const RenderParams &P) {
     copy_f4<AUX_FLOATS / 4>(aux, D.packed);
     copy_f4<packedT_total(KIND) / 4>(wt, D.packed + AUX_FLOATS + packed_total(KIND));
     if (gl) for (int i = tid(); i < P.lds_grid_floats; i += nthreads()) gl[i] = 0.f;
+    if (use_hot) hot_init(hot);
     block_sync();
     dbg.stamp(1);
 
@@ -294,7 +297,8 @@ NSR_DEV void dx_pass(const RenderParams &P) {
         if (RAYS) coord_grad(G, L, g, dc, dux, duy, duz);
         dx_keep(nx);
         dbg.stamp(5);
-        if (do_grid && !(P.xflags & 1)) scatter_merged(G, L, lane, dc, active, Sw + kDxTx, Sw + kDxTab, gl);
+        if (do_grid && !(P.xflags & 1))
+            scatter_merged(G, L, lane, dc, active, Sw + kDxTx, Sw + kDxTab, gl, use_hot ? &hot : nullptr, (float)cur.z < P.hot_z[KIND]);
         dbg.stamp(6);
         if (RAYS) {
             // d p = d u * (n-1)/2 * 2/(hi-lo) (+ embedding part), fp64 like autograd through Renderer.py:172;
@@ -331,6 +335,10 @@ NSR_DEV void dx_pass(const RenderParams &P) {
         dbg.stamp(7);
     }
     dbg.stamp(8);
+    if (use_hot) {
+        block_sync();
+        hot_flush(hot, G);
+    }
     if (gl && do_grid) {
         block_sync();
         for (int i = tid(); i < P.lds_grid_floats; i += nthreads()) {

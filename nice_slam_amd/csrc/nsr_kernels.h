@@ -99,6 +99,7 @@ struct RenderParams {
     int draw_scaled;          // 1: `draw` already carries nsr_bwd_args.grad_scale (comp_bwd_kernel ran); 0: the forward wrote it
     int xflags;               // measurement switches (NSR_X environment variable; 0 in normal operation)
     int lds_grid_floats;      // > 0 (coarse stage): the gradient grid (this many floats) is accumulated in the dX block's LDS
+    float hot_z[4];           // dX kernel, per grid: samples with z below it use the block's hot-voxel table (0: no table)
     int pass_beg[4];          // pass kernels (nsr_fwd2.h): blocks [pass_beg[p], pass_beg[p + 1]) of the launch work on decoder pass p
     // eval_points only
     const double *points;
@@ -402,8 +403,32 @@ NSR_DEV void coord_grad(const GridDev &G, const Lvl &L, int g, const Act<2> &dc,
 // of 396 k voxel updates per 1000 colour-stage rays of the bench scene).
 //   Tx  : [16][kTxS] floats  dc of the tile, point-major
 //   tab : [16][8] ints (voxel of the class or -1) followed by [16][8] floats (its weight)
+// Hot voxels.  The rays of a keyframe all leave from its camera centre: the few voxels around it take an update from every ray
+// (~2 000 per 1000-ray batch of the bench scene), and memory-side atomics on one line serialise -- a third of the dX kernel's
+// time in the middle stage (profiles/r03_dx_experiments.txt, the run with the voxels spread by a hash).  A dX block therefore
+// keeps a small direct-mapped table of voxel rows in LDS: updates of samples closer to their ray's origin than `hot_z` (two
+// cells) go there when their voxel owns or can claim its slot, everything else straight to memory, and the block adds its
+// table to memory once at the end.
+constexpr int kHotSlots = 64, kHotBit = 1 << 30, kHotFloats = kHotSlots * (kC + 1);     // tags [64] | rows [64][32]
+struct HotTab {
+    int *tag;                // -1: free
+    float *val;
+};
+NSR_DEV HotTab hot_tab(float *base) { return HotTab{reinterpret_cast<int *>(base), base + kHotSlots}; }
+NSR_DEV void hot_init(const HotTab &H) {
+    for (int i = tid(); i < kHotSlots * kC; i += nthreads()) H.val[i] = 0.f;
+    for (int i = tid(); i < kHotSlots; i += nthreads()) H.tag[i] = -1;
+}
+NSR_DEV void hot_flush(const HotTab &H, const GridDev &G) {       // after a block barrier: one half wave per occupied slot
+    const int ch = tid() & 31;
+    for (int s = tid() >> 5; s < kHotSlots; s += nthreads() >> 5) {
+        const int v = H.tag[s];
+        if (v >= 0) atomic_add_global(G.dfeat + (long long)v * kC + ch, H.val[s * kC + ch]);
+    }
+}
+
 // part 1 (the wave that owns the tile): dc point-major into Tx, the class table into tab
-NSR_DEV void scatter_stage(const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab) {
+NSR_DEV void scatter_stage(const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab, bool hot = false) {
     const int pt = lane & 15, g = lane >> 4;
     int *vt = reinterpret_cast<int *>(tab);
     float *wt = tab + 128;
@@ -411,7 +436,7 @@ NSR_DEV void scatter_stage(const Lvl &L, int lane, const Act<2> &dc, bool active
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int k = 2 * g + c, cls = k ^ L.par;
-        vt[pt * 8 + cls] = active ? corner_vox(L, k) : -1;
+        vt[pt * 8 + cls] = active ? (corner_vox(L, k) | (hot ? kHotBit : 0)) : -1;
         wt[pt * 8 + cls] = corner_w(L, k);
     }
 }
@@ -420,7 +445,8 @@ NSR_DEV void scatter_stage(const Lvl &L, int lane, const Act<2> &dc, bool active
 // the only divergent code is one predicated atomic per point -- the first version walked with a data-dependent branch nest
 // per point (~25 instructions and three branches, ~380 cycles per atomic: the walk, not the atomic unit, set the pace).
 NSR_DEV void scatter_walk(const GridDev &G, int lane, const float *Tx, const float *tab,
-                          float *lds_grid = nullptr) { // != NULL: the whole gradient grid sits in LDS (small grids, nsr_bwd2.h)
+                          float *lds_grid = nullptr,   // != NULL: the whole gradient grid sits in LDS (small grids, nsr_bwd2.h)
+                          const HotTab *hot = nullptr) {
     const int *vt = reinterpret_cast<const int *>(tab);
     const float *wt = tab + 128;
     const int h = lane >> 5, ch = lane & 31;
@@ -444,17 +470,25 @@ NSR_DEV void scatter_walk(const GridDev &G, int lane, const float *Tx, const flo
         for (int p = 0; p < 16; ++p) {
             const bool end = p == 15 || v[p] != v[p + 1];
             if (end && v[p] >= 0) {
-                if (lds_grid) atomic_add_lds(lds_grid + v[p] * kC + ch, s[p]);
-                else atomic_add_global(G.dfeat + (long long)v[p] * kC + ch, s[p]);
+                const int vox = v[p] & ~kHotBit;
+                bool done = false;
+                if (lds_grid) { atomic_add_lds(lds_grid + vox * kC + ch, s[p]); done = true; }
+                else if (hot && (v[p] & kHotBit)) {
+                    const int slot = (int)(((unsigned)vox * 2654435761u) >> 26);       // kHotSlots = 64
+                    int tg = hot->tag[slot];
+                    if (tg == -1) { const int old = atomic_cas_lds_i(hot->tag + slot, -1, vox); tg = old == -1 ? vox : old; }
+                    if (tg == vox) { atomic_add_lds(hot->val + slot * kC + ch, s[p]); done = true; }
+                }
+                if (!done) atomic_add_global(G.dfeat + (long long)vox * kC + ch, s[p]);
             }
         }
     }
 }
 NSR_DEV void scatter_merged(const GridDev &G, const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab,
-                            float *lds_grid = nullptr) {
-    scatter_stage(L, lane, dc, active, Tx, tab);
+                            float *lds_grid = nullptr, const HotTab *hot = nullptr, bool hot_pt = false) {
+    scatter_stage(L, lane, dc, active, Tx, tab, hot && hot_pt);
     wave_fence();
-    scatter_walk(G, lane, Tx, tab, lds_grid);
+    scatter_walk(G, lane, Tx, tab, lds_grid, hot);
     wave_fence();
 }
 

@@ -186,6 +186,7 @@ NSR_DEV void atomic_add_global(float *p, float v) {
 NSR_DEV void atomic_add_lds(float *p, float v) { *p += v; }
 NSR_DEV void atomic_add_lds_i(int *p, int v) { *p += v; }
 NSR_DEV int atomic_fetch_add_lds_i(int *p, int v) { const int o = *p; *p += v; return o; }
+NSR_DEV int atomic_cas_lds_i(int *p, int expect, int v) { const int o = *p; if (o == expect) *p = v; return o; }
 NSR_DEV void atomic_add_global_d(double *p, double v) { *p += v; }
 NSR_DEV void atomic_max_pos(float *p, float v) {
     uint32_t *u = reinterpret_cast<uint32_t *>(p);
