@@ -126,3 +126,7 @@ def test_kernel_register_budget():
         assert v["occupancy_waves_per_simd"] >= 3 and v["scratch_bytes_per_lane"] == 0, (k, v)
     for k, v in fwd.items():
         assert v["occupancy_waves_per_simd"] >= 3 and v["scratch_bytes_per_lane"] <= 96, (k, v)
+    fwp = {k: v for k, v in res.items() if "render_fwd_pass_kernel" in k}          # the three-launch forward (csrc/nsr_fwd2.h)
+    assert len(fwp) == 4
+    for k, v in fwp.items():
+        assert v["occupancy_waves_per_simd"] >= 3 and v["scratch_bytes_per_lane"] <= 128, (k, v)

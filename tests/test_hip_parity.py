@@ -69,9 +69,11 @@ def test_forward_backward_small(stage):
 
 @pytest.mark.parametrize("stage", ("middle", "fine", "color"))
 def test_saved_activations_and_forward_rerun_agree(stage):
-    """Renderer.save_activations (default: the forward writes hidden states + relu masks, a backward kernel variant loads
-    them) against the variant that re-runs the decoder forward: same outputs bit for bit, same gradients up to the order of
-    the gradient atomics; the re-run variant is also held to the oracle (the default one is by every other test)."""
+    """Renderer.save_activations (default: the forward runs as sample placement -> per-decoder passes -> compositor
+    (csrc/nsr_fwd2.h) and writes hidden states + relu masks, the split backward loads them) against the one-launch forward
+    kernel + the backward that re-runs the decoder forward: same outputs BIT FOR BIT (the two forward implementations share
+    every expression), same gradients up to the order of the gradient atomics; the re-run variant is also held to the oracle
+    (the default one is by every other test)."""
     sc = make_scene(seed=14, n_rays=301, small=True)
     prod = build_product(sc, "cuda:0")
     saved = hip_render(sc, stage, backward=True, product=prod)
