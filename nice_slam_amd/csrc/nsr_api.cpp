@@ -334,7 +334,9 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
             nblocks = nb > nblocks ? nb : nblocks;
         }
         for (int r = rows; r < 3; ++r) R.job[r] = nsr::FinalJob{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
-        NSR_LAUNCH(nsr::bwd_finalize_kernel, dim3(nblocks, rows), dim3(1024), (2048 + 32 + 1024) * 4, stream, R);
+        // (512 threads = four resident blocks per CU instead of two was measured: 17.4 vs 15.1 us -- the kernel is a chain of round trips, not a queue of blocks)
+        static const int fin_threads = env_int("NSR_FIN_THREADS", 1024);
+        NSR_LAUNCH(nsr::bwd_finalize_kernel, dim3(nblocks, rows), dim3(fin_threads), (2048 + 32 + 1024) * 4, stream, R);
     }
     if (b->ev_stop) nsr::rt_record(b->ev_stop, stream);
     return finish("nsr_render_bwd(split)");

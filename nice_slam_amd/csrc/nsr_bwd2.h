@@ -718,11 +718,15 @@ NSR_DEV void dw_compute(const RenderParams &P, W &Wv, float *ring, int *ctl, flo
     typedef DwLay<KIND> Y;
     Wv.init(P, lane & 15);
     const long long ntiles = (P.n_points_total + kTile - 1) / kTile;
+    const long long ntl = (P.xflags & 64) ? 0 : ntiles;             // measurement: no tiles (prologue + flush only)
     const long long last = ntiles - 1, step = nbp;
     const int ragged = (int)(P.n_points_total & (kTile - 1));
+    // (Requesting tile k + 1's operands into a second register set before tile k's MFMAs -- the two waves of a SIMD wait for
+    // the same slot flags, so their flag / read / wait phases coincide -- needs 168 VGPRs + 64-320 B of scratch at the three
+    // waves per SIMD a 10-wave block implies: 135 us instead of 65, profiles/r03_dw_variants.txt.)
     typename W::Ops ops;
     int k = 0;
-    for (long long t = bi; t < ntiles; t += step, ++k) {
+    for (long long t = bi; t < ntl; t += step, ++k) {
         loop_fence();
         while (flag_load(ctl + (k & 1)) <= (k >> 1)) spin_pause();          // the loader of this tile has landed it
         Wv.fetch(dw_src<KIND>(ring + (k % kDwRing) * Y::kSlot), lane, ops);
@@ -736,9 +740,9 @@ template <int KIND>
 NSR_DEV void dw_loader(const RenderParams &P, float *ring, int *ctl, int j, int lane, int bi, int nbp) {
     typedef DwLay<KIND> Y;
     const long long ntiles = (P.n_points_total + kTile - 1) / kTile;
-    const long long step = nbp;
+    const long long step = nbp, ntl = (P.xflags & 64) ? 0 : ntiles;
     int m = 0;                                                               // this loader's m-th tile is the block's tile 2 m + j
-    for (long long t = bi + j * step; t < ntiles; t += kDwLoaders * step, ++m) {
+    for (long long t = bi + j * step; t < ntl; t += kDwLoaders * step, ++m) {
         loop_fence();
         const int k = kDwLoaders * m + j;
         if (k >= kDwRing) {                                                  // the slot still holds tile k - kDwRing
@@ -866,35 +870,34 @@ NSR_KERNEL void bwd_finalize_kernel(const FinalParams R) {
     if (i > 4) return;                                              // (grid sized for the largest decoder of the stage)
     // the colour decoder's 4th output is discarded (decoder.py:341): three rows
     const int nrow = i < 4 ? 32 : (nout == 1 ? 1 : 3), goff = xyz_fcw(cd, i);
-    const int e = t & 127, o = e >> 2, c = 4 * chunk + (e & 3), sl = t >> 7;
+    const int e = t & 127, o = e >> 2, c = 4 * chunk + (e & 3), sl = t >> 7, nsl = nt >> 7;       // 128 elements x nsl slices
     // W[o][k]: pts_linears.(i+1).weight (hidden-state columns) or output_linear.weight -- staged in LDS while the image sums
     // are in flight (read straight from memory inside the 32-step product it was 32 dependent L2 round trips: ~10 us)
     const int woff = i < 4 ? xyz_w(cd, i + 1) + (i == 2 ? kE : 0) : xyz_wo(cd);
     const int wstr = i < 4 ? xyz_in(i + 1) : 32;
     float *wl = red + 2048 + 32;                                    // [32][32]
-    wl[t] = (t >> 5) < nrow ? J.params[woff + (t >> 5) * wstr + (t & 31)] : 0.f;
+    for (int q = t; q < 1024; q += nt) wl[q] = (q >> 5) < nrow ? J.params[woff + (q >> 5) * wstr + (q & 31)] : 0.f;
     {
         float sg = 0.f;
-        if (o < nrow) sg = strided_sum(J.images + goff + o * cd + c, R.stride, sl, 8, J.nimg);
+        if (o < nrow) sg = strided_sum(J.images + goff + o * cd + c, R.stride, sl, nsl, J.nimg);
         red[t] = sg;
     }
     if (chunk == 0) {
-        const int ob = t & 31, sb = t >> 5;
+        const int ob = t & 31, sb = t >> 5;                         // 32 bias elements x nt / 32 slices
         const int boff = i < 4 ? xyz_b(cd, i + 1) : xyz_bo(cd, nout);
         float sbv = 0.f;
-        if (ob < nrow) sbv = strided_sum(J.images + boff + ob, R.stride, sb, 32, J.nimg);
+        if (ob < nrow) sbv = strided_sum(J.images + boff + ob, R.stride, sb, nt >> 5, J.nimg);
         red[1024 + t] = sbv;
     }
     block_sync();
     if (t < 128) {
         float sg = red[t];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) sg += red[k * 128 + t];
+        for (int k = 1; k < nsl; ++k) sg += red[k * 128 + t];
         red[t] = sg;
     }
     if (chunk == 0 && t >= 256 && t < 288) {
         float sbv = 0.f;
-        for (int k = 0; k < 32; ++k) sbv += red[1024 + k * 32 + (t - 256)];
+        for (int k = 0; k < (nt >> 5); ++k) sbv += red[1024 + k * 32 + (t - 256)];
         red[2048 + (t - 256)] = sbv;
     }
     block_sync();
