@@ -3,7 +3,7 @@
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 launched under
 torch.distributed.run, one rank per GPU.  One STEP = one mapping iteration's pass of the hot path over one ray batch:
-index draw -> window sampling (all keyframes, bounding-box mask) -> render forward -> mapping loss -> backward (every grid,
+window sampling (pixel draw inside the kernel, all keyframes, bounding-box mask) -> render forward -> mapping loss -> backward (every grid,
 every decoder, like the reference's autograd; no optimiser: Adam and the masked write-back belong to the caller,
 SURVEY §8(f)).  Default workload = BASELINE configs[1] (Replica room0 full config); ``--config {0,2,3,4,tracking}`` selects
 the other BASELINE configurations.  For the staged configurations the stage of step i follows the reference schedule of a
@@ -519,10 +519,10 @@ def main():
                        "stage_mix": {s: stages.count(s) for s in sorted(set(stages))},
                        "timed_region": (("get_samples (crop) + bounding-box mask + render_batch_ray(color) + tracking loss (torch) + backward to the pose"
                                          if args.unfused else
-                                         "index draw + window kernel (crop, bounding-box mask) + render forward (colour stage) + tracking loss kernel "
+                                         "window kernel (pixel draw: philox inside the kernel; crop, bounding-box mask) + render forward (colour stage) + tracking loss kernel "
                                          "(median mask) + render backward + pose gradient") if tracking else
                                         ("get_samples x window + cat + render_batch_ray + torch loss + backward" if args.unfused else
-                                         "index draw + window sampling kernel + render forward (with the mapping loss) + render backward") +
+                                         "window sampling kernel (pixel draw: philox inside the kernel) + render forward (with the mapping loss) + render backward") +
                                         " (all grid + all decoder grads, like the reference autograd), no optimiser"),
                        "decoder_grads": "none (tracking)" if tracking else ("colour decoder only (what Mapper's optimiser steps)" if args.stepped_grads_only else "all decoders (reference autograd semantics)"),
                        "launch": "hipGraph replay (one captured graph per stage)" if use_graph else "eager",

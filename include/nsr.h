@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define NSR_VERSION 4
+#define NSR_VERSION 5
 
 /* stages of NICE.forward (decoder.py:312-342) */
 enum { NSR_STAGE_COARSE = 0, NSR_STAGE_MIDDLE = 1, NSR_STAGE_FINE = 2, NSR_STAGE_COLOR = 3 };
@@ -176,6 +176,15 @@ int nsr_get_samples_window(const int64_t *indices, int32_t K, int64_t n, int32_t
                            int32_t W_full, float fx, float fy, float cx, float cy, const nsr_frame *frames,
                            float *rays_o, float *rays_d, float *out_depth, float *out_color,
                            const double *bound_lo, const double *bound_hi, uint8_t *keep, float *kept_max, void *stream);
+/* The same with the pixel draw of src/common.py:99 (`torch.randint(h * w, (n,))`, one call per keyframe there) inside the
+ * kernel: ray t of the window takes one uniform index in [0, crop_h * crop_w) from philox4x32-10 (counter = (t, calls so far),
+ * key = seed) and the drawn indices are written to indices_out [K * n] (for nsr_pose_grad and the caller).  rng_state: three
+ * uint64 on the device -- {seed, calls so far, 0} -- owned by the caller and advanced by the kernel, so that a captured graph
+ * draws afresh on every replay without the host.  Same distribution as the reference's draw, not the same stream. */
+int nsr_get_samples_window_draw(int64_t *indices_out, uint64_t *rng_state, int32_t K, int64_t n, int32_t H0, int32_t H1, int32_t W0,
+                                int32_t W1, int32_t W_full, float fx, float fy, float cx, float cy, const nsr_frame *frames,
+                                float *rays_o, float *rays_d, float *out_depth, float *out_color,
+                                const double *bound_lo, const double *bound_hi, uint8_t *keep, float *kept_max, void *stream);
 /* gradient of the K poses from the ray gradients of such a window (autograd of src/common.py:74-88; local BA,
  * src/Mapper.py:417-419,441-453): d_c2w + k * out_stride holds rows 0..2 of pose k's gradient, row-major (12 floats;
  * out_stride = 12 for 3x4 poses, 16 for 4x4 ones whose last row the caller zero-fills). */

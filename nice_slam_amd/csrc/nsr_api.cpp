@@ -601,18 +601,24 @@ int nsr_frustum_mask(const float *w2c, const float *cam_center, double fx, doubl
     return finish("nsr_frustum_mask");
 }
 
-int nsr_get_samples_window(const int64_t *indices, int32_t K, int64_t n, int32_t H0, int32_t H1, int32_t W0, int32_t W1,
-                           int32_t W_full, float fx, float fy, float cx, float cy, const nsr_frame *frames,
-                           float *rays_o, float *rays_d, float *out_depth, float *out_color,
-                           const double *bound_lo, const double *bound_hi, uint8_t *keep, float *kept_max, void *stream) {
+}  // extern "C"
+namespace {
+int window_launch(const int64_t *indices, int64_t *indices_out, uint64_t *rng, int32_t K, int64_t n, int32_t H0, int32_t H1, int32_t W0, int32_t W1,
+                  int32_t W_full, float fx, float fy, float cx, float cy, const nsr_frame *frames,
+                  float *rays_o, float *rays_d, float *out_depth, float *out_color,
+                  const double *bound_lo, const double *bound_hi, uint8_t *keep, float *kept_max, void *stream) {
     if (K < 0 || K > NSR_MAX_WINDOW) return fail("nsr_get_samples_window: K must be in [0, 32]");
     if (n < 0 || H1 <= H0 || W1 <= W0 || W_full < W1) return fail("nsr_get_samples_window: bad crop");
     if (K == 0 || n == 0) return 0;
-    if (!indices || !frames || !rays_o || !rays_d || !out_depth || !out_color || !bound_lo || !bound_hi)
+    if ((!indices && (!indices_out || !rng)) || !frames || !rays_o || !rays_d || !out_depth || !out_color || !bound_lo || !bound_hi)
         return fail("nsr_get_samples_window: null pointer");
+    if ((long long)(H1 - H0) * (W1 - W0) >= (1ll << 32)) return fail("nsr_get_samples_window: crop too large");
     nsr::WindowParams P;
     std::memset(&P, 0, sizeof(P));
     P.indices = reinterpret_cast<const long long *>(indices);
+    P.indices_out = reinterpret_cast<long long *>(indices_out);
+    P.rng = reinterpret_cast<unsigned long long *>(rng);
+    P.crop_pixels = (unsigned)((H1 - H0) * (W1 - W0));
     P.n = n; P.K = K; P.H0 = H0; P.W0 = W0; P.crop_w = W1 - W0; P.W_full = W_full;
     P.fx = fx; P.fy = fy; P.cx = cx; P.cy = cy;
     for (int k = 0; k < K; ++k) {
@@ -625,6 +631,25 @@ int nsr_get_samples_window(const int64_t *indices, int32_t K, int64_t n, int32_t
     const int tb = 256;
     NSR_LAUNCH(nsr::get_samples_window_kernel, dim3((unsigned)((n + tb - 1) / tb), K), dim3(tb), 0, stream, P);
     return finish("nsr_get_samples_window");
+}
+}  // namespace
+extern "C" {
+
+int nsr_get_samples_window(const int64_t *indices, int32_t K, int64_t n, int32_t H0, int32_t H1, int32_t W0, int32_t W1,
+                           int32_t W_full, float fx, float fy, float cx, float cy, const nsr_frame *frames,
+                           float *rays_o, float *rays_d, float *out_depth, float *out_color,
+                           const double *bound_lo, const double *bound_hi, uint8_t *keep, float *kept_max, void *stream) {
+    if (!indices) return fail("nsr_get_samples_window: null pointer");
+    return window_launch(indices, nullptr, nullptr, K, n, H0, H1, W0, W1, W_full, fx, fy, cx, cy, frames, rays_o, rays_d, out_depth, out_color,
+                         bound_lo, bound_hi, keep, kept_max, stream);
+}
+
+int nsr_get_samples_window_draw(int64_t *indices_out, uint64_t *rng_state, int32_t K, int64_t n, int32_t H0, int32_t H1, int32_t W0,
+                                int32_t W1, int32_t W_full, float fx, float fy, float cx, float cy, const nsr_frame *frames,
+                                float *rays_o, float *rays_d, float *out_depth, float *out_color,
+                                const double *bound_lo, const double *bound_hi, uint8_t *keep, float *kept_max, void *stream) {
+    return window_launch(nullptr, indices_out, rng_state, K, n, H0, H1, W0, W1, W_full, fx, fy, cx, cy, frames, rays_o, rays_d, out_depth,
+                         out_color, bound_lo, bound_hi, keep, kept_max, stream);
 }
 
 int nsr_pose_grad(const int64_t *indices, int32_t K, int64_t n, int32_t H0, int32_t H1, int32_t W0, int32_t W1,

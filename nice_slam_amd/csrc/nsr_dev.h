@@ -126,6 +126,7 @@ NSR_DEV void atomic_add_lds_i(int *p, int v) { atomicAdd(p, v); }
 NSR_DEV int atomic_fetch_add_lds_i(int *p, int v) { return atomicAdd(p, v); }
 NSR_DEV int atomic_cas_lds_i(int *p, int expect, int v) { return atomicCAS(p, expect, v); }
 NSR_DEV void atomic_add_global_d(double *p, double v) { unsafeAtomicAdd(p, v); }
+NSR_DEV unsigned long long atomic_fetch_add_global_u64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 // max of non-negative floats (their bit patterns order like unsigned integers)
 NSR_DEV void atomic_max_pos(float *p, float v) { atomicMax(reinterpret_cast<unsigned *>(p), __builtin_bit_cast(unsigned, v)); }
 

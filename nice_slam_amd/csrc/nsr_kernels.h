@@ -1253,8 +1253,23 @@ NSR_KERNEL void get_samples_kernel(const SampleParams P) {
 // with its bounding-box pre-filter (:471-481) as a byte mask + the kept rays' maximum depth.  grid.y = frame.
 // ------------------------------------------------------------------------------------------------
 #define NSR_MAX_WINDOW 32
+// philox4x32-10 (Salmon et al., SC'11; the generator torch.randint runs on the device): 128-bit counter, 64-bit key
+NSR_DEV unsigned philox_word(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
 struct WindowParams {
-    const long long *indices;          // [K][n]
+    const long long *indices;          // [K][n]; NULL: the kernel draws them (rng) and writes them to indices_out
+    long long *indices_out;
+    unsigned long long *rng;           // [seed, calls so far, blocks done (internal)]: one uniform draw in [0, crop_h * crop_w) per
+    unsigned crop_pixels;              //   ray from philox(counter = (ray, call), key = seed); the last block advances `calls`
     long long n;
     int K, H0, W0, crop_w, W_full;
     float fx, fy, cx, cy;
@@ -1269,9 +1284,17 @@ struct WindowParams {
 NSR_KERNEL void get_samples_window_kernel(const WindowParams P) {
     const long long i = (long long)bid_x() * nthreads() + tid();
     const int k = bid_y();
-    if (i >= P.n) return;
+    if (i < P.n) {
     const long long t = (long long)k * P.n + i;
-    const long long idx = P.indices[t];
+    long long idx;
+    if (P.indices) {
+        idx = P.indices[t];
+    } else {
+        const unsigned long long seed = P.rng[0], call = P.rng[1];
+        const unsigned r = philox_word((unsigned)t, (unsigned)(t >> 32), (unsigned)call, (unsigned)(call >> 32), (unsigned)seed, (unsigned)(seed >> 32));
+        idx = (long long)(((unsigned long long)r * P.crop_pixels) >> 32);                  // uniform up to 2^-32 * crop_pixels
+        P.indices_out[t] = idx;
+    }
     const int row = (int)(idx / P.crop_w) + P.H0, col = (int)(idx % P.crop_w) + P.W0;
     const long long pix = (long long)row * P.W_full + col;
     const float gd = P.depth[k][pix];
@@ -1295,6 +1318,15 @@ NSR_KERNEL void get_samples_window_kernel(const WindowParams P) {
     const bool kp = tb >= (double)gd;
     if (P.keep) P.keep[t] = kp ? 1 : 0;
     if (kp && P.kept_max && gd > 0.f) atomic_max_pos(P.kept_max, gd);
+    }
+    if (!P.indices) {
+        // the last block to get here (every thread of every block has read the call counter by then) advances it
+        block_sync();
+        if (tid() == 0) {
+            const unsigned long long total = (unsigned long long)nblk_x() * P.K;
+            if (atomic_fetch_add_global_u64(P.rng + 2, 1ull) == total - 1) { P.rng[2] = 0ull; P.rng[1] = P.rng[1] + 1ull; }
+        }
+    }
 }
 
 // gradient of the window's poses from the ray gradients (autograd of common.py:74-88): per frame k

@@ -19,6 +19,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from . import _capi
@@ -51,11 +53,52 @@ def _bound_arrays(bound):
     return lo, hi
 
 
+# Where the pixel indices of a window come from when the caller passes none (src/common.py:99: `torch.randint(h * w, (n,))`
+# per keyframe): "kernel" -- drawn inside the window kernel (philox4x32-10 keyed by torch's seed, nsr_get_samples_window_draw):
+# no launch of its own and, under graph capture, none of the fills with which torch keeps a captured generator's offset -- or
+# "torch" -- one `torch.randint` call for the window.  Same distribution either way; neither is the reference's stream (it
+# draws once per keyframe).  `get_samples` (the drop-in of common.py:91-106) always uses torch.randint like the reference.
+PIXEL_DRAW = os.environ.get("NSR_PIXEL_DRAW", "kernel")
+_DRAW_STATE = {}
+
+
+def _draw_state(dev) -> torch.Tensor:
+    """Device-side state of the in-kernel draw: [seed, calls so far, internal]; follows torch.manual_seed (a new seed starts a
+    new sequence) and is advanced by the kernel itself, so replays of a captured graph draw afresh."""
+    key = (dev.type, dev.index)
+    seed = torch.initial_seed() & ((1 << 63) - 1)
+    st = _DRAW_STATE.get(key)
+    if st is None or st[0] != seed:
+        st = (seed, torch.tensor([seed, 0, 0, 0], dtype=torch.int64, device=dev))
+        _DRAW_STATE[key] = st
+    return st[1]
+
+
+def seed_pixel_draws(seed: int, device=None):
+    """Restart the in-kernel pixel draw of ``device`` (default: every device that has drawn so far) from ``seed``.  (A NEW
+    ``torch.manual_seed`` value restarts it too; re-seeding torch with the SAME value cannot be seen from here.)"""
+    keys = list(_DRAW_STATE) if device is None else [(torch.device(device).type, torch.device(device).index)]
+    for key in keys:
+        dev = torch.device(*key) if key[1] is not None else torch.device(key[0])
+        tag = _DRAW_STATE[key][0] if key in _DRAW_STATE else torch.initial_seed() & ((1 << 63) - 1)
+        _DRAW_STATE[key] = (tag, torch.tensor([int(seed) & ((1 << 63) - 1), 0, 0, 0], dtype=torch.int64, device=dev))
+
+
 def _launch_window(indices, K, n, crop, intr, frames, bound6, sbuf, keep, kmax_ptr, dev):
     lib = _capi.get_lib()
     H0, H1, W0, W1, W_full = crop
     fx, fy, cx, cy = intr
     N = K * n
+    if getattr(indices, "_nsr_draw", False):               # drawn by the kernel, written to `indices` for the backward / the caller
+        indices._nsr_draw = False
+        state = getattr(indices, "_nsr_state", None)
+        if state is None:
+            state = _draw_state(dev)
+        lib.check(lib.nsr_get_samples_window_draw(indices.data_ptr(), state.data_ptr(), K, n, H0, H1, W0, W1, W_full,
+                                                  fx, fy, cx, cy, frames, sbuf.data_ptr(), sbuf.data_ptr() + 12 * N,
+                                                  sbuf.data_ptr() + 24 * N, sbuf.data_ptr() + 28 * N, bound6[0], bound6[1],
+                                                  keep.data_ptr(), kmax_ptr, _stream(dev)), "nsr_get_samples_window_draw")
+        return
     lib.check(lib.nsr_get_samples_window(indices.data_ptr(), K, n, H0, H1, W0, W1, W_full, fx, fy, cx, cy, frames,
                                          sbuf.data_ptr(), sbuf.data_ptr() + 12 * N, sbuf.data_ptr() + 24 * N, sbuf.data_ptr() + 28 * N,
                                          bound6[0], bound6[1], keep.data_ptr(), kmax_ptr, _stream(dev)), "nsr_get_samples_window")
@@ -84,22 +127,28 @@ class _WindowFn(torch.autograd.Function):
         return (None, *[g.to(device=dv, dtype=dt) for g, dv, dt in zip(grads, devs, dtypes)])
 
 
-def pose_grads(indices, K, n, crop, intr, g_o, g_d, shapes) -> List[torch.Tensor]:
-    """d c2w[k] (shape of the pose, rows 0..2 filled) from the gradients of the window's rays: one launch."""
+def pose_grads(indices, K, n, crop, intr, g_o, g_d, shapes, out=None) -> List[torch.Tensor]:
+    """d c2w[k] (shape of the pose, rows 0..2 filled) from the gradients of the window's rays: one launch.  ``out``: an already
+    zero-filled [K, 4, 4] fp32 tensor (the fused iteration's one zero-filled buffer has room for it), else allocated here."""
     lib = _capi.get_lib()
     dev = g_o.device
     H0, H1, W0, W1, _ = crop
     fx, fy, cx, cy = intr
-    out = torch.zeros((K, 4, 4), dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.zeros((K, 4, 4), dtype=torch.float32, device=dev)
     lib.check(lib.nsr_pose_grad(indices.data_ptr(), K, n, H0, H1, W0, W1, fx, fy, cx, cy, g_o.data_ptr(), g_d.data_ptr(),
                                 out.data_ptr(), 16, _stream(dev)), "nsr_pose_grad")
     return [out[k, :shp[0], :] for k, shp in enumerate(shapes)], out
 
 
-def _window_meta(H0, H1, W0, W1, n, W, fx, fy, cx, cy, c2ws, depths, colors, bound, device, indices):
+def _window_meta(H0, H1, W0, W1, n, W, fx, fy, cx, cy, c2ws, depths, colors, bound, device, indices, draw_state=None):
     K = len(depths)
     dev = torch.device(device)
-    if indices is None:
+    if indices is None and (PIXEL_DRAW == "kernel" or draw_state is not None) and dev.type == "cuda":
+        indices = torch.empty((K * n,), dtype=torch.int64, device=dev)            # filled by the window kernel (see PIXEL_DRAW)
+        indices._nsr_draw = True
+        indices._nsr_state = draw_state                                           # None: the device's default state
+    elif indices is None:
         indices = torch.randint((H1 - H0) * (W1 - W0), (K * n,), device=dev)      # one draw for the window (common.py:99 per frame)
     else:
         indices = indices.to(dev).reshape(-1).contiguous()
@@ -115,7 +164,7 @@ def get_samples_window(H0, H1, W0, W1, n, H, W, fx, fy, cx, cy, c2ws: Sequence[t
     ``colors[k]`` [H,W,3] on the device), concatenated in frame order -- the sampling loop of Mapper.py:437-468 -- plus the
     bounding-box pre-filter of :471-481 as ``keep`` (bool per ray) and ``kept_max`` (1-element tensor: maximum depth over
     the kept rays, to be passed as ``render_batch_ray(..., gt_max=kept_max)``).  ``indices``: optional [K*n] flat crop
-    indices (default: one ``torch.randint`` draw)."""
+    indices (default: drawn inside the kernel, see ``PIXEL_DRAW``)."""
     meta, c2ws = _window_meta(H0, H1, W0, W1, n, W, fx, fy, cx, cy, c2ws, depths, colors, bound, device, indices)
     _require_cuda(depths[0] if depths[0].is_cuda else torch.empty(0, device=meta[-1]), "get_samples_window: frames")
     ro, rd, gd, gc, keep, kmax = _WindowFn.apply(meta, *c2ws)
@@ -151,7 +200,8 @@ class _MappingLossFn(torch.autograd.Function):
         if need_bwd:
             n_grad = sum(grids[s].numel() for s, nd in zip(slots, need_grid) if nd) + (6 * N if need_pose else 0) + \
                 sum(param_count(s) for s, nd in zip(slots, need_par) if nd)
-        Z = torch.zeros((4 + n_grad,), dtype=torch.float32, device=dev)
+        n_pose = 16 * K if need_pose else 0                     # d c2w of the window (pose_grads), behind the gradients
+        Z = torch.zeros((4 + n_grad + n_pose,), dtype=torch.float32, device=dev)
         loss = Z[:2].view(torch.float64)
         kmax = Z[2:3]
         frames, hold = _frames_block(c2ws, depths, colors, dev)
@@ -197,6 +247,7 @@ class _MappingLossFn(torch.autograd.Function):
                        uncertainty=var, color=rgb, indices=indices)
         if need_bwd:
             ctx.sharder, ctx.loss32 = sharder, Z[3:4]
+            ctx.pose_buf = Z[4 + n_grad:4 + n_grad + n_pose].view(K, 4, 4) if need_pose else None
             ctx.state = (a, (renderer, decoders, stage, S, None if sharder is None else sharder.collect),
                          ([kmax, F, sbuf, Z, hold, acts], rays_o, rays_d, gt_depth, grids, flats, packed, raw, depth),
                          (need_pose, need_grid, need_par), dl_depth,
@@ -221,7 +272,7 @@ class _MappingLossFn(torch.autograd.Function):
         g_pose = [None] * K
         gp, pose_base = None, None
         if need_pose:
-            gp, pose_base = pose_grads(indices, K, n, crop, intr, d_o, d_d, shapes)
+            gp, pose_base = pose_grads(indices, K, n, crop, intr, d_o, d_d, shapes, out=ctx.pose_buf)
         if ctx.sharder is not None:                            # multi-GPU: ONE packed all-reduce of everything this iteration produced
             ctx.loss32.copy_(kept[0][3][:2].view(torch.float64).to(torch.float32))
             ctx.sharder.exchange([("grid_" + s_, g) for s_, g in zip(stage_slots(meta[2]), d_grids) if g is not None], pose_base, ctx.loss32)
@@ -234,7 +285,8 @@ class _MappingLossFn(torch.autograd.Function):
 
 def mapping_loss(renderer, c, decoders, frames: Sequence[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], pixs_per_image: int,
                  stage: str, w_color: float = 0.2, device=None, indices: Optional[torch.Tensor] = None, coarse_mapper: bool = False,
-                 crop: Optional[Tuple[int, int, int, int]] = None, out: Optional[dict] = None, sharder=None) -> torch.Tensor:
+                 crop: Optional[Tuple[int, int, int, int]] = None, out: Optional[dict] = None, sharder=None,
+                 draw_state: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One mapping iteration's loss (src/Mapper.py:437-493) as a single autograd node.
 
     ``frames``: ``(c2w, depth [H,W], color [H,W,3])`` per frame of the window, in the reference's order; a pose that requires
@@ -248,7 +300,8 @@ def mapping_loss(renderer, c, decoders, frames: Sequence[Tuple[torch.Tensor, tor
     dev = torch.device(device) if device is not None else frames[0][1].device
     H0, H1, W0, W1 = crop if crop is not None else (0, renderer.H, 0, renderer.W)
     wmeta, c2ws = _window_meta(H0, H1, W0, W1, pixs_per_image, renderer.W, renderer.fx, renderer.fy, renderer.cx, renderer.cy,
-                               [f[0] for f in frames], [f[1] for f in frames], [f[2] for f in frames], renderer.bound, dev, indices)
+                               [f[0] for f in frames], [f[1] for f in frames], [f[2] for f in frames], renderer.bound, dev, indices,
+                               draw_state=draw_state)
     slots = stage_slots(stage)
     grids = _prep_grids(c, stage, dev)
     gates = [_gate(dev, torch.is_grad_enabled() and decoders.sub(s).wants_grad() and

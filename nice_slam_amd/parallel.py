@@ -257,6 +257,7 @@ class ShardedMapping:
         # a generator of this object, seeded per rank.
         self.seed = int(seed)
         self._gen = None
+        self._draw_state = None
 
     def generator(self, dev) -> torch.Generator:
         """This rank's pixel generator.  A hipGraph that captures ``mapping_loss`` must know it:
@@ -269,6 +270,15 @@ class ShardedMapping:
 
     def _draw(self, n_total: int, n_pixels_crop: int, dev) -> torch.Tensor:
         return torch.randint(n_pixels_crop, (n_total,), device=dev, generator=self.generator(dev))
+
+    def draw_state(self, dev) -> torch.Tensor:
+        """This rank's state of the in-kernel pixel draw (mapping.PIXEL_DRAW = "kernel"): seeded per rank like ``generator``,
+        advanced by the window kernel itself -- nothing to register with a capturing graph."""
+        dev = torch.device(dev)
+        if self._draw_state is None or self._draw_state.device != dev:
+            s = (self.seed * 1000003 + 7919 * (dist.get_rank(self.group) + 1)) & ((1 << 63) - 1)
+            self._draw_state = torch.tensor([s, 0, 0, 0], dtype=torch.int64, device=dev)
+        return self._draw_state
 
     def set_voxel_masks(self, masks):
         """dict grid key -> bool/uint8 [Z,Y,X] voxel mask (``FrustumSelector.voxel_mask``), identical on every rank;
@@ -332,9 +342,13 @@ class ShardedMapping:
     def mapping_loss(self, c, decoders, frames, pixs_per_image, stage, w_color: float = 0.2, indices=None, out=None):
         """This rank's share of one mapping iteration (``pixs_per_image`` pixels per frame HERE); returns the rank's partial
         loss -- ``backward()`` leaves the all-rank gradients on every rank (and the all-rank loss in ``last_total_loss``)."""
-        from .mapping import mapping_loss
-        if indices is None:                  # this rank's own draw (see __init__): never the global generator
+        from . import mapping
+        state = None
+        if indices is None:                  # this rank's own draw (see __init__): never the global generator / the device's state
             dev = frames[0][1].device
-            indices = self._draw(len(frames) * int(pixs_per_image), self.renderer.H * self.renderer.W, dev)
-        return mapping_loss(self.renderer, c, decoders, frames, pixs_per_image, stage, w_color=w_color, indices=indices,
-                            coarse_mapper=(stage == "coarse"), out=out, sharder=self)
+            if mapping.PIXEL_DRAW == "kernel" and dev.type == "cuda":
+                state = self.draw_state(dev)
+            else:
+                indices = self._draw(len(frames) * int(pixs_per_image), self.renderer.H * self.renderer.W, dev)
+        return mapping.mapping_loss(self.renderer, c, decoders, frames, pixs_per_image, stage, w_color=w_color, indices=indices,
+                                    coarse_mapper=(stage == "coarse"), out=out, sharder=self, draw_state=state)

@@ -188,6 +188,7 @@ NSR_DEV void atomic_add_lds_i(int *p, int v) { *p += v; }
 NSR_DEV int atomic_fetch_add_lds_i(int *p, int v) { const int o = *p; *p += v; return o; }
 NSR_DEV int atomic_cas_lds_i(int *p, int expect, int v) { const int o = *p; if (o == expect) *p = v; return o; }
 NSR_DEV void atomic_add_global_d(double *p, double v) { *p += v; }
+NSR_DEV unsigned long long atomic_fetch_add_global_u64(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
 NSR_DEV void atomic_max_pos(float *p, float v) {
     uint32_t *u = reinterpret_cast<uint32_t *>(p);
     uint32_t nw, old = __atomic_load_n(u, __ATOMIC_RELAXED);

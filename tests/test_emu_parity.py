@@ -429,6 +429,68 @@ def test_get_samples_window_and_pose_grad(emu):
         assert np.all(out[k, 3] == 0)
 
 
+def _philox_word(c, key):
+    """philox4x32-10, first output word, restated from Salmon et al. (SC'11) -- the test's own copy, vectorised over counters
+    c [n, 4] uint32; key (k0, k1)."""
+    c = c.astype(np.uint64).copy()
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    M0, M1, m32 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[:, 0], M1 * c[:, 2]
+        n0 = ((p1 >> np.uint64(32)) ^ c[:, 1] ^ k0) & m32
+        n2 = ((p0 >> np.uint64(32)) ^ c[:, 3] ^ k1) & m32
+        c = np.stack([n0, p1 & m32, n2, p0 & m32], 1)
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & m32, (k1 + np.uint64(0xBB67AE85)) & m32
+    return c[:, 0]
+
+
+def test_window_kernel_draws_its_own_pixels(emu):
+    """nsr_get_samples_window_draw: the index draw of common.py:99 inside the window kernel -- philox4x32-10(counter = (ray,
+    call), key = seed) mapped to [0, crop pixels) -- equals the test's own philox, the rays equal those of the explicit-index
+    entry point on the drawn indices, and the kernel advances the call counter (a second call draws other pixels)."""
+    import ctypes as C
+    from emu_harness import ptr
+    from nice_slam_amd import _capi
+    sc, frames, idx, (H0, H1, W0, W1) = _window_case()
+    H, W, fx, fy, cx, cy = sc["intr"]
+    K, n = len(frames), 300                                  # two blocks of 256 per frame: the last-block hand-off is exercised
+    N = K * n
+    fr = (_capi.NsrFrame * K)()
+    hold = []
+    for k, (c2w, d, col) in enumerate(frames):
+        arrs = [np.ascontiguousarray(d.numpy(), dtype=np.float32), np.ascontiguousarray(col.numpy(), dtype=np.float32), np.ascontiguousarray(c2w.numpy(), dtype=np.float32)]
+        hold += arrs
+        fr[k].depth, fr[k].color, fr[k].c2w, fr[k].c2w_stride = arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, 4
+    b = sc["bound"]
+    lo, hi = (C.c_double * 3)(*b[:, 0].tolist()), (C.c_double * 3)(*b[:, 1].tolist())
+    seed = 0x1234567811223344
+    state = np.array([seed, 7, 0, 0], dtype=np.uint64)
+    draws = []
+    for call in (7, 8):
+        ind = np.full((N,), -1, np.int64)
+        ro, rd = np.full((N, 3), np.nan, np.float32), np.full((N, 3), np.nan, np.float32)
+        gd, gc = np.full((N,), np.nan, np.float32), np.full((N, 3), np.nan, np.float32)
+        keep, kmax = np.full((N,), 9, np.uint8), np.zeros((1,), np.float32)
+        emu.check(emu.nsr_get_samples_window_draw(ptr(ind), ptr(state), K, n, H0, H1, W0, W1, W, fx, fy, cx, cy, fr, ptr(ro), ptr(rd),
+                                                  ptr(gd), ptr(gc), lo, hi, ptr(keep), ptr(kmax), None))
+        assert state.tolist() == [seed, call + 1, 0, 0]
+        ctr = np.zeros((N, 4), np.uint32)
+        ctr[:, 0], ctr[:, 2] = np.arange(N), call
+        r = _philox_word(ctr, (seed & 0xFFFFFFFF, seed >> 32))
+        crop = (H1 - H0) * (W1 - W0)
+        assert np.array_equal(ind, ((r * np.uint64(crop)) >> np.uint64(32)).astype(np.int64))
+        assert ind.min() >= 0 and ind.max() < crop
+        ro2, rd2 = np.full((N, 3), np.nan, np.float32), np.full((N, 3), np.nan, np.float32)
+        gd2, gc2 = np.full((N,), np.nan, np.float32), np.full((N, 3), np.nan, np.float32)
+        keep2, kmax2 = np.full((N,), 9, np.uint8), np.zeros((1,), np.float32)
+        emu.check(emu.nsr_get_samples_window(ptr(ind), K, n, H0, H1, W0, W1, W, fx, fy, cx, cy, fr, ptr(ro2), ptr(rd2), ptr(gd2), ptr(gc2),
+                                             lo, hi, ptr(keep2), ptr(kmax2), None))
+        for a_, b_ in ((ro, ro2), (rd, rd2), (gd, gd2), (gc, gc2), (keep, keep2), (kmax, kmax2)):
+            assert np.array_equal(a_, b_)
+        draws.append(ind)
+    assert (draws[0] != draws[1]).mean() > 0.9
+
+
 def test_fused_mapping_loss_in_the_forward(emu):
     """render forward with the mapping loss (Mapper.py:487-493): the loss value and d loss / d outputs it writes equal torch's
     on the forward's own outputs (masked by the bounding-box mask, depth term on gt > 0 only, colour term in the colour stage)"""

@@ -55,6 +55,45 @@ def test_window_sampling_is_the_per_frame_loop():
         assert rel_err(got[k], frames[k][0].grad) < 1e-5, k
 
 
+def test_window_kernel_draws_its_own_pixels():
+    """Default pixel draw of the fused entry points (mapping.PIXEL_DRAW = "kernel"): indices in range and close to uniform, the
+    window's rays are those of the explicit-index path on the drawn indices, every call (and every replay of a captured graph)
+    draws afresh, seed_pixel_draws restarts the sequence."""
+    import nice_slam_amd as nsa
+    from nice_slam_amd import mapping
+    assert mapping.PIXEL_DRAW == "kernel"
+    sc = make_scene(seed=82, n_rays=8, small=True)
+    H, W, fx, fy, cx, cy = sc["intr"]
+    K, n = 3, 4000
+    frames = _frames(sc, K, DEV)
+    args = (4, H - 4, 5, W - 5, n, H, W, fx, fy, cx, cy, [f[0] for f in frames], [f[1] for f in frames], [f[2] for f in frames], sc["bound"], DEV)
+    nsa.seed_pixel_draws(123, DEV)
+    w1 = nsa.get_samples_window(*args)
+    w2 = nsa.get_samples_window(*args)
+    crop = (H - 8) * (W - 10)
+    for w in (w1, w2):
+        assert w.indices.dtype == torch.int64 and int(w.indices.min()) >= 0 and int(w.indices.max()) < crop
+        hist = torch.bincount((w.indices * 16 // crop), minlength=16).double()
+        assert float(((hist - K * n / 16) ** 2 / (K * n / 16)).sum()) < 60.0           # chi-square, 15 degrees of freedom
+        ref = nsa.get_samples_window(*args, indices=w.indices)
+        for a, b in ((w.rays_o, ref.rays_o), (w.rays_d, ref.rays_d), (w.gt_depth, ref.gt_depth), (w.gt_color, ref.gt_color), (w.keep, ref.keep)):
+            assert torch.equal(a, b)
+    assert float((w1.indices != w2.indices).double().mean()) > 0.99
+    nsa.seed_pixel_draws(123, DEV)
+    assert torch.equal(nsa.get_samples_window(*args).indices, w1.indices)
+    # under graph capture: the call counter lives on the device, every replay draws other pixels
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    nsa.get_samples_window(*args)
+    with torch.cuda.graph(g):
+        wg = nsa.get_samples_window(*args)
+    seen = []
+    for _ in range(3):
+        g.replay()
+        seen.append(wg.indices.clone())
+    assert float((seen[0] != seen[1]).double().mean()) > 0.99 and float((seen[1] != seen[2]).double().mean()) > 0.99
+
+
 @pytest.mark.parametrize("stage", ["coarse", "middle", "fine", "color"])
 def test_fused_mapping_loss_equals_unfused_path(stage):
     import nice_slam_amd as nsa

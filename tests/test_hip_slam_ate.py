@@ -30,19 +30,20 @@ def test_ate_product_within_half_a_cm_of_the_reference_ops():
     init = {"grids": {k: v.detach().cpu().contiguous().clone() for k, v in p0.c.items()},
             "params": {k: v.detach().cpu().clone() for k, v in p0.decoders.state_dict().items()}}
     del p0
-    # The loop is chaotic in the small: the two paths draw different pixels (one index draw per window vs one per frame), the
-    # HIP path's gradient atomics are unordered, and a different early pose estimate changes every later keyframe.  One pair
-    # of runs differs by 0.1 ... 0.6 cm either way; the comparison is therefore between the MEANS over three seeds
-    # (pixel draws and keyframe selection), all starting from the same map.
-    seeds = (0, 1, 2)
+    # The loop is chaotic in the small: the two paths draw different pixels (the fused path draws inside its window kernel, the
+    # reference path once per frame with torch.randint), the HIP path's gradient atomics are unordered, and a different early
+    # pose estimate changes every later keyframe.  Single runs of the product on this tiny sequence land between 0.3 and 1.4 cm
+    # whatever the pixel source (eight seeds each, torch.randint: median 1.0, in-kernel draw: median 0.8), the reference path
+    # between 0.3 and 0.85, so the comparison is between MEDIANS: fifteen seeds of the product (a run takes under a second)
+    # against five of the reference path (13 s each), all starting from the same map; the means are printed next to them.
     ate = {"fused": [], "aten": []}
-    for sd in seeds:
-        a_sd = types.SimpleNamespace(seed=sd)
-        for k in ("fused", "aten"):
-            r = ac.run(k, a_sd, seq, cfg, init)
+    for k, seeds in (("fused", range(15)), ("aten", range(5))):
+        for sd in seeds:
+            r = ac.run(k, types.SimpleNamespace(seed=sd), seq, cfg, init)
             ate[k].append(r["ate"]["rmse"] * 100)
             assert r["mapping_iters"] == 1100 and r["tracking_iters"] == 130, (k, sd, r["mapping_iters"], r["tracking_iters"])
     mean = {k: sum(v) / len(v) for k, v in ate.items()}
-    print("ATE [cm] per seed:", ate, "means:", mean)
-    assert mean["aten"] < 3.0, ate                      # the reference path itself holds the trajectory on this sequence
-    assert abs(mean["fused"] - mean["aten"]) < 0.5, (ate, mean)
+    med = {k: sorted(v)[len(v) // 2] for k, v in ate.items()}
+    print("ATE [cm] per seed:", {k: [round(x, 2) for x in v] for k, v in ate.items()}, "medians:", med, "means:", mean)
+    assert med["aten"] < 3.0, ate                       # the reference path itself holds the trajectory on this sequence
+    assert abs(med["fused"] - med["aten"]) < 0.5, (ate, med, mean)
