@@ -679,6 +679,23 @@ def test_full_size_forward_blocks_in_a_subprocess():
     assert " passed" in r.stdout
 
 
+@pytest.mark.parametrize("cells", ["0", "64"])
+def test_hot_voxel_table_extremes_in_a_subprocess(cells):
+    """The dX kernel's hot-voxel table (LDS rows for the samples next to their ray's origin, claimed with a compare-and-swap,
+    flushed once per block): NSR_DX_HOT_CELLS=0 switches it off, 64 sends EVERY sample of these small scenes through it (slot
+    collisions -> the fall-back to memory atomics is exercised too).  Both extremes against the oracle, like the default of
+    two cells in the rest of this file (the switch is read once per process)."""
+    import subprocess, sys
+    if os.environ.get("NSR_DX_HOT_CELLS") is not None:
+        pytest.skip("already the inner run")
+    env = dict(os.environ, NSR_DX_HOT_CELLS=cells)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k",
+                        "golden_forward or random_scene or saved_activations_equal"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 @pytest.mark.parametrize("stage", ["coarse", "middle", "fine", "color"])
 def test_saved_activations_equal_the_forward_rerun(emu, stage):
     """nsr_render_args.acts: the forward writes every decoder's hidden states, relu masks and grid features, and the backward
