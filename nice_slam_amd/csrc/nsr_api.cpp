@@ -257,7 +257,7 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
         int lds = 0;
         const int first = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE, last = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : P.stage;
         for (int kind = first; kind <= last; ++kind) {
-            const int need = (nsr::AUX_FLOATS + nsr::packedT_total(kind) + G.waves * nsr::kDxStg + (kind == NSR_COARSE ? 0 : nsr::kHotFloats)) * 4;
+            const int need = (nsr::AUX_FLOATS + nsr::packedT_total(kind) + G.waves * nsr::kDxStg + (kind == NSR_COARSE ? 0 : nsr::kHotFloats) + 4) * 4;   // + the tile counter
             lds = need > lds ? need : lds;
         }
         // hot-voxel table of a dX block: samples within `hot_cells` cells of their ray's origin (NSR_DX_HOT_CELLS, 0: off)

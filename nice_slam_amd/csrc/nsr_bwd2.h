@@ -146,6 +146,11 @@ NSR_DEV void dx_pass(const RenderParams &P) {
     float *gl = (KIND == NSR_COARSE && P.lds_grid_floats > 0) ? stg + nw * kDxStg : nullptr;
     const bool use_hot = KIND != NSR_COARSE && P.hot_z[KIND] > 0.f && P.grid[KIND].dfeat != nullptr;
     const HotTab hot = hot_tab(stg + nw * kDxStg);
+    // Tiles: block i of the n of a pass owns the contiguous range [T i / n, T (i + 1) / n) and its waves draw from it through
+    // an LDS counter (a wave whose tile was cheap takes the next one: no rounds); NSR_X bit 7: the static deal tile = block *
+    // waves + wave, + blocks * waves, ... of the first version (measurement).
+    const bool dyn = !(P.xflags & 128);
+    int *tcnt = reinterpret_cast<int *>(stg + nw * kDxStg + (KIND == NSR_COARSE ? P.lds_grid_floats : kHotFloats));
     const GridDev &G = P.grid[KIND];
     const DecDev &D = P.dec[KIND];
     const bool do_grid = G.dfeat != nullptr;
@@ -156,6 +161,7 @@ NSR_DEV void dx_pass(const RenderParams &P) {
     copy_f4<packedT_total(KIND) / 4>(wt, D.packed + AUX_FLOATS + packed_total(KIND));
     if (gl) for (int i = tid(); i < P.lds_grid_floats; i += nthreads()) gl[i] = 0.f;
     if (use_hot) hot_init(hot);
+    if (tid() == 0) tcnt[0] = 0;
     block_sync();
     dbg.stamp(1);
 
@@ -169,16 +175,23 @@ NSR_DEV void dx_pass(const RenderParams &P) {
 #pragma unroll
     for (int k = 0; k < kET; ++k) { aB[k][0] = 0.f; aB[k][1] = 0.f; aB[k][2] = 0.f; }
 
-    long long tile = (long long)bid_x() * nw + wave;
+    const long long t0 = dyn ? ntiles * bid_x() / nblk_x() : 0, tend = dyn ? ntiles * (bid_x() + 1) / nblk_x() : ntiles;
+    auto claim = [&]() -> long long {                        // the block's next unclaimed tile (wave-uniform)
+        int k = 0;
+        if (lane == 0) k = atomic_fetch_add_lds_i(tcnt, 1);
+        return t0 + shfl_i(k, 0);
+    };
+    long long tile = dyn ? claim() : (long long)bid_x() * nw + wave;
     DxIn cur;
-    if (tile < ntiles) cur = dx_load(P, acts_pass, tile, pt, g);
-    for (; tile < ntiles; tile += tstep) {
+    if (tile < tend) cur = dx_load(P, acts_pass, tile, pt, g);
+    while (tile < tend) {
         loop_fence();
         // the next tile's inputs are requested now and waited for before this tile's scatter atomics are issued: the
         // vector-memory counter is in-order, a load behind the atomics would wait for all of them
-        const bool has_next = tile + tstep < ntiles;
+        const long long nxt = dyn ? claim() : tile + tstep;
+        const bool has_next = nxt < tend;
         DxIn nx = cur;
-        if (has_next) nx = dx_load(P, acts_pass, tile + tstep, pt, g);
+        if (has_next) nx = dx_load(P, acts_pass, nxt, pt, g);
         dbg.stamp(2);
         const long long gp = tile * kTile + pt;
         const bool active = cur.act;
@@ -332,6 +345,7 @@ NSR_DEV void dx_pass(const RenderParams &P) {
             }
         }
         cur = nx;
+        tile = nxt;
         dbg.stamp(7);
     }
     dbg.stamp(8);
