@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- rendered rays/s (forward + backward) of the NICE-SLAM mapping render hot path on MI355X.
 
-Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 launched under
-torch.distributed.run, one rank per GPU.  One STEP = one mapping iteration's pass of the hot path over one ray batch:
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 either launched under torch.distributed.run
+(one rank per GPU: WORLD_SIZE / RANK / LOCAL_RANK in the environment) or, as a plain ``python bench.py --gpus N``, this
+script starts the N ranks itself (`spawn_ranks`); rank 0 prints the line, `--verify-shards` is on by default for N > 1.  One STEP = one mapping iteration's pass of the hot path over one ray batch:
 window sampling (pixel draw inside the kernel, all keyframes, bounding-box mask) -> render forward -> mapping loss -> backward (every grid,
 every decoder, like the reference's autograd; no optimiser: Adam and the masked write-back belong to the caller,
 SURVEY §8(f)).  Default workload = BASELINE configs[1] (Replica room0 full config); ``--config {0,2,3,4,tracking}`` selects
@@ -30,8 +31,9 @@ HBM_PEAK = 8.0e12
 # necessary / executed MAC per sample point, SURVEY §8(d)
 FWD_MAC = {"coarse": 6176, "middle": 15479, "fine": 36078, "color": 51653}
 NEC_MAC = {"coarse": 12352, "middle": 24727, "fine": 59694, "color": 106140}          # fwd + bwd, what the optimiser needs
-# MACs per sample point the backward kernel actually issues (forward re-run + dX + dW of every decoder): counted by
-# SQ_INSTS_VALU_MFMA_MOPS_F32 (x 512 FLOP) in profiles/r02_pmc_bench_kernels.txt; coarse: 3 x forward (not measured)
+# MACs per sample point a re-run backward would issue (decoder forward + dX + dW of every decoder; SQ_INSTS_VALU_MFMA_MOPS_F32
+# x 512 FLOP of round 2's kernel, profiles/r02_pmc_bench_kernels.txt; coarse: 3 x forward); the split backward issues this minus
+# the forward (FWD_MAC), which is what `executed_frac` below uses
 EXEC_BWD_MAC = {"coarse": 3 * 6176, "middle": 46080, "fine": 102400, "color": 148480}
 
 # ---- BASELINE.json configs ------------------------------------------------------------------------
@@ -255,6 +257,39 @@ def verify_shards(nsa, shard, renderer, grids, dec, frames, per_frame, stage, H,
                         "rendering the union batch, tensors: %d" % (len(ref) + 1)}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N copies of this command, one rank per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in the environment, exactly what torch.distributed.run would set), wait for them, and return the
+    worst exit code.  Rank 0 inherits stdout and prints the one JSON line.  Fewer than N devices is an error unless
+    NSR_SINGLE_DEVICE=1 (CI on a 1-GPU box: every rank on device 0, NSR_DIST_BACKEND=gloo)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("NSR_SINGLE_DEVICE") != "1":
+        print(f"bench.py: --gpus {n} but only {have} device(s) visible (set NSR_SINGLE_DEVICE=1 NSR_DIST_BACKEND=gloo to share one)", file=sys.stderr)
+        return 2
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + int(os.environ.get("NSR_BENCH_DEADLINE_S", "900")) + 60
+    for p in procs:
+        try:
+            rc = max(rc, abs(p.wait(timeout=max(1.0, deadline - time.time()))))
+        except subprocess.TimeoutExpired:
+            rc = max(rc, 124)
+    for p in procs:                                               # a rank that died leaves the others waiting in a collective
+        if p.poll() is None:
+            p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,20 +300,24 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage", default=None, help="pin every step to one stage (profiling)")
     ap.add_argument("--rays", type=int, default=None, help="rays per iteration (default: the configuration's)")
-    ap.add_argument("--verify-shards", action="store_true",
+    ap.add_argument("--verify-shards", action="store_true", default=None,
                     help="multi-GPU self check after the timed region: one iteration with shared fixed pixel draws, the all-reduced "
-                         "loss / grid / decoder / pose gradients against a single-GPU evaluation of the union batch on every rank")
+                         "loss / grid / decoder / pose gradients against a single-GPU evaluation of the union batch on every rank "
+                         "(default: on whenever more than one rank runs)")
+    ap.add_argument("--no-verify-shards", dest="verify_shards", action="store_false")
     ap.add_argument("--eager", action="store_true", help="do not capture the iteration in a hipGraph")
     ap.add_argument("--unfused", action="store_true", help="the drop-in call sequence (get_samples per frame, render_batch_ray, torch loss) instead of mapping_loss")
     ap.add_argument("--stepped-grads-only", action="store_true",
                     help="parameter gradients only for the decoder the reference's optimiser steps (colour); default: all, like the reference autograd")
     ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
                     help="multi-GPU: weak = the configuration's rays per GPU, strong = in total (default: strong for config 3 / 4, else weak)")
-    ap.add_argument("--rerun-activations", action="store_true",
-                    help="backward re-runs the decoder forward instead of loading activations saved by the forward (Renderer.save_activations)")
     ap.add_argument("--dense-exchange", action="store_true",
                     help="multi-GPU: all-reduce the whole feature-grid gradients instead of the frustum-selected voxel rows")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))                          # `python bench.py --gpus N`: launch the N ranks ourselves
+    if "WORLD_SIZE" in os.environ and args.gpus > 1 and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}")
 
     # stdout carries exactly ONE line, the result JSON: anything a library prints there (RCCL's version banner, ...) is
     # sent to stderr by pointing file descriptor 1 at it; the JSON goes to the saved original descriptor at the end
@@ -287,6 +326,8 @@ def main():
     os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.verify_shards is None:
+        args.verify_shards = world > 1
     if world > 1:
         import signal
         signal.alarm(int(os.environ.get("NSR_BENCH_DEADLINE_S", "900")))   # a wedged collective must not hang the node: die loudly
@@ -324,8 +365,6 @@ def main():
         grids = {k: v.detach() for k, v in grids.items()}
     if args.stepped_grads_only:
         renderer.decoder_grads = ("color",)
-    if args.rerun_activations:
-        renderer.save_activations = False
     H, W, fx, fy, cx, cy = sc["intr"]
     frames = [(c.to(dev), d.to(dev), col.to(dev)) for c, d, col in sc["frames"]]
     K = len(frames)
@@ -337,13 +376,6 @@ def main():
     if args.stage:
         stages_cfg = (args.stage,)
     mix = {s: _CYCLE.count(s) for s in stages_cfg} if C["stages"] == "mix" and not args.stage else {s: 1 for s in stages_cfg}
-
-    def acts_saved(stage, n):            # does Renderer._attach_acts hand the forward an activation buffer at this size?
-        if not renderer.save_activations:
-            return False
-        from nice_slam_amd import _capi
-        nfl = _capi.get_lib().nsr_acts_floats(_capi.STAGE_ID[stage], n, 48)
-        return 0 < 4 * nfl <= renderer.max_saved_activation_bytes
 
     def stage_of(it):
         if len(stages_cfg) == 1:
@@ -526,10 +558,8 @@ def main():
                                         " (all grid + all decoder grads, like the reference autograd), no optimiser"),
                        "decoder_grads": "none (tracking)" if tracking else ("colour decoder only (what Mapper's optimiser steps)" if args.stepped_grads_only else "all decoders (reference autograd semantics)"),
                        "launch": "hipGraph replay (one captured graph per stage)" if use_graph else "eager",
-                       "activations": ("saved by the forward (832 B per point and decoder + 640 B of dY scratch) and consumed by the split "
-                                       "backward (dX + dW kernels) where the buffer stays below %d MB, else the decoder forward is "
-                                       "re-run in the backward" % (renderer.max_saved_activation_bytes >> 20))
-                                      if renderer.save_activations else "decoder forward re-run in the backward",
+                       "activations": "saved by the forward (832 B per point and decoder + 640 B of dY scratch) and consumed by the split "
+                                      "backward (dX + dW kernels)",
                        "timed_windows_ms": [round(w_ * 1e3, 3) for w_ in windows], "reported": "median window",
                        "parallelism": exchange},
         }
@@ -539,30 +569,28 @@ def main():
             nec = pts * (NEC_MAC[dom] - FWD_MAC[dom]) * 2
             ach = nec / (ms * 1e-3)
             traffic, tsrc = None, None
-            split = acts_saved(dom, rays_rank)                 # the backward ran as comp_bwd + dX + dW + finalize over saved activations
             tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")      # from a separate rocprofv3 --pmc run (tools/pmc_bench.sh)
-            if os.path.exists(tpath) and args.config == "1" and rays_rank == 1000 and dom == "color" and split:
+            if os.path.exists(tpath) and args.config == "1" and rays_rank == 1000 and dom == "color":
                 tall = json.load(open(tpath))                 # one entry per kernel: the backward = the sum over its kernels
                 ks = [k for k in tall if any(n_ in k for n_ in ("render_bwd_dx_kernel<3", "render_bwd_dw_kernel<3", "bwd_finalize", "comp_bwd"))]
                 if ks:
                     traffic = sum(tall[k]["hbm_bytes_per_launch"] for k in ks)
                     tsrc = "profiles/r03_traffic.json (" + " + ".join(k.replace("nsr::", "") for k in ks) + "): " + tall[ks[0]].get("note", "")
             res["roofline"] = {"bound": "mfma",
-                               "kernel": (f"render backward, stage {dom}: comp_bwd + render_bwd_dx_kernel + render_bwd_dw_kernel + "
-                                          "bwd_finalize (split backward over saved activations)") if split else f"render_bwd_kernel<{dom}> (re-run)",
+                               "kernel": f"render backward, stage {dom}: comp_bwd + render_bwd_dx_kernel + render_bwd_dw_kernel + "
+                                         "bwd_finalize (split backward over saved activations)",
                                "achieved": ach / 1e12, "peak": FP32_PEAK / 1e12,
                                "unit": "TFLOP/s", "frac": ach / FP32_PEAK, "traffic": traffic, "traffic_source": tsrc,
                                "traffic_measured_in_this_run": False,
                                "avg_kernel_ms": ms, "launches": cnt,
                                "measured": "HIP events recorded inside nsr_render_bwd on the launch stream around its kernels "
-                                           "(compositor backward, dX, dW, finalize; or the one re-run kernel): " + events_from,
+                                           "(compositor backward, dX, dW, finalize): " + events_from,
                                "algorithmic_flop_per_launch": nec,
-                               "executed_frac": (pts * (EXEC_BWD_MAC[dom] - (FWD_MAC[dom] if acts_saved(dom, rays_rank) else 0)) * 2
+                               "executed_frac": (pts * (EXEC_BWD_MAC[dom] - FWD_MAC[dom]) * 2
                                                  / (ms * 1e-3)) / FP32_PEAK
                                if not (args.stepped_grads_only or tracking) else None,
                                "executed_note": "MFMA work the backward actually issues (dX + dW for every decoder -- the reference "
-                                                "autograd's semantics -- plus the decoder forward re-run where the activations were not "
-                                                "saved) over the same peak; `frac` counts only the necessary part"}
+                                                "autograd's semantics) over the same peak; `frac` counts only the necessary part"}
         if shard is not None:
             res["config"]["grad_exchange_MB_last_iter"] = round(shard.last_exchange_floats * 4 / 1e6, 2)
             res["rccl_ranks"] = world

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define NSR_VERSION 5
+#define NSR_VERSION 6
 
 /* stages of NICE.forward (decoder.py:312-342) */
 enum { NSR_STAGE_COARSE = 0, NSR_STAGE_MIDDLE = 1, NSR_STAGE_FINE = 2, NSR_STAGE_COLOR = 3 };
@@ -129,6 +129,12 @@ typedef struct nsr_bwd_args {
     const double *grad_scale; /* optional DEVICE scalar every output gradient (d_depth, d_var, d_rgb) is multiplied by -- the
                                  incoming gradient of a loss node fused around the render (no host sync, no extra launch);
                                  NULL = 1 */
+    int32_t loss_grads_from_forward; /* ABI 6, opt-in.  1: d_depth / d_rgb ARE nsr_render_args.dl_depth / dl_rgb exactly as the forward's
+                                 loss epilogue wrote them (same pointers, contents unmodified, d_var NULL): the backward then uses
+                                 the per-sample `d raw` that epilogue already left in `acts` and skips the compositor backward (one
+                                 launch).  0 (default): d_depth / d_var / d_rgb are read as given -- a caller may mask or re-weight
+                                 dl_* in place before the backward.  Only grad_scale is applied on top in either case. */
+    int32_t pad_;
 } nsr_bwd_args;
 
 int nsr_version(void);

@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401  -- must be loaded first: libnsr.so binds to the HIP runtime (libamdhip64.so.7) torch already mapped
 
 MAX_SAMPLES = 64
-ABI_VERSION = 5
+ABI_VERSION = 6
 STAGE_ID = {"coarse": 0, "middle": 1, "fine": 2, "color": 3}
 SLOT_NAMES = ("coarse", "middle", "fine", "color")
 
@@ -48,7 +48,8 @@ class NsrBwdArgs(C.Structure):
                 ("d_rays_o", C.c_void_p), ("d_rays_d", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
                 ("max_blocks", C.c_int32), ("overwrite_dparams", C.c_int32),
-                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p), ("grad_scale", C.c_void_p)]
+                ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p), ("grad_scale", C.c_void_p),
+                ("loss_grads_from_forward", C.c_int32), ("pad_", C.c_int32)]
 
 
 class NsrFrame(C.Structure):

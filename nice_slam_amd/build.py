@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libnsr.so")
 SOURCES = ("nsr_api.cpp",)
-HEADERS = ("nsr_kernels.h", "nsr_bwd.h", "nsr_bwd2.h", "nsr_fwd2.h", "nsr_layout.h", "nsr_dev.h", "nsr_rt.h", os.path.join("..", "..", "include", "nsr.h"))
+HEADERS = ("nsr_kernels.h", "nsr_bwd2.h", "nsr_fwd2.h", "nsr_layout.h", "nsr_dev.h", "nsr_rt.h", os.path.join("..", "..", "include", "nsr.h"))
 # -ffp-contract=off: every fused multiply-add in the kernels is written explicitly (fmaf / MFMA) so that
 #   the CPU emulation used by the unit tests and the GPU agree operation by operation.
 # -munsafe-fp-atomics: grid-gradient scatter uses hardware global_atomic_add_f32 (coarse-grained memory).

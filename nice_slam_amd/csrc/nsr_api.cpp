@@ -20,23 +20,15 @@ int fail(const std::string &msg) {
 }
 
 constexpr int kMaxTiles = 12;            // 12 waves = 768 threads per block
-constexpr int kDefaultBwdBlocks = 256;   // persistent-grid cap of the backward kernel: one block per CU (LDS-bound), fewer partial images
+constexpr int kDefaultBwdBlocks = 256;   // persistent-grid cap of the backward kernels: one block per CU (LDS-bound)
 constexpr int kLdsLimit = 160 * 1024;
 
 inline int round16(int bytes) { return (bytes + 15) & ~15; }
 
-// forward: up to 12 tiles (768 threads, 3 waves/SIMD, <=168 VGPRs).  backward: 4 waves (one per SIMD, the full 512-entry
-// register file each, nsr_bwd.h) that take the kBwdTiles tiles of a ray group in turns.
-constexpr int kBwdTiles = NSR_BWD_TILES;
-constexpr int kBwdWaves = nsr::kBwdWaves;
-int rays_per_block_t(int S, int max_tiles) {
-    int rb = (max_tiles * nsr::kTile) / S;
+// forward: up to 12 tiles (768 threads, 3 waves/SIMD, <=168 VGPRs)
+int rays_per_block(int S) {
+    const int rb = (kMaxTiles * nsr::kTile) / S;
     return rb < 1 ? 1 : rb;
-}
-int rays_per_block(int S) { return rays_per_block_t(S, kMaxTiles); }
-int rays_per_block_bwd(int S) {                // at most 16 rays per group: the group's rays are staged in LDS (few samples per
-    const int rb = rays_per_block_t(S, kBwdTiles);   // ray only occur in tests; render configurations have 32 or 48)
-    return rb > 16 ? 16 : rb;
 }
 
 int stage_passes(int stage) { return stage == NSR_STAGE_COARSE ? 1 : 3; }
@@ -45,17 +37,7 @@ int max_param_count(int stage) {
     return stage == NSR_STAGE_COARSE ? nsr::param_total(0) : nsr::param_total(2);
 }
 
-int bwd_blocks(long long n_groups, int max_blocks) {
-    long long cap = max_blocks > 0 ? max_blocks : kDefaultBwdBlocks;
-    return (int)(n_groups < cap ? n_groups : cap);
-}
-
-// Decoder passes of one backward launch (grid.y): a block serves ONE pass -- that decoder's operand stream sits in its LDS,
-// its parameter-gradient accumulators in its registers -- and one block fits a CU, so the passes run as successive rounds
-// over the chip.  (Measured alternative, profiles/r02_ts/r02n_partition.txt: ONE round of 256 blocks shared among the
-// passes by a cost model, so that a block pays its fixed costs once: at 1000 rays the 4-ray group granularity (250 groups
-// per pass) leaves the best such partition no better than the rounds, at >= 5000 rays it gains < 3 %, and it depends on
-// per-scene cost weights.)
+// Decoder passes of one backward launch: a block serves ONE pass -- that decoder's operand stream sits in its LDS.
 int bwd_passes(int stage) { return stage == NSR_STAGE_COARSE ? 1 : stage; }     // middle 1, fine 2, colour 3
 
 // ---- split backward over saved activations (nsr_bwd2.h) -----------------------------------------------------------------
@@ -123,7 +105,7 @@ int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays,
         if (a->n_rays < 0) return fail("nsr: negative ray count");
         if (a->n_rays > 0 && (!a->rays_o || !a->rays_d)) return fail("nsr: null ray pointers");
     }
-    P.rays_per_block = bwd ? rays_per_block_bwd(P.S) : rays_per_block(P.S);
+    P.rays_per_block = rays_per_block(P.S);
     if (!bwd) {
         // Small batches (the tracker's 200 rays): a forward block runs its decoders one after the other, so with few blocks the
         // launch takes one block's serial chain while most CUs idle.  Fewer rays per block -> one block per CU as long as
@@ -210,23 +192,10 @@ int fwd_lds_bytes(int stage, int npts) {
     return round16(3 * nsr::AUX_FLOATS * 4) + npts * (8 + 8 + 16) + wl * 4;
 }
 
-int bwd_lds_bytes(int stage, int npts, int rays, int waves) {
-    // every decoder pass of the launch lays LDS out for ITS decoder (nsr_bwd.h: bwd_pass): the launch needs the largest
-    const int first = stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE;
-    const int last = stage == NSR_STAGE_COARSE ? NSR_COARSE : stage;
-    int need = 0;
-    for (int kind = first; kind <= last; ++kind) {
-        const int head = (nsr::AUX_FLOATS + nsr::packed_total(kind) + 3) & ~3;
-        const int bytes = round16(head * 4 + npts * (8 + 8 + 16 + 24) + rays * 24) + waves * nsr::bwd_stg_floats(kind) * 4;
-        need = bytes > need ? bytes : need;
-    }
-    return need;
-}
-
 // the backward as comp_bwd -> dX -> dW -> finalize over the activations the forward saved (nsr_bwd2.h)
 int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::RenderParams &P, bool any_params, void *stream) {
     const SplitLayout L = split_layout(P.stage, P.n_rays, P.S);
-    if (L.stride * 4 >= (1ll << 31)) return fail("nsr_render_bwd: batch too large for the saved-activation path (pass acts = NULL)");
+    if (L.stride * 4 >= (1ll << 31)) return fail("nsr_render_bwd: more than 2^25 sample points in one call (split the ray batch)");
     const SplitGeo G = split_geo(P.stage, P.n_rays, P.S, b->max_blocks);
     const int passes = bwd_passes(P.stage);
     P.dy = P.acts + L.o_dy;
@@ -236,6 +205,8 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
     if (any_params && P.acts_masks_only) return fail("nsr_render_bwd: the forward saved relu masks only (acts_masks_only); parameter gradients need the full activations");
     static const int xflags = env_int("NSR_X", 0);
     P.xflags = xflags;
+    static const int stagger_dx = env_int("NSR_DX_STAGGER", 0);
+    P.stagger_dx = stagger_dx;
     if (any_params) {
         const long long need = (long long)passes * ((long long)G.nimg * P.partial_stride + (long long)G.nb * nsr::kDbPart);
         if (!b->workspace || b->workspace_floats < need) return fail("nsr_render_bwd: workspace too small");
@@ -243,9 +214,10 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
         P.dbpart = b->workspace + (long long)passes * G.nimg * P.partial_stride;
     }
     if (b->ev_start) nsr::rt_record(b->ev_start, stream);
-    // the forward's loss epilogue already wrote d raw (for an incoming gradient of 1) when the caller hands back exactly the
-    // derivative arrays that forward produced; else the compositor backward runs here
-    const bool draw_ready = a->loss && a->dl_depth && b->d_depth == a->dl_depth && !b->d_var &&
+    // the forward's loss epilogue already wrote d raw (for an incoming gradient of 1): used when the caller SAYS that it hands
+    // back exactly the derivative arrays that forward produced, unmodified (nsr_bwd_args.loss_grads_from_forward); else the
+    // compositor backward runs here on d_depth / d_var / d_rgb as given
+    const bool draw_ready = b->loss_grads_from_forward && a->loss && a->dl_depth && b->d_depth == a->dl_depth && !b->d_var &&
                             (b->d_rgb == nullptr || b->d_rgb == a->dl_rgb) && (P.stage != NSR_STAGE_COLOR || b->d_rgb == a->dl_rgb || !a->gt_color);
     P.draw_scaled = draw_ready ? 0 : 1;
     if (!draw_ready) {
@@ -359,15 +331,10 @@ int64_t nsr_acts_floats(int stage, int64_t n_rays, int n_samples_total) {
 
 int64_t nsr_bwd_workspace_floats(int stage, int64_t n_rays, int n_samples_total, int max_blocks) {
     if (stage < 0 || stage > 3 || n_samples_total < 1 || n_samples_total > NSR_MAX_SAMPLES) return -1;
-    const int rb = rays_per_block_bwd(n_samples_total);
-    const long long groups = (n_rays + rb - 1) / rb;
-    long long blocks = bwd_blocks(groups, max_blocks);
-    if (blocks < 1) blocks = 1;
-    const long long rerun = (long long)stage_passes(stage) * blocks * max_param_count(stage);
-    // split backward: partial images of the dW kernel + d _B partials of the dX kernel
+    // partial images of the dW kernel + d _B partials of the dX kernel
     const SplitGeo G = split_geo(stage, n_rays, n_samples_total, max_blocks);
     const long long split = (long long)bwd_passes(stage) * ((long long)G.nimg * max_param_count(stage) + (long long)G.nb * nsr::kDbPart);
-    return (int64_t)(rerun > split ? rerun : split);
+    return (int64_t)split;
 }
 
 int nsr_pack_params(int slot, const float *params, float *packed, void *stream) {
@@ -414,6 +381,8 @@ int nsr_render_fwd(const nsr_render_args *a, void *stream) {
             P.pass_beg[p + 1] = P.pass_beg[p] + nbp;
         }
         const int waves = (int)(most > nsr::kDxMaxWaves ? nsr::kDxMaxWaves : most);
+        static const int stagger_fwd = env_int("NSR_FWD_STAGGER", 0);
+        P.stagger_fwd = stagger_fwd;
         const dim3 rgrid((unsigned)((P.n_rays + rpb - 1) / rpb)), rblock(64 * rpb);
         NSR_LAUNCH(nsr::fwd_sample_kernel, rgrid, rblock, rpb * 64 * 8, stream, P);
         int lds = 0;
@@ -441,12 +410,13 @@ int nsr_render_fwd(const nsr_render_args *a, void *stream) {
 #define NSR_FWD(ST, SV)                                                                               \
     if (int rc = launch_cfg(nsr::render_fwd_kernel<ST, SV>, lds, "nsr_render_fwd")) return rc;         \
     NSR_LAUNCH((nsr::render_fwd_kernel<ST, SV>), grid, block, lds, stream, P);
-    const bool save = P.acts != nullptr;           // the variant that also writes the activation slots (nsr_render_args.acts)
+    // (the one-launch kernel saves nothing: a call that will be differentiated passes acts + zvals + raw and took the branch above)
+    P.acts = nullptr;
     switch (P.stage) {
-        case 0: if (save) { NSR_FWD(0, true) } else { NSR_FWD(0, false) } break;
-        case 1: if (save) { NSR_FWD(1, true) } else { NSR_FWD(1, false) } break;
-        case 2: if (save) { NSR_FWD(2, true) } else { NSR_FWD(2, false) } break;
-        default: if (save) { NSR_FWD(3, true) } else { NSR_FWD(3, false) } break;
+        case 0: NSR_FWD(0, false) break;
+        case 1: NSR_FWD(1, false) break;
+        case 2: NSR_FWD(2, false) break;
+        default: NSR_FWD(3, false) break;
     }
 #undef NSR_FWD
     return finish("nsr_render_fwd");
@@ -470,52 +440,9 @@ int nsr_render_bwd(const nsr_render_args *a, const nsr_bwd_args *b, void *stream
     bool any_params = false;
     for (int s = 0; s < 4; ++s) any_params |= P.dec[s].dparams != nullptr;
     P.partial_stride = max_param_count(P.stage);
-    if (P.acts && a->zvals) return render_bwd_split(a, b, P, any_params, stream);      // else: the re-run kernel (nsr_bwd.h)
-    const int nblk = bwd_blocks(P.n_groups, b->max_blocks);
-    if (any_params) {
-        const long long need = (long long)passes * nblk * P.partial_stride;
-        if (!b->workspace || b->workspace_floats < need) return fail("nsr_render_bwd: workspace too small");
-        P.partials = b->workspace;
-    }
-    const int npts = P.rays_per_block * P.S;
-    const int waves = kBwdWaves;
-    const int lds = bwd_lds_bytes(P.stage, npts, P.rays_per_block, waves);
-    const dim3 grid(nblk, passes), block(64 * waves);
-#define NSR_BWD(ST)                                                                               \
-    if (int rc = launch_cfg(nsr::render_bwd_kernel<ST>, lds, "nsr_render_bwd")) return rc;         \
-    NSR_LAUNCH((nsr::render_bwd_kernel<ST>), grid, block, lds, stream, P);
-    if (b->ev_start) nsr::rt_record(b->ev_start, stream);
-    switch (P.stage) {
-        case 0: NSR_BWD(0) break;
-        case 1: NSR_BWD(1) break;
-        case 2: NSR_BWD(2) break;
-        default: NSR_BWD(3) break;
-    }
-#undef NSR_BWD
-    if (b->ev_stop) nsr::rt_record(b->ev_stop, stream);
-    if (int rc = finish("nsr_render_bwd")) return rc;
-    if (any_params) {
-        const int first = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE;
-        const int last = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : P.stage;
-        nsr::ReduceParams R;
-        R.stride = P.partial_stride; R.overwrite = b->overwrite_dparams ? 1 : 0;
-        int rows = 0, nmax = 0;
-        for (int s = first; s <= last; ++s) {
-            if (!P.dec[s].dparams) continue;
-            const int pass = P.stage == NSR_STAGE_COARSE ? 0 : s - NSR_MIDDLE;
-            R.job[rows].partials = P.partials + (long long)pass * nblk * P.partial_stride;
-            R.job[rows].nblocks = nblk;
-            R.job[rows].dparams = P.dec[s].dparams;
-            R.job[rows].n = nsr::param_total(s);
-            nmax = nmax > R.job[rows].n ? nmax : R.job[rows].n;
-            ++rows;
-        }
-        for (int r = rows; r < 3; ++r) R.job[r] = nsr::ReduceJob{nullptr, nullptr, 0, 0};
-        const int tb = 1024;                                      // 64 parameters x 16 slices of the partial list
-        NSR_LAUNCH(nsr::reduce_partials_kernel, dim3((nmax + 63) / 64, rows), dim3(tb), tb * 4, stream, R);
-        if (int rc = finish("nsr_render_bwd(reduce)")) return rc;
-    }
-    return 0;
+    if (!P.acts || !a->zvals)
+        return fail("nsr_render_bwd: the forward must have been given an activation buffer (nsr_render_args.acts, sized by nsr_acts_floats) and zvals");
+    return render_bwd_split(a, b, P, any_params, stream);
 }
 
 int nsr_eval_points_fwd(const nsr_render_args *a, const double *points, int64_t n_points, float *out, void *stream) {

@@ -164,6 +164,11 @@ NSR_DEV void dx_pass(const RenderParams &P) {
     if (tid() == 0) tcnt[0] = 0;
     block_sync();
     dbg.stamp(1);
+    // The waves of the whole launch start together and a tile costs every wave the same: compute and scatter phases would stay
+    // in step across the chip -- all CUs scatter at once against the chip-wide atomic rate, then all compute while it idles.
+    // Wave group k (= wave / 4: the k-th wave of every SIMD) therefore starts k * stagger_dx us late; the tiles are drawn
+    // dynamically, so a late wave just takes fewer of them.
+    for (int i = (wave >> 2) * P.stagger_dx; i > 0; --i) nap_us();
 
     constexpr long long sstride = 256;                       // floats between two slots of a tile
     const float *acts_pass = P.acts + (long long)act_pass(KIND) * P.act_tiles * kActSlots * 256;

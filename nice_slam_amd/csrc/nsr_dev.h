@@ -120,6 +120,8 @@ NSR_DEV int flag_load(const int *p) {
     return v;
 }
 NSR_DEV void spin_pause() { __builtin_amdgcn_s_sleep(1); }
+// idle this wave for about a microsecond (2048 cycles) without occupying an issue slot: start offsets of the waves of a block
+NSR_DEV void nap_us() { __builtin_amdgcn_s_sleep(32); }
 NSR_DEV void atomic_add_global(float *p, float v) { unsafeAtomicAdd(p, v); }
 NSR_DEV void atomic_add_lds(float *p, float v) { atomicAdd(p, v); }
 NSR_DEV void atomic_add_lds_i(int *p, int v) { atomicAdd(p, v); }

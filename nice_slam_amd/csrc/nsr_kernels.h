@@ -8,10 +8,8 @@
 //   * y = W x is a chain of v_mfma_f32_16x16x4_f32 with A = packed weights staged in LDS (one 16-byte read per lane
 //     feeds four MFMAs) and B = the register that already holds x, output again CL,
 //   * dx = W^T dy reads the same packed stream through a transposed index, B = the dy registers,
-//   * dW = dy^T x contracts over points: each wave re-lays its tile's operands out through a private LDS staging tile
-//     ("channel rows": one 16-byte read = the operand of four k-steps) and accumulates EVERY 16x16 block of the decoder's
-//     dW in its own registers for the whole kernel (nsr_bwd.h); one image of the flat gradient blob per block goes to
-//     global memory at the end, summed over blocks by reduce_partials_kernel.
+//   * dW = dy^T x contracts over points: the forward saves every layer's input as [16 points][16 channels] slot tiles, which
+//     read as dwords q * 64 + lane ARE the operand of a contraction over points (nsr_bwd2.h: the dW kernel).
 // References: Renderer.render_batch_ray (src/utils/Renderer.py:63-198), eval_points (:23-61),
 // NICE/MLP/MLP_no_xyz forward (src/conv_onet/models/decoder.py:168-203,254-274,312-342),
 // raw2outputs_nerf_color (src/common.py:204-245), ATen grid_sampler_3d (GridSampler.h).
@@ -98,6 +96,7 @@ struct RenderParams {
     int dw_beg[4];            // dW kernel: blocks [dw_beg[p], dw_beg[p + 1]) = partial images of decoder pass p
     int draw_scaled;          // 1: `draw` already carries nsr_bwd_args.grad_scale (comp_bwd_kernel ran); 0: the forward wrote it
     int xflags;               // measurement switches (NSR_X environment variable; 0 in normal operation)
+    int stagger_dx, stagger_fwd; // start offset between the three wave groups (wave / 4) of a dX / forward-pass block, in ~us (0: none)
     int lds_grid_floats;      // > 0 (coarse stage): the gradient grid (this many floats) is accumulated in the dX block's LDS
     float hot_z[4];           // dX kernel, per grid: samples with z below it use the block's hot-voxel table (0: no table)
     int pass_beg[4];          // pass kernels (nsr_fwd2.h): blocks [pass_beg[p], pass_beg[p + 1]) of the launch work on decoder pass p
@@ -521,31 +520,6 @@ NSR_DEV void gemv_fwd(f32x4 (&acc)[2], const Act<NT> &x, const float *pk, int la
     sched_fence_gemv();
 }
 
-// dx[Tk] += W(slice)^T * dy       (B = dy registers; A = W[16To+4g+r][16Tk+i])
-// read from the same packed stream (`w` = LDS base of the slice): element W[o][k] of a slice sits at
-//   ((Tk*2 + (o>>4))*64 + (o&15) + 16*((k>>2)&3))*4 + (k&3)    -- scalar reads, 4-way bank conflict, fine next to
-// a 64-cycle MFMA pair; columns beyond kcols are zero in the packed stream.
-template <int NTK>
-NSR_DEV void gemv_bwd(f32x4 (&dx)[NTK], const Act<2> &dy, const float *w, int i, int g) {
-    const int lo = (4 * g + 16 * (i >> 2)) * 4 + (i & 3);
-    constexpr int kD = 4, NS = 8;                     // step q = (To, r); NTK reads + NTK MFMAs per step
-    float ra[kD][NTK];
-#pragma unroll
-    for (int q = 0; q < kD; ++q)
-#pragma unroll
-        for (int Tk = 0; Tk < NTK; ++Tk) ra[q][Tk] = w[Tk * 512 + (q >> 2) * 256 + (q & 3) * 4 + lo];
-#pragma unroll
-    for (int q = 0; q < NS; ++q) {
-#pragma unroll
-        for (int Tk = 0; Tk < NTK; ++Tk) dx[Tk] = mfma16(ra[q % kD][Tk], dy.t[q >> 2][q & 3], dx[Tk]);
-        if (q + kD < NS) {
-#pragma unroll
-            for (int Tk = 0; Tk < NTK; ++Tk) ra[q % kD][Tk] = w[Tk * 512 + ((q + kD) >> 2) * 256 + ((q + kD) & 3) * 4 + lo];
-        }
-    }
-    sched_fence_gemv();
-}
-
 // cooperative copy of a decoder's packed operand stream into LDS (caller provides the barriers)
 template <int KIND>
 NSR_DEV void load_packed(float *wl, const float *__restrict__ packed) { copy_f4<packed_total(KIND) / 4>(wl, packed + AUX_FLOATS); }
@@ -597,37 +571,7 @@ NSR_DEV F4 load_b1(const float *aux, int ch) {        // (Bx, By, Bz) of one cha
     return F4{b[0], b[4], b[8], 0.f};
 }
 
-// ------------------------------------------------------------------------------------------------
-// Parameter gradients (see nsr_bwd.h): dW = dy^T x contracts over the points of a tile, so both operands are needed in
-// "lane = channel" form.  Each wave re-lays its tile out through a private LDS staging region.
-// Measured (tools/lds_atomic_probe.hip): ds_add_f32 costs ~195 cycles per wave instruction per CU, so gradients are
-// never summed with LDS atomics.
-// Per-wave staging region (floats): P[3][16] | DO[4][16] | A0 | A1 | X0 | C[cdim/32]; a tile is 16 rows x 32
-// channels in the "channel rows" layout below (conflict-free scalar stores, one conflict-free 16-byte operand read).
-// ------------------------------------------------------------------------------------------------
-constexpr int kStP = 0, kStDO = 64, kStA0 = 128, kStA1 = 128 + 512, kStX0 = 128 + 1024, kStC = 128 + 1536;
-constexpr int stg_floats(int kind) { return 128 + 512 * (3 + cdim_of(kind) / 32); }
-
-// Tile layout "channel rows": 32 rows (channels) x 16 floats (points), 512 floats.  Channel ch = 16T + 4g + r lives in
-// row rho = 16T + 4r + g (g and r swapped, so that the four lane groups g of one store instruction hit four different
-// bank quarters); inside a row the four 4-point groups are XOR-permuted by (ch & 3) (so that the 16 lanes of one b128
-// operand read cover all 64 banks).  Stores: 8 conflict-free ds_write_b32 per tile; operand reads: ONE conflict-free
-// ds_read_b128 per (tile, 16-channel k-tile) = the MFMA operand of 4 k-steps, k-step q <-> point 4g + q.
-NSR_DEV int st_row(int ch) { return (ch & ~15) + ((ch & 3) << 2) + ((ch >> 2) & 3); }
-NSR_DEV void st_store(float *T, const Act<2> &v, int pt, int g) {
-    float *B = T + g * 16 + (pt & 3);
-    const int pg = pt >> 2;
-#pragma unroll
-    for (int Tt = 0; Tt < 2; ++Tt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) B[(16 * Tt + 4 * r) * 16 + ((pg ^ r) << 2)] = v.t[Tt][r];
-}
-// element q = T[point 4g+q][channel 16*Tt + i]: MFMA operand "lane = channel i of k-tile Tt, k-step q = point 4g+q"
-NSR_DEV f32x4 st_load_cm(const float *T, int Tt, int i, int g) {
-    return to_v(ld4(T + st_row(16 * Tt + i) * 16 + ((g ^ (i & 3)) << 2)));
-}
-// points 4*grp .. 4*grp+3 of one channel
-NSR_DEV F4 st_row4(const float *T, int ch, int grp) { return ld4(T + st_row(ch) * 16 + ((grp ^ (ch & 3)) << 2)); }
+NSR_DEV float sum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 
 NSR_DEV unsigned relu_mask(f32x4 (&acc)[2]) {
     unsigned m = 0;
@@ -1057,39 +1001,6 @@ NSR_KERNEL NSR_BOUNDS(768) void eval_points_kernel(const RenderParams P) {
         if (!inside) raw.w = 100.f;                                         // Renderer.py:57
         if (active && (lane >> 4) == 0) st4(P.out_points + pi * 4, raw);
         block_sync();                                                       // before the next group re-stages the weights
-    }
-}
-
-struct BwdFlags { bool grid, params, rays; };      // what the backward of one decoder pass has to produce (nsr_bwd.h)
-
-// sum the per-block partial parameter gradients:  dparams[t] += sum_b partials[b][t], one grid row (blockIdx.y) per
-// decoder pass of the stage.  block = 64 parameters x (blockDim/64) slices of the partial list (coalesced 256-byte
-// rows, split serial sum)
-struct ReduceJob {
-    const float *partials;   // [nblocks][stride] of this pass
-    float *dparams;          // flat gradient blob of the decoder (accumulated into)
-    int n;                   // its parameter count (0: nothing to do for this row)
-    int nblocks;             // blocks that worked on this pass
-};
-struct ReduceParams {
-    ReduceJob job[3];
-    int stride;
-    int overwrite;           // 1: dparams = sum (no caller-side zero fill needed), 0: dparams += sum
-};
-NSR_KERNEL void reduce_partials_kernel(const ReduceParams R) {
-    const ReduceJob J = R.job[bid_y()];
-    float *red = reinterpret_cast<float *>(lds_base());
-    const int lane = tid() & 63, slice = tid() >> 6, nslice = nthreads() >> 6;
-    const int t = bid_x() * 64 + lane;
-    if (bid_x() * 64 >= J.n) return;                     // whole block beyond this decoder's blob (uniform)
-    float s = 0.f;
-    if (t < J.n)
-        for (int b = slice; b < J.nblocks; b += nslice) s += J.partials[(long long)b * R.stride + t];
-    red[tid()] = s;
-    block_sync();
-    if (slice == 0 && t < J.n) {
-        for (int k = 1; k < nslice; ++k) s += red[k * 64 + lane];
-        J.dparams[t] = R.overwrite ? s : J.dparams[t] + s;
     }
 }
 
@@ -1700,6 +1611,5 @@ NSR_KERNEL void camera_from_tensor_kernel(const CamParams P) {
 
 }  // namespace nsr
 
-#include "nsr_bwd.h"
 #include "nsr_bwd2.h"
 #include "nsr_fwd2.h"

@@ -62,26 +62,52 @@ PIXEL_DRAW = os.environ.get("NSR_PIXEL_DRAW", "kernel")
 _DRAW_STATE = {}
 
 
+def _capturing() -> bool:
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def _set_state(st: torch.Tensor, seed: int):
+    """(Re)start a draw state IN PLACE: a hipGraph captured earlier has the tensor's address baked into its window kernel, so
+    the tensor must live -- at that address -- as long as the process; the replays then see the new seed."""
+    st.copy_(torch.tensor([int(seed) & ((1 << 63) - 1), 0, 0, 0], dtype=torch.int64), non_blocking=False)
+
+
 def _draw_state(dev) -> torch.Tensor:
-    """Device-side state of the in-kernel draw: [seed, calls so far, internal]; follows torch.manual_seed (a new seed starts a
-    new sequence) and is advanced by the kernel itself, so replays of a captured graph draw afresh."""
-    key = (dev.type, dev.index)
+    """Device-side state of the in-kernel draw: [seed, calls so far, internal]; ONE tensor per device for the life of the process.
+    It follows torch.manual_seed (a new seed restarts the sequence, in place) and is advanced by the kernel itself, so replays
+    of a captured graph draw afresh.  Never re-seeded while a stream is capturing (the copy would become part of the graph and
+    reset the sequence on every replay): a capture keeps the state it finds."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
     seed = torch.initial_seed() & ((1 << 63) - 1)
     st = _DRAW_STATE.get(key)
-    if st is None or st[0] != seed:
-        st = (seed, torch.tensor([seed, 0, 0, 0], dtype=torch.int64, device=dev))
+    if st is None:
+        if _capturing():
+            raise RuntimeError("nice_slam_amd: the first in-kernel pixel draw on a device cannot happen under graph capture "
+                               "(run one eager iteration first)")
+        st = [seed, torch.tensor([seed, 0, 0, 0], dtype=torch.int64, device=dev)]
         _DRAW_STATE[key] = st
+    elif st[0] != seed and not _capturing():
+        _set_state(st[1], seed)
+        st[0] = seed
     return st[1]
 
 
 def seed_pixel_draws(seed: int, device=None):
-    """Restart the in-kernel pixel draw of ``device`` (default: every device that has drawn so far) from ``seed``.  (A NEW
-    ``torch.manual_seed`` value restarts it too; re-seeding torch with the SAME value cannot be seen from here.)"""
-    keys = list(_DRAW_STATE) if device is None else [(torch.device(device).type, torch.device(device).index)]
+    """Restart the in-kernel pixel draw of ``device`` (default: every device that has drawn so far) from ``seed``, in place:
+    graphs captured before keep working and draw the new sequence.  (A NEW ``torch.manual_seed`` value restarts it too;
+    re-seeding torch with the SAME value cannot be seen from here.)  Not allowed while a stream is capturing."""
+    if _capturing():
+        raise RuntimeError("nice_slam_amd.seed_pixel_draws: not under graph capture")
+    if device is None:
+        keys = list(_DRAW_STATE)
+    else:
+        d = torch.device(device)
+        keys = [(d.type, d.index if d.index is not None else torch.cuda.current_device())]
     for key in keys:
-        dev = torch.device(*key) if key[1] is not None else torch.device(key[0])
-        tag = _DRAW_STATE[key][0] if key in _DRAW_STATE else torch.initial_seed() & ((1 << 63) - 1)
-        _DRAW_STATE[key] = (tag, torch.tensor([int(seed) & ((1 << 63) - 1), 0, 0, 0], dtype=torch.int64, device=dev))
+        st = _DRAW_STATE.get(key)
+        if st is None:
+            st = _DRAW_STATE[key] = [torch.initial_seed() & ((1 << 63) - 1), torch.zeros(4, dtype=torch.int64, device=torch.device(*key))]
+        _set_state(st[1], seed)
 
 
 def _launch_window(indices, K, n, crop, intr, frames, bound6, sbuf, keep, kmax_ptr, dev):
@@ -237,6 +263,9 @@ class _MappingLossFn(torch.autograd.Function):
             a.gt_color, a.keep, a.loss, a.w_color = gt_color.data_ptr(), keep.data_ptr(), loss.data_ptr(), float(w_color)
             a.dl_depth, a.dl_rgb = dl_depth.data_ptr(), dl_rgb.data_ptr()
         acts = renderer._attach_acts(a, stage, N, S, dev, masks_only=not any(need_par)) if need_bwd else None
+        if need_bwd and acts is None:
+            raise _capi.NsrError("nice_slam_amd: the activation buffer of a %d-ray fused iteration does not fit (Renderer."
+                                 "max_saved_activation_bytes / free device memory); use smaller batches or render_batch_ray" % N)
         lib.check(lib.nsr_render_fwd(C.byref(a), stream), "nsr_render_fwd")
         if track is not None:                                   # the tracker's loss needs the batch median of the rendered outputs
             lib.check(lib.nsr_tracking_loss(N, gt_depth.data_ptr(), gt_color.data_ptr(), keep.data_ptr(), depth.data_ptr(), var.data_ptr(),
@@ -247,6 +276,7 @@ class _MappingLossFn(torch.autograd.Function):
                        uncertainty=var, color=rgb, indices=indices)
         if need_bwd:
             ctx.sharder, ctx.loss32 = sharder, Z[3:4]
+            ctx.from_forward = track is None            # the mapper's loss epilogue wrote dl_* AND d raw; nobody touches them in between
             ctx.pose_buf = Z[4 + n_grad:4 + n_grad + n_pose].view(K, 4, 4) if need_pose else None
             ctx.state = (a, (renderer, decoders, stage, S, None if sharder is None else sharder.collect),
                          ([kmax, F, sbuf, Z, hold, acts], rays_o, rays_d, gt_depth, grids, flats, packed, raw, depth),
@@ -267,7 +297,7 @@ class _MappingLossFn(torch.autograd.Function):
         # no host sync, no extra launch
         gs = g_loss.detach().to(device=dl_depth.device, dtype=torch.float64).reshape(1)
         d_o, d_d, d_grids = render_backward(a, meta, kept, (need_pose, need_pose, need_grid, need_par), dl_depth, None, dl_rgb,
-                                            zero_buf=zero_buf, grad_scale=gs)
+                                            zero_buf=zero_buf, grad_scale=gs, loss_grads_from_forward=ctx.from_forward)
         indices, K, n, crop, intr, shapes, dtypes, devs = wm
         g_pose = [None] * K
         gp, pose_base = None, None

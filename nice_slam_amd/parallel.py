@@ -275,10 +275,13 @@ class ShardedMapping:
         """This rank's state of the in-kernel pixel draw (mapping.PIXEL_DRAW = "kernel"): seeded per rank like ``generator``,
         advanced by the window kernel itself -- nothing to register with a capturing graph."""
         dev = torch.device(dev)
-        if self._draw_state is None or self._draw_state.device != dev:
+        if self._draw_state is None:
+            self._draw_state = {}                    # one state tensor per device, kept for the life of the object: a graph
+        st = self._draw_state.get(dev)               # captured on a device has that tensor's address baked in
+        if st is None:
             s = (self.seed * 1000003 + 7919 * (dist.get_rank(self.group) + 1)) & ((1 << 63) - 1)
-            self._draw_state = torch.tensor([s, 0, 0, 0], dtype=torch.int64, device=dev)
-        return self._draw_state
+            st = self._draw_state[dev] = torch.tensor([s, 0, 0, 0], dtype=torch.int64, device=dev)
+        return st
 
     def set_voxel_masks(self, masks):
         """dict grid key -> bool/uint8 [Z,Y,X] voxel mask (``FrustumSelector.voxel_mask``), identical on every rank;

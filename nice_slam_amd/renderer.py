@@ -1,8 +1,9 @@
 """Drop-in ``Renderer`` (reference: src/utils/Renderer.py) on top of the fused HIP kernels.
 
-Same constructor, same method names, same argument meaning.  ``render_batch_ray`` is one forward
-kernel (+ one backward kernel under autograd) instead of the ~250 ATen launches of the reference
-(SURVEY §2.1).  The decoders object must be a ``nice_slam_amd.NICE``.
+Same constructor, same method names, same argument meaning.  ``render_batch_ray`` is one forward kernel -- three under autograd
+(sample placement, decoder passes, compositor; csrc/nsr_fwd2.h), followed by the split backward (compositor backward, dX, dW,
+finalize; csrc/nsr_bwd2.h) -- instead of the ~250 ATen launches of the reference.  The decoders object must be a
+``nice_slam_amd.NICE``.
 """
 from __future__ import annotations
 
@@ -140,10 +141,21 @@ class _RenderFn(torch.autograd.Function):
         zsave = torch.empty((n, S), dtype=torch.float64, device=dev) if need_bwd else None
         a.zvals = zsave.data_ptr() if zsave is not None else None
         keep.append(zsave)
+        chunk = 0
         if need_bwd:
             n_sl = len(slots)
-            keep.append(renderer._attach_acts(a, stage, n, S, dev, masks_only=not any(ctx.needs_input_grad[3 + n_sl:3 + 2 * n_sl])))
+            masks_only = not any(ctx.needs_input_grad[3 + n_sl:3 + 2 * n_sl])
+            acts = renderer._attach_acts(a, stage, n, S, dev, masks_only=masks_only)
+            keep.append(acts)
+            if acts is None:
+                # The activation buffer of the whole batch does not fit (Renderer.max_saved_activation_bytes / free memory / 2^25
+                # sample points): this forward runs without one and the backward goes through the batch in chunks, each chunk a
+                # forward that saves its activations followed by the split backward (_chunked_backward).
+                chunk = renderer.acts_chunk_rays(stage, S, dev)
+                a.raw = a.zvals = None
+                raw = zsave = None
         lib.check(lib.nsr_render_fwd(C.byref(a), stream), "nsr_render_fwd")
+        ctx.chunk = chunk
         if need_bwd:
             # `depth` is an OUTPUT: kept as a detached alias (same storage, different tensor object), so that no reference
             # cycle output -> grad_fn -> ctx -> output forms (a forward whose backward never runs is then freed normally)
@@ -163,17 +175,72 @@ class _RenderFn(torch.autograd.Function):
         g_depth = g_depth.to(torch.float64).contiguous()
         g_var = g_var.to(torch.float64).contiguous()
         g_rgb = g_rgb.to(torch.float32).contiguous()
-        d_o, d_d, d_grids = render_backward(ctx.args, ctx.meta, ctx.keep, need, g_depth, g_var, g_rgb)
+        if ctx.chunk:
+            d_o, d_d, d_grids = _chunked_backward(ctx.args, ctx.meta, ctx.keep, need, g_depth, g_var, g_rgb, ctx.chunk)
+        else:
+            d_o, d_d, d_grids = render_backward(ctx.args, ctx.meta, ctx.keep, need, g_depth, g_var, g_rgb)
         ctx.keep = ctx.args = None
         return (None, d_o, d_d, *d_grids, *([None] * len(slots)))
 
 
-def render_backward(a, meta, kept, need, g_depth, g_var, g_rgb, zero_buf=None, grad_scale=None):
+def _chunked_backward(a, meta, kept, need, g_depth, g_var, g_rgb, chunk):
+    """Backward of a batch whose activation buffer was too large to keep: per chunk of ``chunk`` rays the forward is run again
+    with an activation buffer (same kernels, same batch-global depth cap) and the split backward follows; grid and decoder
+    gradients accumulate over the chunks, the ray gradients are written per chunk."""
+    lib = _capi.get_lib()
+    renderer, decoders, stage, S, reduce_hook = meta
+    keep, rays_o, rays_d, gt_depth, grids, flats, packed, _, _ = kept
+    if reduce_hook is not None:
+        raise _capi.NsrError("nice_slam_amd: a sharded render call whose activation buffer does not fit is not supported (use smaller batches)")
+    slots = stage_slots(stage)
+    dev = rays_o.device
+    stream = _stream(dev)
+    n = rays_o.shape[0]
+    need_o, need_d, need_grid, need_par = need
+    d_o = torch.zeros_like(rays_o) if (need_o or need_d) else None
+    d_d = torch.zeros_like(rays_d) if (need_o or need_d) else None
+    d_grids = [None] * len(slots)
+    for i0 in range(0, n, chunk):
+        i1 = min(n, i0 + chunk)
+        m = i1 - i0
+        ac = _capi.NsrRenderArgs.from_buffer_copy(a)
+        ac.n_rays = m
+        ro, rd = rays_o[i0:i1].contiguous(), rays_d[i0:i1].contiguous()
+        ac.rays_o, ac.rays_d = ro.data_ptr(), rd.data_ptr()
+        gdc = None
+        if gt_depth is not None and a.gt_depth:
+            gdc = gt_depth[i0:i1].contiguous()
+            ac.gt_depth = gdc.data_ptr()
+        depth = torch.empty((m,), dtype=torch.float64, device=dev)
+        var = torch.empty((m,), dtype=torch.float64, device=dev)
+        rgb = torch.empty((m, 3), dtype=torch.float32, device=dev)
+        raw = torch.empty((m, S, 4), dtype=torch.float32, device=dev)
+        zs = torch.empty((m, S), dtype=torch.float64, device=dev)
+        ac.depth, ac.var, ac.rgb, ac.raw, ac.zvals = depth.data_ptr(), var.data_ptr(), rgb.data_ptr(), raw.data_ptr(), zs.data_ptr()
+        acts = renderer._attach_acts(ac, stage, m, S, dev, masks_only=not any(need_par))
+        if acts is None:
+            raise _capi.NsrError("nice_slam_amd: no room for the activation buffer of a %d-ray chunk" % m)
+        lib.check(lib.nsr_render_fwd(C.byref(ac), stream), "nsr_render_fwd(chunk)")
+        kc = (keep + [acts, zs, gdc], ro, rd, gdc, grids, flats, packed, raw, depth)
+        co, cd, cg = render_backward(ac, meta, kc, need, g_depth[i0:i1].contiguous(), g_var[i0:i1].contiguous(), g_rgb[i0:i1].contiguous())
+        if co is not None:
+            d_o[i0:i1] = co
+        if cd is not None:
+            d_d[i0:i1] = cd
+        for k, g in enumerate(cg):
+            if g is not None:
+                d_grids[k] = g if d_grids[k] is None else d_grids[k].add_(g)
+    return (d_o if need_o else None, d_d if need_d else None, d_grids)
+
+
+def render_backward(a, meta, kept, need, g_depth, g_var, g_rgb, zero_buf=None, grad_scale=None, loss_grads_from_forward=False):
     """The backward launch of one render call (shared by ``_RenderFn`` and the fused mapping loss, mapping.py).
     ``a``: the forward's argument block; ``need`` = (rays_o, rays_d, per-grid, per-decoder) gradient requests;
     ``g_*``: gradients of the outputs (contiguous, fp64 / fp64 / fp32) or None; ``zero_buf``: an already zero-filled fp32
     buffer of the size ``backward_buffer_floats`` returns (saves the fill launch); ``grad_scale``: optional 1-element fp64 device
-    tensor every ``g_*`` is multiplied by inside the kernel (the incoming gradient of a fused loss node).
+    tensor every ``g_*`` is multiplied by inside the kernel (the incoming gradient of a fused loss node);
+    ``loss_grads_from_forward``: ``g_depth`` / ``g_rgb`` are the forward's own ``dl_depth`` / ``dl_rgb``, untouched (the backward
+    then starts from the ``d raw`` the forward's loss epilogue precomputed, nsr_bwd_args.loss_grads_from_forward).
     -> (d_rays_o, d_rays_d, [d_grid ...])."""
     lib = _capi.get_lib()
     renderer, decoders, stage, S, reduce_hook = meta
@@ -189,6 +256,7 @@ def render_backward(a, meta, kept, need, g_depth, g_var, g_rgb, zero_buf=None, g
     b.d_rgb = g_rgb.data_ptr() if g_rgb is not None else None
     b.depth = depth.data_ptr()
     b.grad_scale = grad_scale.data_ptr() if grad_scale is not None else None
+    b.loss_grads_from_forward = 1 if loss_grads_from_forward else 0
     # every gradient this call produces lives in ONE zero-filled buffer (a single fill kernel): channels-last views for
     # the dense grid gradients, then the ray gradients, then the flat decoder-gradient blob
     need_ray = need_o or need_d
@@ -308,11 +376,12 @@ class Renderer(object):
         self.bwd_max_blocks = 0                 # 0 = library default persistent-grid cap
         # Saved activations: the forward of a call that will be differentiated also writes the decoders' hidden states, relu
         # masks and grid features (832 B per sample point and decoder) and the backward runs as the split dX / dW kernels over
-        # them (csrc/nsr_bwd2.h; +640 B per point and decoder of dY scratch in the same buffer: 212 MB per 1000 colour-stage
-        # rays) instead of the re-run kernel (csrc/nsr_bwd.h), which holds every parameter-gradient accumulator in one wave.
-        # Batches whose buffer would exceed `max_saved_activation_bytes` keep the re-run kernel (24 B per point of saved state).
-        self.save_activations = True
+        # them (csrc/nsr_bwd2.h; +640 B per point and decoder of dY scratch in the same buffer: 214 MB per 1000 colour-stage
+        # rays).  The buffer may take `max_saved_activation_bytes` at most, and never more than `acts_memory_fraction` of the
+        # device memory that is free when the call is made; a batch that needs more is differentiated in chunks
+        # (_chunked_backward: per chunk a forward that saves, then the split backward).
         self.max_saved_activation_bytes = 64 << 30
+        self.acts_memory_fraction = 0.6
         # Optional: restrict parameter gradients to these decoders, e.g. ("color",).  The reference's autograd
         # produces dW for every decoder in every stage although src/Mapper.py:335-341 only ever steps the colour
         # decoder (and the fine one when fix_fine is False); None = reference semantics (requires_grad decides).
@@ -374,15 +443,43 @@ class Renderer(object):
                 self._gt_max = None
         return _RenderFn.apply(meta, rays_o, rays_d, *[grids[s] for s in slots], *gates)
 
+    def _acts_budget(self, dev) -> int:
+        """bytes an activation buffer may take right now (not queried while a stream is capturing: the cap alone applies)"""
+        cap = int(self.max_saved_activation_bytes)
+        if not torch.cuda.is_current_stream_capturing():
+            free, _ = torch.cuda.mem_get_info(dev)
+            try:                                            # + what the caching allocator holds but has not handed out
+                st = torch.cuda.memory_stats(dev)
+                free += int(st.get("reserved_bytes.all.current", 0)) - int(st.get("allocated_bytes.all.current", 0))
+            except Exception:
+                pass
+            cap = min(cap, int(self.acts_memory_fraction * free))
+        return cap
+
+    def acts_chunk_rays(self, stage, S, dev) -> int:
+        """rays per chunk of a batch whose activation buffer does not fit: the budget and the 2^25-point limit of one call"""
+        per_ray = 4 * max(1, _capi.get_lib().nsr_acts_floats(_capi.STAGE_ID[stage], 1024, S)) / 1024.0
+        rays = int(min(self._acts_budget(dev) / per_ray, ((1 << 25) - 16) // S))
+        rays -= rays % 64
+        if rays < 64:
+            raise _capi.NsrError("nice_slam_amd: not enough device memory for the activation buffer of even 64 rays")
+        return rays
+
     def _attach_acts(self, a, stage, n, S, dev, masks_only=False):
-        """allocate the activation buffer of a differentiable forward and point the argument block at it (None: re-run);
+        """allocate the activation buffer of a differentiable forward and point the argument block at it; None when it does not
+        fit (budget, 2^25 sample points per call, or the allocation fails): the caller then differentiates in chunks.
         ``masks_only``: no decoder will want parameter gradients (tracking) -- the forward then only writes the relu masks"""
-        if not self.save_activations:
-            return None
         nfl = _capi.get_lib().nsr_acts_floats(_capi.STAGE_ID[stage], n, S)
-        if nfl <= 0 or 4 * nfl > self.max_saved_activation_bytes:
+        if nfl <= 0:
+            raise _capi.NsrError("nsr_acts_floats: bad arguments")
+        if n * S > (1 << 25) - 16 or 4 * nfl > self.max_saved_activation_bytes:
             return None
-        acts = torch.empty((nfl,), dtype=torch.float32, device=dev)
+        if 4 * nfl > (256 << 20) and 4 * nfl > self._acts_budget(dev):      # small buffers: no query on the per-iteration path
+            return None
+        try:
+            acts = torch.empty((nfl,), dtype=torch.float32, device=dev)
+        except torch.cuda.OutOfMemoryError:
+            return None
         a.acts = acts.data_ptr()
         a.acts_masks_only = 1 if masks_only else 0
         return acts

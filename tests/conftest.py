@@ -47,22 +47,32 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     import json
     sec, sig = [], []
     su = sys.modules.get("scene_util")
+    counts = {}
     if su is not None:
-        sec = [dict(case=t, tensor=k, err_vs_fp32_oracle=a, err_vs_fp64=b, reference_noise=c) for t, k, a, b, c in su.SECONDARY_LOG]
+        sd = getattr(su, "SELF_DISAGREEMENT", {})
+        sec = [dict(case=t, tensor=k, err_vs_fp32_oracle=a, err_vs_fp64=b, reference_noise=c,
+                    reference_fp32_self_disagreement=sd.get(t, {}).get(k)) for t, k, a, b, c in su.SECONDARY_LOG]
+        for e in sec:
+            counts[e["case"]] = counts.get(e["case"], 0) + 1
+        counts = {t: {"took_secondary_gate": n, "budget": su.secondary_ceiling(t)} for t, n in counts.items()}
     thp = sys.modules.get("test_hip_parity")
     if thp is not None:
         sig = [dict(case=t, tensor=k, what=w) for t, k, w in thp.SIGNATURES]
     if not sec and not sig:
         return
     terminalreporter.write_line(f"parity: {len(sec)} tensor(s) passed through the secondary (reference-noise) gate, {len(sig)} through a bounded signature:")
+    for t, c in counts.items():
+        terminalreporter.write_line("   case %-16s %d tensor(s) through the secondary gate (budget %d)" % (t, c["took_secondary_gate"], c["budget"]))
     for e in sec:
-        terminalreporter.write_line("   %-16s %-44s vs fp32 oracle %.2e, vs fp64 %.2e, reference noise %.2e" %
-                                    (e["case"], e["tensor"], e["err_vs_fp32_oracle"], e["err_vs_fp64"], e["reference_noise"]))
+        sdv = e["reference_fp32_self_disagreement"]
+        terminalreporter.write_line("   %-16s %-44s vs fp32 oracle %.2e, vs fp64 %.2e, reference noise %.2e, reference vs itself (fp32) %s" %
+                                    (e["case"], e["tensor"], e["err_vs_fp32_oracle"], e["err_vs_fp64"], e["reference_noise"],
+                                     "n/a" if sdv is None else "%.2e" % sdv))
     for e in sig:
         terminalreporter.write_line("   %-16s %-44s %s" % (e["case"], e["tensor"], e["what"]))
     out = os.environ.get("NSR_PARITY_REPORT") or (os.path.join(ROOT, "gpurun_out", "parity_report.json") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None)
     if out:
         try:
-            json.dump({"secondary_gate": sec, "bounded_signatures": sig}, open(out, "w"), indent=1)
+            json.dump({"secondary_gate_counts": counts, "secondary_gate": sec, "bounded_signatures": sig}, open(out, "w"), indent=1)
         except OSError:
             pass

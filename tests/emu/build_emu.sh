@@ -8,7 +8,7 @@ CXX="${NSR_EMU_CXX:-/opt/rocm/lib/llvm/bin/clang++}"
 [ -x "$CXX" ] || CXX=clang++
 mkdir -p "$HERE/_build"
 # the shim directory comes first on the include path so that its nsr_dev.h / nsr_rt.h shadow the HIP ones
-cp "$ROOT/nice_slam_amd/csrc/nsr_api.cpp" "$ROOT/nice_slam_amd/csrc/nsr_kernels.h" "$ROOT/nice_slam_amd/csrc/nsr_bwd.h" "$ROOT/nice_slam_amd/csrc/nsr_bwd2.h" "$ROOT/nice_slam_amd/csrc/nsr_fwd2.h" "$ROOT/nice_slam_amd/csrc/nsr_layout.h" "$HERE/_build/"
+cp "$ROOT/nice_slam_amd/csrc/nsr_api.cpp" "$ROOT/nice_slam_amd/csrc/nsr_kernels.h" "$ROOT/nice_slam_amd/csrc/nsr_bwd2.h" "$ROOT/nice_slam_amd/csrc/nsr_fwd2.h" "$ROOT/nice_slam_amd/csrc/nsr_layout.h" "$HERE/_build/"
 sed -i 's#"../../include/nsr.h"#"nsr.h"#' "$HERE/_build/nsr_kernels.h"
 "$CXX" -O1 -std=c++17 -ffp-contract=off -fPIC -shared -pthread $NSR_EMU_DEFS \
     -I"$HERE" -I"$ROOT/include" \

@@ -172,6 +172,7 @@ template <int N> NSR_DEV void dma_wait() {}
 NSR_DEV void flag_store(int *p, int v) { *p = v; }
 NSR_DEV int flag_load(const int *p);                  // (below shfl_any: every lane of the wave sees lane 0's reading)
 NSR_DEV void spin_pause() { emu::wave_sync(); }       // a polling wave lets the block's other waves run
+NSR_DEV void nap_us() {}
 NSR_DEV void atomic_add_global(float *p, float v) {
     // blocks may run on different OS threads: real atomic read-modify-write
     uint32_t *u = reinterpret_cast<uint32_t *>(p);

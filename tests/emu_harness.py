@@ -20,7 +20,7 @@ EMU_LIB = os.path.join(EMU_DIR, "libnsr_emu.so")
 
 
 def build_emu(force=False):
-    srcs = [os.path.join(ROOT, "nice_slam_amd", "csrc", f) for f in ("nsr_api.cpp", "nsr_kernels.h", "nsr_bwd.h", "nsr_bwd2.h", "nsr_fwd2.h", "nsr_layout.h")]
+    srcs = [os.path.join(ROOT, "nice_slam_amd", "csrc", f) for f in ("nsr_api.cpp", "nsr_kernels.h", "nsr_bwd2.h", "nsr_fwd2.h", "nsr_layout.h")]
     srcs += [os.path.join(EMU_DIR, f) for f in ("nsr_dev.h", "nsr_rt.h", "emu_runtime.cpp", "build_emu.sh")]
     srcs += [os.path.join(ROOT, "include", "nsr.h")]
     if not force and os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(s) for s in srcs):
@@ -65,8 +65,11 @@ class HostScene:
         self.bound = np.asarray(bound, dtype=np.float64)
         self.enl = float(coarse_enlarge)
         self.n_samples, self.n_surface = n_samples, n_surface
-        self.save_z = True          # exercise the saved-depth path of the backward; False = recompute
-        self.save_acts = os.environ.get("NSR_EMU_SAVE_ACTS", "1") == "1"     # saved decoder activations (default) vs forward re-run
+        self.save_z = True          # the forward saves the sample depths (required by the backward)
+        # True (default): the forward gets an activation buffer (three-launch forward, nsr_fwd2.h); False: the one-launch forward
+        # kernel, as for calls that will not be differentiated -- backward() then runs the saving forward first, like
+        # nice_slam_amd.renderer._chunked_backward does for batches whose buffer does not fit
+        self.save_acts = os.environ.get("NSR_EMU_SAVE_ACTS", "1") == "1"
         self.grids = {}
         for k, v in grids.items():          # [1,32,Z,Y,X] -> [Z,Y,X,32] contiguous
             a = v.detach().numpy()[0].transpose(1, 2, 3, 0)
@@ -145,7 +148,17 @@ class HostScene:
         return out
 
     def backward(self, stage, fwd, d_depth, d_var, d_rgb, want_grid=True, want_params=True, want_rays=True, max_blocks=0,
-                 overwrite_dparams=False, grad_scale=None, from_forward=False):
+                 overwrite_dparams=False, grad_scale=None, from_forward=False, in_place=False):
+        if "acts" not in fwd:                              # forward without an activation buffer: run the saving forward now
+            assert not from_forward and not in_place
+            was, self.save_acts = self.save_acts, True
+            try:
+                fwd2 = self.forward(stage, fwd["_ctx"][2], fwd["_ctx"][3], fwd["_ctx"][4])
+            finally:
+                self.save_acts = was
+            for k in ("depth", "var", "rgb", "raw"):       # the two forward implementations share every expression
+                assert np.array_equal(fwd2[k], fwd[k]), k
+            fwd = fwd2
         a, keep, rays_o, rays_d, gt, S = fwd["_ctx"]
         n = rays_o.shape[0]
         res = {}
@@ -161,6 +174,9 @@ class HostScene:
                 a.dec[i].dparams = ptr(res["d_flat_" + s])
         b = _capi.NsrBwdArgs()
         if from_forward:            # exactly the derivative arrays the fused forward wrote (same pointers: no comp_bwd launch)
+            dd, dv, dr = fwd["dl_depth"], None, (fwd["dl_rgb"] if stage == "color" else None)
+            b.loss_grads_from_forward = 1
+        elif in_place:              # the forward's own arrays, same pointers, but EDITED by the caller: the flag stays 0
             dd, dv, dr = fwd["dl_depth"], None, (fwd["dl_rgb"] if stage == "color" else None)
         else:
             dd = np.ascontiguousarray(d_depth, dtype=np.float64)

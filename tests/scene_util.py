@@ -162,18 +162,51 @@ PRIMARY_ONLY = ("depth", "var", "rgb")      # forward outputs: the 1e-4 gate aga
 _ALLOWED = None
 
 
-def secondary_allowed(tag, tensor):
-    """May `tensor` take the secondary gate in test case `tag`?  tests/golden/secondary_gate.json lists, per case pattern, the
-    tensor patterns that are known to need it (large-bound scenes: every gradient downstream of the fp32 sines; everywhere:
-    the two cancelling bias sums).  A tensor outside the list that misses the primary gate FAILS: a regression that pushes
-    more tensors into the noise-floor gate is not silently absorbed."""
+def _gate_table():
     global _ALLOWED
-    from fnmatch import fnmatch
     if _ALLOWED is None:
         import json
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "secondary_gate.json")
-        _ALLOWED = {k: v for k, v in json.load(open(path)).items() if not k.startswith("_")} if os.path.exists(path) else {}
-    return any(fnmatch(tag, case) and any(fnmatch(tensor, pat) for pat in pats) for case, pats in _ALLOWED.items())
+        _ALLOWED = json.load(open(path)) if os.path.exists(path) else {"cases": {}, "everywhere": [], "everywhere_max_count": 0}
+    return _ALLOWED
+
+
+def secondary_allowed(tag, tensor):
+    """May `tensor` take the secondary gate in test case `tag`?  tests/golden/secondary_gate.json lists, per case, the tensors
+    BY NAME that are known to need it on some box (large-bound scenes: gradients downstream of the fp32 sines) and, for every
+    case, the two heavily cancelling bias sums of each decoder.  A tensor outside the list that misses the primary gate FAILS:
+    a regression that pushes more tensors into the noise-floor gate is not silently absorbed."""
+    t = _gate_table()
+    return tensor in t.get("everywhere", ()) or tensor in t.get("cases", {}).get(tag, {}).get("tensors", ())
+
+
+def secondary_ceiling(tag):
+    """How many tensors of case `tag` may take the secondary gate in one run (the budget next to the name list)."""
+    t = _gate_table()
+    case = t.get("cases", {}).get(tag)
+    return case["max_count"] if case is not None else t.get("everywhere_max_count", 0)
+
+
+SELF_DISAGREEMENT = {}      # tag -> {tensor: rel. distance between two legitimate fp32 evaluations of the REFERENCE's own operators}
+
+
+def reference_self_disagreement(sc, stage, backward=True, with_depth=True, rays=None):
+    """The reference path against ITSELF in fp32: the oracle's index-arithmetic trilinear with one thread vs the same graph
+    through ATen's grid_sampler_3d (decoder.py:173, what the reference calls) with every host thread -- two evaluations a user
+    of the reference gets on two machines.  -> {tensor: max|a-b| / max|b|}."""
+    from oracle import nice_oracle as orc
+    nthr, impl = torch.get_num_threads(), orc.TRILINEAR_IMPL
+    try:
+        torch.set_num_threads(1)
+        orc.TRILINEAR_IMPL = "index"
+        a = oracle_render(sc, stage, backward=backward, with_depth=with_depth, rays=rays)
+        torch.set_num_threads(max(nthr, min(16, os.cpu_count() or 1)))
+        orc.TRILINEAR_IMPL = "grid_sample"
+        b = oracle_render(sc, stage, backward=backward, with_depth=with_depth, rays=rays)
+    finally:
+        torch.set_num_threads(nthr)
+        orc.TRILINEAR_IMPL = impl
+    return {k: rel_err(a[k], b[k]) for k in b}
 
 
 def parity_failures(got, sc, stage, tol=1e-4, backward=True, with_depth=True, rays=None, ref=None, truth_fn=None, tag=None):
@@ -223,6 +256,14 @@ def parity_failures(got, sc, stage, tol=1e-4, backward=True, with_depth=True, ra
         SECONDARY_LOG.append((tag or "?", k, rel_err(got[k], ref[k]), e_truth, e_ref))
         if tag is not None and os.environ.get("NSR_PARITY_COLLECT") != "1" and not secondary_allowed(tag, k):
             out.append((k, rel_err(got[k], ref[k]), e_truth, e_ref, "needed the secondary gate but is not on the committed list of " + tag))
+    if tag is not None:
+        took = [e for e in SECONDARY_LOG if e[0] == tag]
+        if took and os.environ.get("NSR_PARITY_COLLECT") != "1" and len(took) > secondary_ceiling(tag):
+            out.append((tag, "%d tensors took the secondary gate, the committed budget of this case is %d" % (len(took), secondary_ceiling(tag))))
+        if took and tag not in SELF_DISAGREEMENT and truth_fn is None and sc["rays_o"].shape[0] <= 5000:
+            # what the same tensors do between two fp32 evaluations of the reference itself (recorded in parity_report.json)
+            sd = reference_self_disagreement(sc, stage, backward=backward, with_depth=with_depth, rays=rays)
+            SELF_DISAGREEMENT[tag] = {e[1]: sd.get(e[1]) for e in took}
     return out
 
 

@@ -95,12 +95,11 @@ def test_backward_flag_subsets(emu):
         assert rel_err(rays[k], full[k]) < 1e-6
     for k in grid:
         assert rel_err(grid[k], full[k]) < 1e-6
-    # backward that re-derives the sample depths instead of loading the ones the forward saved
+    # a forward that saved no sample depths (zvals = NULL) cannot be differentiated: loud error, no silent recomputation
     sc.save_z = False
     fwd2 = sc.forward("color", s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy())
-    again = sc.backward("color", fwd2, w["depth"].numpy(), w["var"].numpy(), w["rgb"].numpy())
-    for k in full:
-        assert rel_err(again[k], full[k]) < 1e-6, k
+    with pytest.raises(Exception, match="activation buffer"):
+        sc.backward("color", fwd2, w["depth"].numpy(), w["var"].numpy(), w["rgb"].numpy())
     sc.save_z = True
     # depth-only upstream gradient (d_var = d_rgb = NULL)
     dd = sc.backward("fine", sc.forward("fine", s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy()),
@@ -671,7 +670,7 @@ def test_full_size_forward_blocks_in_a_subprocess():
     import subprocess, sys
     if os.environ.get("NSR_FWD_SMALL") == "0":
         pytest.skip("already the inner run")
-    env = dict(os.environ, NSR_FWD_SMALL="0", NSR_EMU_SAVE_ACTS="0")      # ... and the forward re-run path of the backward
+    env = dict(os.environ, NSR_FWD_SMALL="0", NSR_EMU_SAVE_ACTS="0")      # ... through the one-launch forward kernel (no activation buffer)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k",
                         "golden_forward or random_scene or fused_mapping_loss or other_sample_counts"],
                        env=env, capture_output=True, text=True, timeout=900)
@@ -698,9 +697,10 @@ def test_hot_voxel_table_extremes_in_a_subprocess(cells):
 
 @pytest.mark.parametrize("stage", ["coarse", "middle", "fine", "color"])
 def test_saved_activations_equal_the_forward_rerun(emu, stage):
-    """nsr_render_args.acts: the forward writes every decoder's hidden states, relu masks and grid features, and the backward
-    runs as the split dX / dW kernels over them (nsr_bwd2.h) instead of the re-run kernel (nsr_bwd.h) -- same gradients up
-    to summation order (the fc_c weights come out as W^T G), ragged ray count (a partial last tile), small persistent grid."""
+    """nsr_render_args.acts: the three-launch forward (nsr_fwd2.h) writes every decoder's hidden states, relu masks and grid
+    features for the split backward (nsr_bwd2.h) -- its outputs equal the one-launch forward kernel's (no activation buffer)
+    BIT FOR BIT, every slot of every point is written, and the backward's specialisations (no parameter gradients; relu masks
+    only) agree with the full one.  Ragged ray count (a partial last tile), small persistent grid."""
     s = make_scene(seed=120, n_rays=29, small=True)
     res = {}
     for mode in (True, False):
@@ -718,7 +718,7 @@ def test_saved_activations_equal_the_forward_rerun(emu, stage):
         res[mode] = (fwd, sc.backward(stage, fwd, s["w"]["depth"].numpy(), s["w"]["var"].numpy(), s["w"]["rgb"].numpy(), max_blocks=2))
     for k in ("depth", "var", "rgb", "raw"):
         assert np.array_equal(res[True][0][k], res[False][0][k]), k
-    for k, v in res[False][1].items():
+    for k, v in res[False][1].items():                              # (mode False: backward() ran the saving forward itself)
         assert rel_err(res[True][1][k], v) < 1e-5, (stage, k)      # (emulated blocks run on several OS threads: atomics order)
     # without parameter gradients (tracking): the specialisation without accumulators takes the same path
     sc = _host_scene(emu, s["grids"], s["params"], s["bound"].numpy())
@@ -740,7 +740,7 @@ def test_saved_activations_equal_the_forward_rerun(emu, stage):
 @pytest.mark.parametrize("stage,acts", [("color", True), ("fine", False), ("coarse", True)])
 def test_grad_scale_multiplies_every_gradient(emu, stage, acts):
     """nsr_bwd_args.grad_scale (the incoming gradient of a fused loss node, a device scalar): every gradient of the backward
-    is the unscaled one times the scalar -- split kernels (saved activations) and the re-run kernel alike."""
+    is the unscaled one times the scalar."""
     s = make_scene(seed=121, n_rays=13, small=True)
     res = {}
     for sc_ in (None, -2.5):
@@ -773,3 +773,12 @@ def test_fused_forward_leaves_d_raw_for_the_split_backward(emu, stage):
     assert set(res["forward"]) == set(res["comp_bwd"])
     for k, v in res["comp_bwd"].items():
         assert rel_err(res["forward"][k], v) < 1e-5, (stage, k)
+    # a C-API caller that edits dl_* IN PLACE (masking, re-weighting) and hands the same pointers back without the opt-in
+    # flag: the edit must be honoured (ABI 6: nsr_bwd_args.loss_grads_from_forward; pointer equality alone decided before)
+    sc = _host_scene(emu, s["grids"], s["params"], s["bound"].numpy())
+    fwd = sc.forward(stage, s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy(), fused_loss=fl)
+    fwd["dl_depth"] *= -3.0
+    fwd["dl_rgb"] *= -3.0
+    edited = sc.backward(stage, fwd, None, None, None, in_place=True, grad_scale=1.75)
+    for k, v in res["comp_bwd"].items():
+        assert rel_err(edited[k], -3.0 * v) < 1e-5, (stage, k)

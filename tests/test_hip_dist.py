@@ -216,3 +216,22 @@ def test_two_ranks_sharded_fused_mapping(masked, own_draws):
         from nice_slam_amd.layout import param_count
         want = sum(int(masks[k].sum()) for k in ("grid_middle", "grid_fine")) * 32 + param_count("middle") + param_count("fine") + K_FR * 16 + 1
         assert int(res[0]["exchange_floats"]) == want
+
+
+def test_bench_gpus_2_spawns_two_ranks_and_checks_its_shards():
+    """The driver's command line, `python bench.py --gpus 2`, on a 1-GPU box: both ranks on device 0 over gloo (RCCL refuses two
+    ranks on one device).  ONE JSON line, n_gpus / rccl_ranks = 2, and the run's own shard check (the all-reduced loss and
+    gradients against one GPU on the union batch) green."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(NSR_SINGLE_DEVICE="1", NSR_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--windows", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak", d
+    assert d["shard_check"]["ok"], d["shard_check"]
+    assert d["config"]["rays_per_iteration"] == 2 * d["config"]["rays_per_gpu"]

@@ -92,6 +92,25 @@ def test_window_kernel_draws_its_own_pixels():
         g.replay()
         seen.append(wg.indices.clone())
     assert float((seen[0] != seen[1]).double().mean()) > 0.99 and float((seen[1] != seen[2]).double().mean()) > 0.99
+    # Re-seeding AFTER the capture: the state tensor is updated in place (the graph has its address baked in), so the replays
+    # restart the sequence -- and nothing the allocator may have placed at a freed address is written to.  Both ways of
+    # re-seeding: seed_pixel_draws and a new torch.manual_seed value.
+    st = mapping._draw_state(torch.device(DEV))
+    ptr = st.data_ptr()
+    nsa.seed_pixel_draws(123, DEV)
+    g.replay()
+    assert torch.equal(wg.indices, w1.indices)
+    assert mapping._draw_state(torch.device(DEV)).data_ptr() == ptr
+    canary = [torch.full((4,), 0x5a5a5a5a, dtype=torch.int64, device=DEV) for _ in range(64)]     # small blocks the allocator reuses
+    old_seed = torch.initial_seed()
+    torch.manual_seed(old_seed + 1)
+    wn = nsa.get_samples_window(*args)                          # eager call: notices the new torch seed, re-seeds in place
+    assert mapping._draw_state(torch.device(DEV)).data_ptr() == ptr
+    nsa.seed_pixel_draws(int(mapping._DRAW_STATE[("cuda", 0)][1][0]), DEV)
+    g.replay()
+    assert torch.equal(wg.indices, wn.indices)                  # the captured graph follows the new seed
+    assert all(bool((c == 0x5a5a5a5a).all()) for c in canary)
+    torch.manual_seed(old_seed)
 
 
 @pytest.mark.parametrize("stage", ["coarse", "middle", "fine", "color"])

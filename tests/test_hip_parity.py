@@ -29,7 +29,7 @@ def _compare(got, ref, tag, sc=None, stage=None, **kw):
 def test_native_library_is_the_path():
     from nice_slam_amd import _capi
     lib = _capi.get_lib()
-    assert lib.path.endswith("libnsr.so") and lib.nsr_version() == _capi.ABI_VERSION == 5
+    assert lib.path.endswith("libnsr.so") and lib.nsr_version() == _capi.ABI_VERSION == 6
 
 
 def test_golden_fixture_through_hip(golden):
@@ -68,22 +68,29 @@ def test_forward_backward_small(stage):
 
 
 @pytest.mark.parametrize("stage", ("middle", "fine", "color"))
-def test_saved_activations_and_forward_rerun_agree(stage):
-    """Renderer.save_activations (default: the forward runs as sample placement -> per-decoder passes -> compositor
-    (csrc/nsr_fwd2.h) and writes hidden states + relu masks, the split backward loads them) against the one-launch forward
-    kernel + the backward that re-runs the decoder forward: same outputs BIT FOR BIT (the two forward implementations share
-    every expression), same gradients up to the order of the gradient atomics; the re-run variant is also held to the oracle
-    (the default one is by every other test)."""
+def test_forward_kernels_agree_and_oversized_batches_are_chunked(stage):
+    """Two forward implementations share every expression: the one-launch kernel (calls that are not differentiated) and
+    sample placement -> per-decoder passes -> compositor (csrc/nsr_fwd2.h: differentiated calls, saves the activations the split
+    backward loads) -- same outputs BIT FOR BIT.  A batch whose activation buffer exceeds Renderer.max_saved_activation_bytes
+    is differentiated in chunks (renderer._chunked_backward: per chunk the saving forward, then the split backward): same
+    gradients as the unchunked call up to the order of the gradient atomics, and held to the oracle itself."""
     sc = make_scene(seed=14, n_rays=301, small=True)
     prod = build_product(sc, "cuda:0")
     saved = hip_render(sc, stage, backward=True, product=prod)
-    prod[0].save_activations = False
-    rerun = hip_render(sc, stage, backward=True, product=prod)
+    plain = hip_render(sc, stage, backward=False, product=prod)
     for k in ("depth", "var", "rgb"):
-        assert torch.equal(saved[k], rerun[k]), k
-    for k, v in rerun.items():
+        assert torch.equal(saved[k], plain[k]), k
+    from nice_slam_amd import _capi
+    per_ray = 4 * _capi.get_lib().nsr_acts_floats(_capi.STAGE_ID[stage], 1024, 48) / 1024.0
+    prod[0].max_saved_activation_bytes = int(130 * per_ray)          # 301 rays do not fit: chunks of 128, 128, 45 rays
+    assert prod[0].acts_chunk_rays(stage, 48, torch.device("cuda:0")) == 128
+    chunked = hip_render(sc, stage, backward=True, product=prod)
+    for k in ("depth", "var", "rgb"):
+        assert torch.equal(saved[k], chunked[k]), k
+    assert set(chunked) == set(saved)
+    for k, v in chunked.items():
         assert rel_err(saved[k], v) < 1e-5, (stage, k)
-    _compare(rerun, oracle_render(sc, stage, backward=True), stage + "/rerun", sc, stage)
+    _compare(chunked, oracle_render(sc, stage, backward=True), stage + "/chunked", sc, stage)
 
 
 @pytest.mark.parametrize("stage", ("middle", "color"))

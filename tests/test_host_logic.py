@@ -1,8 +1,12 @@
 """CPU: host-side logic of the drop-in modules (no kernel is launched)."""
 import copy
+import os
 
 import numpy as np
+import pytest
 import torch
+
+from conftest import ROOT
 
 import nice_slam_amd as nsa
 from nice_slam_amd.layout import param_count, param_spec
@@ -142,3 +146,17 @@ def test_grad_target_state_machine():
     cp = copy.deepcopy(sub)
     f4, m4 = cp.grad_target()
     assert m4 == "overwrite" and f4.data_ptr() != flat.data_ptr()
+
+
+def test_bench_gpus_n_fails_loudly_without_n_devices():
+    """`python bench.py --gpus 2` starts its ranks itself (bench.spawn_ranks); with fewer than two devices and no
+    NSR_SINGLE_DEVICE it must say so and exit non-zero instead of silently measuring one rank."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two devices present")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NSR_SINGLE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "--gpus 2" in r.stderr and "device" in r.stderr, (r.returncode, r.stdout, r.stderr[-500:])
