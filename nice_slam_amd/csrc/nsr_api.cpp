@@ -205,8 +205,6 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
     if (any_params && P.acts_masks_only) return fail("nsr_render_bwd: the forward saved relu masks only (acts_masks_only); parameter gradients need the full activations");
     static const int xflags = env_int("NSR_X", 0);
     P.xflags = xflags;
-    static const int stagger_dx = env_int("NSR_DX_STAGGER", 0);
-    P.stagger_dx = stagger_dx;
     if (any_params) {
         const long long need = (long long)passes * ((long long)G.nimg * P.partial_stride + (long long)G.nb * nsr::kDbPart);
         if (!b->workspace || b->workspace_floats < need) return fail("nsr_render_bwd: workspace too small");
@@ -381,8 +379,6 @@ int nsr_render_fwd(const nsr_render_args *a, void *stream) {
             P.pass_beg[p + 1] = P.pass_beg[p] + nbp;
         }
         const int waves = (int)(most > nsr::kDxMaxWaves ? nsr::kDxMaxWaves : most);
-        static const int stagger_fwd = env_int("NSR_FWD_STAGGER", 0);
-        P.stagger_fwd = stagger_fwd;
         const dim3 rgrid((unsigned)((P.n_rays + rpb - 1) / rpb)), rblock(64 * rpb);
         NSR_LAUNCH(nsr::fwd_sample_kernel, rgrid, rblock, rpb * 64 * 8, stream, P);
         int lds = 0;

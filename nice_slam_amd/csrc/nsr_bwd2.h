@@ -100,33 +100,25 @@ NSR_DEV void gemv_t(f32x4 (&dx)[NTK], const Act<2> &dy, const float *wt, int lan
     sched_fence_gemv();
 }
 
+// What a tile's layers need first: d raw and the relu masks.  Requested one tile ahead and handed over RAW -- anything computed on
+// a loaded value at request time (zeroing the rows beyond the last point, the incoming-gradient scale) makes the compiler wait for
+// the load right behind its issue, i.e. at the top of the previous tile instead of a whole tile later.
 struct DxIn {
-    double px, py, pz, z;
     F4 dr;
     unsigned m0, m1;
-    bool act;
 };
-
 NSR_DEV DxIn dx_load(const RenderParams &P, const float *acts_pass, long long tile, int pt, int g) {
     DxIn I;
     const long long gp = tile * kTile + pt;
-    I.act = gp < P.n_points_total;
-    const long long q = I.act ? gp : 0;
-    const double *pp = P.pd + q * 4;
-    I.px = pp[0]; I.py = pp[1]; I.pz = pp[2]; I.z = pp[3];
+    const long long q = gp < P.n_points_total ? gp : 0;
     I.dr = ld4(P.draw + q * 4);
-    if (!P.draw_scaled && P.g_scale) {             // d raw written by the forward's loss epilogue: the incoming gradient applies here
-        const float sc = (float)P.g_scale[0];
-        I.dr.x *= sc; I.dr.y *= sc; I.dr.z *= sc; I.dr.w *= sc;
-    }
     const float *mp = acts_pass + ((q >> 4) * kActSlots + kActMask) * 256 + ((q & 15) * 4 + g) * 4;
     I.m0 = __builtin_bit_cast(unsigned, mp[0]);
     I.m1 = __builtin_bit_cast(unsigned, mp[1]);
-    if (!I.act) { I.dr = F4{0.f, 0.f, 0.f, 0.f}; I.m0 = 0u; I.m1 = 0u; }
     return I;
 }
 NSR_DEV void dx_keep(const DxIn &I) {           // force the loads behind `I` to have landed (see dx_pass)
-    keep_alive((float)I.z); keep_alive(I.dr.w); keep_alive(__builtin_bit_cast(float, I.m1));
+    keep_alive(I.dr.w); keep_alive(__builtin_bit_cast(float, I.m1));
 }
 
 template <int KIND, bool PARAMS, bool RAYS>
@@ -143,9 +135,11 @@ NSR_DEV void dx_pass(const RenderParams &P) {
     // A grid small enough for LDS (the coarse grid: 616 voxels = 79 KB at Replica) takes every block's contributions there
     // (LDS atomics) and goes to memory once per block: all 32 k samples of a 1024-ray batch hit those 616 voxels, and
     // same-line memory-side atomics serialise (coarse dX kernel 67 -> see profiles/r03*_c0).
-    float *gl = (KIND == NSR_COARSE && P.lds_grid_floats > 0) ? stg + nw * kDxStg : nullptr;
+    const int tail_off = uniform((int)(stg + nw * kDxStg - reinterpret_cast<float *>(lds))); // what follows the waves' staging (floats from the LDS base)
+    const int gl_off = (KIND == NSR_COARSE && P.lds_grid_floats > 0) ? tail_off : -1;
+    float *gl = gl_off >= 0 ? reinterpret_cast<float *>(lds) + gl_off : nullptr;
     const bool use_hot = KIND != NSR_COARSE && P.hot_z[KIND] > 0.f && P.grid[KIND].dfeat != nullptr;
-    const HotTab hot = hot_tab(stg + nw * kDxStg);
+    const HotTab hot{use_hot ? tail_off : -1};
     // Tiles: block i of the n of a pass owns the contiguous range [T i / n, T (i + 1) / n) and its waves draw from it through
     // an LDS counter (a wave whose tile was cheap takes the next one: no rounds); NSR_X bit 7: the static deal tile = block *
     // waves + wave, + blocks * waves, ... of the first version (measurement).
@@ -164,12 +158,6 @@ NSR_DEV void dx_pass(const RenderParams &P) {
     if (tid() == 0) tcnt[0] = 0;
     block_sync();
     dbg.stamp(1);
-    // The waves of the whole launch start together and a tile costs every wave the same: compute and scatter phases would stay
-    // in step across the chip -- all CUs scatter at once against the chip-wide atomic rate, then all compute while it idles.
-    // Wave group k (= wave / 4: the k-th wave of every SIMD) therefore starts k * stagger_dx us late; the tiles are drawn
-    // dynamically, so a late wave just takes fewer of them.
-    for (int i = (wave >> 2) * P.stagger_dx; i > 0; --i) nap_us();
-
     constexpr long long sstride = 256;                       // floats between two slots of a tile
     const float *acts_pass = P.acts + (long long)act_pass(KIND) * P.act_tiles * kActSlots * 256;
     float *dys = P.dy + (long long)act_pass(KIND) * P.act_tiles * kDySlots * 256;
@@ -186,28 +174,35 @@ NSR_DEV void dx_pass(const RenderParams &P) {
         if (lane == 0) k = atomic_fetch_add_lds_i(tcnt, 1);
         return t0 + shfl_i(k, 0);
     };
+    // d raw written by the forward's loss epilogue: the incoming gradient applies here (one uniform scalar, read once)
+    const float dr_scale = (!P.draw_scaled && P.g_scale) ? (float)P.g_scale[0] : 1.f;
     long long tile = dyn ? claim() : (long long)bid_x() * nw + wave;
     DxIn cur;
-    if (tile < tend) cur = dx_load(P, acts_pass, tile, pt, g);
-    while (tile < tend) {
+    if (tile < tend) { cur = dx_load(P, acts_pass, tile, pt, g); dx_keep(cur); }     // (waited for HERE: otherwise the loop header
+    while (tile < tend) {                                                              //  carries an `s_waitcnt vmcnt(0)` for them, which
+                                                                                       //  every later iteration spends on its atomics)
         loop_fence();
-        // the next tile's inputs are requested now and waited for before this tile's scatter atomics are issued: the
-        // vector-memory counter is in-order, a load behind the atomics would wait for all of them
+        // The vector-memory counter is in order: a load behind this wave's scatter atomics waits for all of them.  So the next
+        // tile's first inputs (d raw, masks) are requested now and waited for (dx_keep) before this tile's atomics are issued;
+        // this tile's positions are requested now as well and first used behind the layers, by when the previous tile's
+        // atomics have drained.
         const long long nxt = dyn ? claim() : tile + tstep;
         const bool has_next = nxt < tend;
         DxIn nx = cur;
         if (has_next) nx = dx_load(P, acts_pass, nxt, pt, g);
-        dbg.stamp(2);
         const long long gp = tile * kTile + pt;
-        const bool active = cur.act;
-        const float px = (float)cur.px, py = (float)cur.py, pz = (float)cur.pz;       // decoder.py:189
+        const bool active = gp < P.n_points_total;
+        const double *pp = P.pd + (active ? gp : 0) * 4;
+        const double cpx = pp[0], cpy = pp[1], cpz = pp[2], cz = pp[3];
+        dbg.stamp(2);
         unsigned mk[5];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) mk[i] = (cur.m0 >> (8 * i)) & 255u;
-        mk[4] = cur.m1 & 255u;
+        for (int i = 0; i < 4; ++i) mk[i] = active ? (cur.m0 >> (8 * i)) & 255u : 0u;
+        mk[4] = active ? cur.m1 & 255u : 0u;
+        const float dsc = active ? dr_scale : 0.f;           // rows beyond the last point carry no gradient
         float d_out[4] = {0.f, 0.f, 0.f, 0.f};
-        if (NOUT == 1) d_out[0] = cur.dr.w;
-        else { d_out[0] = cur.dr.x; d_out[1] = cur.dr.y; d_out[2] = cur.dr.z; }      // decoder.py:341 overwrites the 4th colour output
+        if (NOUT == 1) d_out[0] = cur.dr.w * dsc;
+        else { d_out[0] = cur.dr.x * dsc; d_out[1] = cur.dr.y * dsc; d_out[2] = cur.dr.z * dsc; }      // decoder.py:341 overwrites the 4th colour output
         // output layer
         Act<2> dh;
 #pragma unroll
@@ -248,6 +243,7 @@ NSR_DEV void dx_pass(const RenderParams &P) {
         }
         // ---- embedding backward: dE = W0^T dY0 + W3e^T dY3, d arg = dE cos(arg); d p (rays) and d _B (parameters)
         dbg.stamp(3);
+        const float px = (float)cpx, py = (float)cpy, pz = (float)cpz;       // decoder.py:189
         float dpe[3] = {0.f, 0.f, 0.f};
         if (XYZ && PARAMS && !(P.xflags & 4)) {
             // "lane = channel" form: swapping the MFMA operands (A = dY registers, B = transposed stream) yields
@@ -310,13 +306,16 @@ NSR_DEV void dx_pass(const RenderParams &P) {
         // ---- grid: coordinate gradient, scatter; ray gradients
         dbg.stamp(4);
         Lvl L;
-        if (need_dc) L = make_level(G, cur.px, cur.py, cur.pz);
+        if (need_dc) L = make_level(G, cpx, cpy, cpz);
         float dux = 0.f, duy = 0.f, duz = 0.f;
         if (RAYS) coord_grad(G, L, g, dc, dux, duy, duz);
         dx_keep(nx);
+        // (every load of this iteration is consumed on EVERY path before the atomics: a destination register still pending at the
+        // loop header costs an `s_waitcnt vmcnt(0)` there, i.e. a wait for the whole tile's atomics)
+        keep_alive_d(cpx); keep_alive_d(cpy); keep_alive_d(cpz); keep_alive_d(cz);
         dbg.stamp(5);
         if (do_grid && !(P.xflags & 1))
-            scatter_merged(G, L, lane, dc, active, Sw + kDxTx, Sw + kDxTab, gl, use_hot ? &hot : nullptr, (float)cur.z < P.hot_z[KIND]);
+            scatter_merged(G, L, lane, dc, active, Sw + kDxTx, Sw + kDxTab, gl_off, hot, (float)cz < P.hot_z[KIND]);
         dbg.stamp(6);
         if (RAYS) {
             // d p = d u * (n-1)/2 * 2/(hi-lo) (+ embedding part), fp64 like autograd through Renderer.py:172;
@@ -326,7 +325,7 @@ NSR_DEV void dx_pass(const RenderParams &P) {
             v[0] = mine ? (double)dux * (2.0 * G.inv[0]) + (double)dpe[0] : 0.0;
             v[1] = mine ? (double)duy * (2.0 * G.inv[1]) + (double)dpe[1] : 0.0;
             v[2] = mine ? (double)duz * (2.0 * G.inv[2]) + (double)dpe[2] : 0.0;
-            v[3] = v[0] * cur.z; v[4] = v[1] * cur.z; v[5] = v[2] * cur.z;
+            v[3] = v[0] * cz; v[4] = v[1] * cz; v[5] = v[2] * cz;
             if ((P.S & (kTile - 1)) == 0) {                      // a tile never straddles two rays: one atomic per component
 #pragma unroll
                 for (int m = 1; m < 16; m <<= 1)

@@ -61,6 +61,7 @@ NSR_DEV void sched_fence_emb() {
 }
 // keep a loaded value (and thereby its load) alive up to this point without doing anything with it
 NSR_DEV void keep_alive(float v) { asm volatile("" ::"v"(v)); }
+NSR_DEV void keep_alive_d(double v) { asm volatile("" ::"v"(v)); }
 // compiler-only memory clobber: stops loop-invariant code motion of loads across loop iterations
 NSR_DEV void loop_fence() { asm volatile("" ::: "memory"); }
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter
@@ -71,10 +72,18 @@ NSR_DEV void block_sync() { __syncthreads(); }
 
 // Profiling stamps (tests/perf/ts_probe.py): compiled in only with -DNSR_TS (tools/build_ts.sh); the product build has none.
 struct Dbg {
-    long long *p;        // this wave's slot array, or NULL
+    long long *p;        // this wave's slot array (64 entries), or NULL
+    mutable long long last = 0;
+    // slot: the time of the LAST passage; slot + 16: the time spent between the previous stamp and this one, summed over all
+    // passages (the per-phase totals of a wave over its tiles); slot + 32: number of passages
     NSR_DEV void stamp(int slot) const {
 #ifdef NSR_TS
-        if (p && (threadIdx.x & 63) == 0) p[slot] = (long long)__builtin_amdgcn_s_memtime();
+        const long long t = (long long)__builtin_amdgcn_s_memtime();
+        if (p && (threadIdx.x & 63) == 0) {
+            p[slot] = t;
+            if (last) { p[16 + slot] += t - last; p[32 + slot] += 1; }
+        }
+        last = t;
 #else
         (void)slot;
 #endif
@@ -120,17 +129,45 @@ NSR_DEV int flag_load(const int *p) {
     return v;
 }
 NSR_DEV void spin_pause() { __builtin_amdgcn_s_sleep(1); }
-// idle this wave for about a microsecond (2048 cycles) without occupying an issue slot: start offsets of the waves of a block
-NSR_DEV void nap_us() { __builtin_amdgcn_s_sleep(32); }
-NSR_DEV void atomic_add_global(float *p, float v) { unsafeAtomicAdd(p, v); }
-NSR_DEV void atomic_add_lds(float *p, float v) { atomicAdd(p, v); }
-NSR_DEV void atomic_add_lds_i(int *p, int v) { atomicAdd(p, v); }
-NSR_DEV int atomic_fetch_add_lds_i(int *p, int v) { return atomicAdd(p, v); }
-NSR_DEV int atomic_cas_lds_i(int *p, int expect, int v) { return atomicCAS(p, expect, v); }
-NSR_DEV void atomic_add_global_d(double *p, double v) { unsafeAtomicAdd(p, v); }
-NSR_DEV unsigned long long atomic_fetch_add_global_u64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
+// Atomics with an explicit address space.  Through a generic pointer the compiler emits FLAT instructions (flat_atomic_add_f32,
+// flat_load, flat_atomic_cmpswap): they occupy the LDS and the vector-memory queue at once, count on vmcnt AND lgkmcnt -- the dX
+// kernel's scatter walk (nsr_kernels.h) waited for all of its outstanding grid atomics at every `s_waitcnt vmcnt(0) lgkmcnt(0)`
+// behind a hot-table probe -- and a select between an LDS and a global target becomes ONE flat atomic on a selected pointer.
+// The casts below pin the address space: global_atomic_add_f32 / ds_add_f32 / ds_cmpst_rtn_b32 / ds_read_b32.
+typedef __attribute__((address_space(1))) float nsr_gfloat;
+typedef __attribute__((address_space(1))) double nsr_gdouble;
+typedef __attribute__((address_space(1))) unsigned nsr_guint;
+typedef __attribute__((address_space(1))) unsigned long long nsr_gu64;
+typedef __attribute__((address_space(3))) float nsr_lfloat;
+NSR_DEV void atomic_add_global(float *p, float v) {
+    __hip_atomic_fetch_add((nsr_gfloat *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+NSR_DEV void atomic_add_lds(float *p, float v) {
+    __hip_atomic_fetch_add((nsr_lfloat *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+NSR_DEV void atomic_add_lds_i(int *p, int v) {
+    __hip_atomic_fetch_add((lds_int *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+NSR_DEV int atomic_fetch_add_lds_i(int *p, int v) {
+    return __hip_atomic_fetch_add((lds_int *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+NSR_DEV int atomic_cas_lds_i(int *p, int expect, int v) {      // returns the old value
+    __hip_atomic_compare_exchange_strong((lds_int *)p, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return expect;
+}
+// plain LDS accesses through a pointer whose provenance the compiler has lost (table pointers handed around in structs)
+NSR_DEV int lds_load_i(const int *p) { return *(const volatile lds_int *)p; }
+NSR_DEV float lds_load_f(const float *p) { return *(const nsr_lfloat *)p; }
+NSR_DEV void atomic_add_global_d(double *p, double v) {
+    __hip_atomic_fetch_add((nsr_gdouble *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+NSR_DEV unsigned long long atomic_fetch_add_global_u64(unsigned long long *p, unsigned long long v) {
+    return __hip_atomic_fetch_add((nsr_gu64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // max of non-negative floats (their bit patterns order like unsigned integers)
-NSR_DEV void atomic_max_pos(float *p, float v) { atomicMax(reinterpret_cast<unsigned *>(p), __builtin_bit_cast(unsigned, v)); }
+NSR_DEV void atomic_max_pos(float *p, float v) {
+    __hip_atomic_fetch_max((nsr_guint *)reinterpret_cast<unsigned *>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 NSR_DEV char *lds_base() {
     extern __shared__ __attribute__((aligned(16))) char nsr_lds_[];

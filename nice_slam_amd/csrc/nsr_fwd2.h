@@ -112,7 +112,6 @@ NSR_DEV void fwd_pass(const RenderParams &P, int bi, int nbp) {
     if (tid() == 0) cnt[0] = 0;
     block_sync();
     dbg.stamp(1);
-    for (int i = (wave >> 2) * P.stagger_fwd; i > 0; --i) nap_us();     // start offsets of the wave groups (see dx_pass)
     const long long ntiles = (P.n_points_total + kTile - 1) / kTile;
     const long long t0 = ntiles * bi / nbp, t1 = ntiles * (bi + 1) / nbp;
     for (;;) {

@@ -96,7 +96,6 @@ struct RenderParams {
     int dw_beg[4];            // dW kernel: blocks [dw_beg[p], dw_beg[p + 1]) = partial images of decoder pass p
     int draw_scaled;          // 1: `draw` already carries nsr_bwd_args.grad_scale (comp_bwd_kernel ran); 0: the forward wrote it
     int xflags;               // measurement switches (NSR_X environment variable; 0 in normal operation)
-    int stagger_dx, stagger_fwd; // start offset between the three wave groups (wave / 4) of a dX / forward-pass block, in ~us (0: none)
     int lds_grid_floats;      // > 0 (coarse stage): the gradient grid (this many floats) is accumulated in the dX block's LDS
     float hot_z[4];           // dX kernel, per grid: samples with z below it use the block's hot-voxel table (0: no table)
     int pass_beg[4];          // pass kernels (nsr_fwd2.h): blocks [pass_beg[p], pass_beg[p + 1]) of the launch work on decoder pass p
@@ -409,20 +408,21 @@ NSR_DEV void coord_grad(const GridDev &G, const Lvl &L, int g, const Act<2> &dc,
 // cells) go there when their voxel owns or can claim its slot, everything else straight to memory, and the block adds its
 // table to memory once at the end.
 constexpr int kHotSlots = 64, kHotBit = 1 << 30, kHotFloats = kHotSlots * (kC + 1);     // tags [64] | rows [64][32]
-struct HotTab {
-    int *tag;                // -1: free
-    float *val;
-};
-NSR_DEV HotTab hot_tab(float *base) { return HotTab{reinterpret_cast<int *>(base), base + kHotSlots}; }
+// The table is addressed by its OFFSET from the block's LDS base (floats), a wave-uniform integer (-1: no table): a struct of
+// generic pointers handed down to the walk was spilled to scratch by the register allocator and re-loaded inside the hot
+// branch -- scratch loads count on vmcnt, so every probe waited for ALL of the wave's outstanding grid atomics.
+struct HotTab { int off; };
+NSR_DEV int *hot_tag(const HotTab &H) { return reinterpret_cast<int *>(lds_base()) + H.off; }
+NSR_DEV float *hot_val(const HotTab &H) { return reinterpret_cast<float *>(lds_base()) + H.off + kHotSlots; }
 NSR_DEV void hot_init(const HotTab &H) {
-    for (int i = tid(); i < kHotSlots * kC; i += nthreads()) H.val[i] = 0.f;
-    for (int i = tid(); i < kHotSlots; i += nthreads()) H.tag[i] = -1;
+    for (int i = tid(); i < kHotSlots * kC; i += nthreads()) hot_val(H)[i] = 0.f;
+    for (int i = tid(); i < kHotSlots; i += nthreads()) hot_tag(H)[i] = -1;
 }
 NSR_DEV void hot_flush(const HotTab &H, const GridDev &G) {       // after a block barrier: one half wave per occupied slot
     const int ch = tid() & 31;
     for (int s = tid() >> 5; s < kHotSlots; s += nthreads() >> 5) {
-        const int v = H.tag[s];
-        if (v >= 0) atomic_add_global(G.dfeat + (long long)v * kC + ch, H.val[s * kC + ch]);
+        const int v = hot_tag(H)[s];
+        if (v >= 0) atomic_add_global(G.dfeat + (long long)v * kC + ch, hot_val(H)[s * kC + ch]);
     }
 }
 
@@ -444,8 +444,8 @@ NSR_DEV void scatter_stage(const Lvl &L, int lane, const Act<2> &dc, bool active
 // the only divergent code is one predicated atomic per point -- the first version walked with a data-dependent branch nest
 // per point (~25 instructions and three branches, ~380 cycles per atomic: the walk, not the atomic unit, set the pace).
 NSR_DEV void scatter_walk(const GridDev &G, int lane, const float *Tx, const float *tab,
-                          float *lds_grid = nullptr,   // != NULL: the whole gradient grid sits in LDS (small grids, nsr_bwd2.h)
-                          const HotTab *hot = nullptr) {
+                          int lds_grid = -1,           // >= 0: the whole gradient grid sits in LDS at this offset (floats; small grids, nsr_bwd2.h)
+                          HotTab hot = HotTab{-1}) {
     const int *vt = reinterpret_cast<const int *>(tab);
     const float *wt = tab + 128;
     const int h = lane >> 5, ch = lane & 31;
@@ -471,21 +471,34 @@ NSR_DEV void scatter_walk(const GridDev &G, int lane, const float *Tx, const flo
             if (end && v[p] >= 0) {
                 const int vox = v[p] & ~kHotBit;
                 bool done = false;
-                if (lds_grid) { atomic_add_lds(lds_grid + vox * kC + ch, s[p]); done = true; }
-                else if (hot && (v[p] & kHotBit)) {
+                if (lds_grid >= 0) { atomic_add_lds(reinterpret_cast<float *>(lds_base()) + lds_grid + vox * kC + ch, s[p]); done = true; }
+                else if (hot.off >= 0 && (v[p] & kHotBit)) {
                     const int slot = (int)(((unsigned)vox * 2654435761u) >> 26);       // kHotSlots = 64
-                    int tg = hot->tag[slot];
-                    if (tg == -1) { const int old = atomic_cas_lds_i(hot->tag + slot, -1, vox); tg = old == -1 ? vox : old; }
-                    if (tg == vox) { atomic_add_lds(hot->val + slot * kC + ch, s[p]); done = true; }
+                    int tg = lds_load_i(hot_tag(hot) + slot);
+                    if (tg == -1) { const int old = atomic_cas_lds_i(hot_tag(hot) + slot, -1, vox); tg = old == -1 ? vox : old; }
+                    if (tg == vox) { atomic_add_lds(hot_val(hot) + slot * kC + ch, s[p]); done = true; }
                 }
-                if (!done) atomic_add_global(G.dfeat + (long long)vox * kC + ch, s[p]);
+                if (!done) {
+#if defined(NSR_X_SCATTER_HASH)          // A/B builds (tools/build_ts.sh ... -DNSR_X_...): same request count, voxels spread over the grid
+                    const int vx = (int)(((unsigned)vox * 2654435761u) % (unsigned)(G.X * G.Y * G.Z));
+#else
+                    const int vx = vox;
+#endif
+#if defined(NSR_X_SCATTER_STORE)         // plain stores to the same addresses (what the vector-memory path costs without the atomic)
+                    G.dfeat[(long long)vx * kC + ch] = s[p];
+#elif defined(NSR_X_SCATTER_HALF)        // one of the two 64-byte lines of every voxel row
+                    if (ch < 16) atomic_add_global(G.dfeat + (long long)vx * kC + ch, s[p]);
+#else
+                    atomic_add_global(G.dfeat + (long long)vx * kC + ch, s[p]);
+#endif
+                }
             }
         }
     }
 }
 NSR_DEV void scatter_merged(const GridDev &G, const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab,
-                            float *lds_grid = nullptr, const HotTab *hot = nullptr, bool hot_pt = false) {
-    scatter_stage(L, lane, dc, active, Tx, tab, hot && hot_pt);
+                            int lds_grid = -1, HotTab hot = HotTab{-1}, bool hot_pt = false) {
+    scatter_stage(L, lane, dc, active, Tx, tab, hot.off >= 0 && hot_pt);
     wave_fence();
     scatter_walk(G, lane, Tx, tab, lds_grid, hot);
     wave_fence();

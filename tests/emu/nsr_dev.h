@@ -163,6 +163,7 @@ NSR_DEV void sched_fence() {}
 NSR_DEV void sched_fence_gemv() {}
 NSR_DEV void sched_fence_emb() {}
 NSR_DEV void keep_alive(float) {}
+NSR_DEV void keep_alive_d(double) {}
 NSR_DEV void loop_fence() {}
 NSR_DEV void block_sync() { emu::block_sync_impl(); }
 
@@ -172,7 +173,6 @@ template <int N> NSR_DEV void dma_wait() {}
 NSR_DEV void flag_store(int *p, int v) { *p = v; }
 NSR_DEV int flag_load(const int *p);                  // (below shfl_any: every lane of the wave sees lane 0's reading)
 NSR_DEV void spin_pause() { emu::wave_sync(); }       // a polling wave lets the block's other waves run
-NSR_DEV void nap_us() {}
 NSR_DEV void atomic_add_global(float *p, float v) {
     // blocks may run on different OS threads: real atomic read-modify-write
     uint32_t *u = reinterpret_cast<uint32_t *>(p);
@@ -188,6 +188,8 @@ NSR_DEV void atomic_add_lds(float *p, float v) { *p += v; }
 NSR_DEV void atomic_add_lds_i(int *p, int v) { *p += v; }
 NSR_DEV int atomic_fetch_add_lds_i(int *p, int v) { const int o = *p; *p += v; return o; }
 NSR_DEV int atomic_cas_lds_i(int *p, int expect, int v) { const int o = *p; if (o == expect) *p = v; return o; }
+NSR_DEV int lds_load_i(const int *p) { return *p; }
+NSR_DEV float lds_load_f(const float *p) { return *p; }
 NSR_DEV void atomic_add_global_d(double *p, double v) { *p += v; }
 NSR_DEV unsigned long long atomic_fetch_add_global_u64(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
 NSR_DEV void atomic_max_pos(float *p, float v) {

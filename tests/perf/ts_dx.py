@@ -48,3 +48,14 @@ for p_ in range(npass):                                      # blocks [p * per, 
     print(f"   pass {p_}: {per} blocks, wave lifetime mean {lf.mean():.1f} max {lf.max():.1f} us; last exit after kernel start {(t[sl, :, 9][o2] - t0).max():.1f} us")
 life = (t[:, :, 9] - t[:, :, 0])[ok]
 print(f"   wave lifetime mean {life.mean():.1f} us, max {life.max():.1f}; exit after kernel start mean {(t[:, :, 9][ok] - t0).mean():.1f}, max {(t[:, :, 9][ok] - t0).max():.1f}")
+# per-phase totals of a wave over ALL its tiles (Dbg::stamp accumulates slot + 16, counts in slot + 32), per decoder pass
+print("   per-phase totals per wave over all its tiles (mean us | mean per passage | passages per wave):")
+for p_ in range(npass):
+    sl = slice(p_ * per, (p_ + 1) * per)
+    o2 = ok[sl]
+    print(f"   pass {p_}:")
+    for s in range(2, 8):
+        tot = (t[sl, :, 16 + s])[o2]
+        cnt = (buf.cpu().numpy().reshape(NB, NW, NS)[sl, :, 32 + s])[o2].astype(np.float64)
+        if cnt.sum() > 0:
+            print("      %-46s %8.2f %8.2f %6.2f" % (names[s], tot.mean(), tot.sum() / cnt.sum(), cnt.mean()))

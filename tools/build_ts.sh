@@ -7,6 +7,6 @@ ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 NAME="${1:-ts}"
 [ $# -gt 0 ] && shift
 mkdir -p "$ROOT/nice_slam_amd/_ab"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -munsafe-fp-atomics -fPIC -shared -x hip -DNSR_TS "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -munsafe-fp-atomics -fPIC -shared -x hip ${NSR_TS_DEF--DNSR_TS} "$@" \
     "$ROOT/nice_slam_amd/csrc/nsr_api.cpp" -o "$ROOT/nice_slam_amd/_ab/libnsr_$NAME.so"
 echo "built $ROOT/nice_slam_amd/_ab/libnsr_$NAME.so"
