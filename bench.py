@@ -184,10 +184,15 @@ def cpu_baseline(sc, n_rays, stages, weights, track_crop=None):
     def once(stage, m):
         G = {k: v.clone().requires_grad_(True) for k, v in grids.items()}
         P = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-        depth, _, col = orc.render_batch_ray(G, P, rays_d[:m], rays_o[:m], stage, gt_depth[:m], sc["bound"])
-        loss = (torch.abs(gt_depth[:m] - depth) * (gt_depth[:m] > 0)).sum()
+        o, d, gd, gc = rays_o[:m], rays_d[:m], gt_depth[:m], gt_color[:m]
+        with torch.no_grad():                                   # the mapper's pre-filter: rays removed from the batch (Mapper.py:471-481)
+            tt = (sc["bound"].unsqueeze(0) - o.unsqueeze(-1)) / d.unsqueeze(-1)
+            inside = torch.min(torch.max(tt, dim=2)[0], dim=1)[0] >= gd
+        o, d, gd, gc = o[inside], d[inside], gd[inside], gc[inside]
+        depth, _, col = orc.render_batch_ray(G, P, d, o, stage, gd, sc["bound"])
+        loss = (torch.abs(gd - depth) * (gd > 0)).sum()
         if stage == "color":
-            loss = loss + 0.2 * torch.abs(gt_color[:m] - col).sum()
+            loss = loss + 0.2 * torch.abs(gc - col).sum()
         loss.backward()
 
     t = {}
@@ -202,7 +207,7 @@ def cpu_baseline(sc, n_rays, stages, weights, track_crop=None):
         t[stage] = sorted(ts)[reps // 2]
     mix = sum(weights[s] * t[s] for s in stages) / sum(weights.values())
     return {"value": n / mix, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": "oracle (grid_sampler_3d mode) fwd+bwd, %d rays, median of %d iterations per stage (%s), weighted like the GPU run"
+            "sample": "oracle (grid_sampler_3d mode) pre-filter + fwd+bwd, %d sampled rays, median of %d iterations per stage (%s), weighted like the GPU run"
                       % (n, reps, ", ".join(f"{s} {t[s]*1e3:.0f} ms" for s in stages)),
             "port_vs_reference": "calibrated in the build container, where both run (tools/calibrate_cpu_baseline.py, "
                                  "profiles/README.md, 1000 rays at Replica shapes): this port takes 0.87 / 0.72 / 0.97 x the time of "
@@ -311,6 +316,9 @@ def main():
                     help="parameter gradients only for the decoder the reference's optimiser steps (colour); default: all, like the reference autograd")
     ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
                     help="multi-GPU: weak = the configuration's rays per GPU, strong = in total (default: strong for config 3 / 4, else weak)")
+    ap.add_argument("--render-masked", action="store_true",
+                    help="render the rays the bounding-box pre-filter rejects too and only mask them out of the loss (default: they are "
+                         "removed from the batch like the reference's compaction does, Mapper.py:471-481)")
     ap.add_argument("--dense-exchange", action="store_true",
                     help="multi-GPU: all-reduce the whole feature-grid gradients instead of the frustum-selected voxel rows")
     args = ap.parse_args()
@@ -365,6 +373,8 @@ def main():
         grids = {k: v.detach() for k, v in grids.items()}
     if args.stepped_grads_only:
         renderer.decoder_grads = ("color",)
+    if args.render_masked:
+        renderer.skip_masked_rays = False
     H, W, fx, fy, cx, cy = sc["intr"]
     frames = [(c.to(dev), d.to(dev), col.to(dev)) for c, d, col in sc["frames"]]
     K = len(frames)
@@ -417,7 +427,7 @@ def main():
         if tracking and not args.unfused:                         # Tracker.optimize_cam_in_batch (Tracker.py:87-125) as one autograd node
             cam.grad = None
             loss = nsa.tracking_loss(renderer, grids, dec, cam, frames[0][1], frames[0][2], rays_rank, crop, crop, w_color=0.5)
-            loss.backward()
+            nsa.backward(loss)                                    # = loss.backward() without autograd's ones_like fill
         elif tracking:                                            # the same through the drop-in surface, sync-free form
             cam.grad = None
             o, d, gd, gc = nsa.get_samples(crop, H - crop, crop, W - crop, rays_rank, H, W, fx, fy, cx, cy, cam, frames[0][1], frames[0][2], dev)
@@ -431,7 +441,7 @@ def main():
             loss.backward()
         elif shard is not None:
             loss = shard.mapping_loss(grids, dec, frames, per_frame, stage)
-            loss.backward()
+            nsa.backward(loss)
         elif args.unfused:                                        # the reference's call sequence through the drop-in surface
             ro, rd, gd, gc = [], [], [], []
             for c2w, dimg, cimg in frames:
@@ -445,7 +455,7 @@ def main():
             loss.backward()
         else:                                                      # Mapper.py:437-503 as one autograd node (mapping.py)
             loss = nsa.mapping_loss(renderer, grids, dec, frames, per_frame, stage, w_color=0.2, coarse_mapper=(stage == "coarse"))
-            loss.backward()
+            nsa.backward(loss)
         renderer.profile_events = ev.pair_for
         return stage
 
@@ -527,6 +537,14 @@ def main():
         windows.append(dt)
     dt = sorted(windows)[len(windows) // 2]
     rays_iter = rays_rank * world
+    kept_frac = None
+    if not args.unfused and shard is None:                          # what share of the sampled rays passes the pre-filter (one extra iteration, untimed)
+        info = {}
+        if tracking:
+            nsa.tracking_loss(renderer, grids, dec, cam, frames[0][1], frames[0][2], rays_rank, crop, crop, w_color=0.5, out=info)
+        else:
+            nsa.mapping_loss(renderer, grids, dec, frames, per_frame, stages_cfg[-1], w_color=0.2, coarse_mapper=(stages_cfg[-1] == "coarse"), out=info)
+        kept_frac = float(info["keep"].float().mean().item())
     shard_check = None
     if args.verify_shards and shard is not None:
         shard_check = verify_shards(nsa, shard, renderer, grids, dec, frames, per_frame, stages_cfg[-1], H, W, world, rank, dev)
@@ -548,6 +566,10 @@ def main():
             "config": {"workload": C["name"] + ": grids " + " / ".join("x".join(str(v) for v in grids[k].shape[2:]) for k in grids) +
                                    f", 32 ch fp32, random-init decoders, {H}x{W} synthetic RGB-D, {K}x{per_frame} pixels/iter/GPU, S=32+16",
                        "rays_per_gpu": rays_rank, "rays_per_iteration": rays_iter,
+                       "rays_kept_by_prefilter": kept_frac,
+                       "prefilter": ("rays whose depth lies outside the bound (Mapper.py:471-481 / Tracker.py:95-104) are sampled and counted in "
+                                     "`value`, then " + ("rendered and masked out of the loss (--render-masked)" if args.render_masked or args.unfused else
+                                                         "removed from the batch like the reference's boolean-mask compaction does: no decoder work, no gradient")),
                        "stage_mix": {s: stages.count(s) for s in sorted(set(stages))},
                        "timed_region": (("get_samples (crop) + bounding-box mask + render_batch_ray(color) + tracking loss (torch) + backward to the pose"
                                          if args.unfused else

@@ -110,6 +110,13 @@ typedef struct nsr_render_args {
      * nsr_render_bwd, given the SAME pointer, loads them instead of re-running -- 288 GB of HBM traded for a quarter of the
      * backward's work.  Ignored in the coarse stage. */
     float *acts;
+    int32_t skip_masked;      /* ABI 6, with `keep`: 1 = rays with keep[r] == 0 are REMOVED from the batch like the reference's
+                                 compaction does (src/Mapper.py:471-481, src/Tracker.py:95-104: `batch_rays_d[inside_mask]`): no
+                                 decoder evaluation, outputs depth = var = rgb = 0, no loss term, no gradient.  Their slots of
+                                 raw / zvals / acts stay unwritten.  nsr_render_bwd must be given the same keep / skip_masked.
+                                 Honoured by calls that will be differentiated (acts + zvals + raw given); a forward-only call
+                                 renders every ray.  0 (default): keep only masks the fused loss; every ray is rendered. */
+    int32_t pad2_;
 } nsr_render_args;
 
 typedef struct nsr_bwd_args {

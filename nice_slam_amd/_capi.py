@@ -40,7 +40,8 @@ class NsrRenderArgs(C.Structure):
                 ("depth", C.c_void_p), ("var", C.c_void_p), ("rgb", C.c_void_p), ("raw", C.c_void_p),
                 ("zvals", C.c_void_p),
                 ("gt_color", C.c_void_p), ("keep", C.c_void_p), ("loss", C.c_void_p), ("dl_depth", C.c_void_p), ("dl_rgb", C.c_void_p),
-                ("w_color", C.c_float), ("acts_masks_only", C.c_int32), ("acts", C.c_void_p)]
+                ("w_color", C.c_float), ("acts_masks_only", C.c_int32), ("acts", C.c_void_p),
+                ("skip_masked", C.c_int32), ("pad2_", C.c_int32)]
 
 
 class NsrBwdArgs(C.Structure):

@@ -159,6 +159,7 @@ int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays,
     }
     P.depth = a->depth; P.var = a->var; P.rgb = a->rgb; P.raw = a->raw; P.zvals = a->zvals;
     P.gt_color = a->gt_color; P.keep = a->keep; P.loss = a->loss; P.w_color = a->w_color;
+    P.skip_masked = (a->skip_masked && a->keep && a->acts && a->zvals && a->raw) ? 1 : 0;      // (the one-launch forward renders every ray)
     P.dl_depth = a->dl_depth; P.dl_rgb = a->dl_rgb; P.loss_depth = a->gt_depth;
     return 0;
 }

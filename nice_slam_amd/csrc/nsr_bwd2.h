@@ -42,6 +42,10 @@ NSR_KERNEL void comp_bwd_kernel(const RenderParams P) {
     const long long ray = (long long)bid_x() * nw + wave;
     if (ray >= P.n_rays) return;
     const int S = P.S;
+    if (!ray_live(P, ray)) {             // removed by the pre-filter: its samples inside a tile shared with a kept ray carry no gradient
+        if (lane < S) st4(P.draw + (ray * S + lane) * 4, F4{0.f, 0.f, 0.f, 0.f});
+        return;
+    }
     const bool act = lane < S;
     const long long gp = ray * S + (act ? lane : 0);
     const F4 rw = act ? ld4(P.raw + gp * 4) : F4{0.f, 0.f, 0.f, 0.f};
@@ -169,10 +173,13 @@ NSR_DEV void dx_pass(const RenderParams &P) {
     for (int k = 0; k < kET; ++k) { aB[k][0] = 0.f; aB[k][1] = 0.f; aB[k][2] = 0.f; }
 
     const long long t0 = dyn ? ntiles * bid_x() / nblk_x() : 0, tend = dyn ? ntiles * (bid_x() + 1) / nblk_x() : ntiles;
-    auto claim = [&]() -> long long {                        // the block's next unclaimed tile (wave-uniform)
-        int k = 0;
-        if (lane == 0) k = atomic_fetch_add_lds_i(tcnt, 1);
-        return t0 + shfl_i(k, 0);
+    auto claim = [&]() -> long long {                        // the block's next unclaimed tile that holds a ray of the batch (wave-uniform)
+        for (;;) {
+            int k = 0;
+            if (lane == 0) k = atomic_fetch_add_lds_i(tcnt, 1);
+            const long long t = t0 + shfl_i(k, 0);
+            if (t >= tend || tile_live(P, t)) return t;
+        }
     };
     // d raw written by the forward's loss epilogue: the incoming gradient applies here (one uniform scalar, read once)
     const float dr_scale = (!P.draw_scaled && P.g_scale) ? (float)P.g_scale[0] : 1.f;
@@ -730,6 +737,20 @@ struct DwNoxWave {
     }
 };
 
+// Which of the 64 tiles bi + (64 c + i) * step, i = 0..63, of a block's sequence hold a ray of the batch (bit i; see tile_live):
+// one vector load per lane and a ballot, once per 64 tiles, so that neither the compute waves' tile loop nor the loaders' DMA
+// queue waits for a mask byte per tile.
+NSR_DEV unsigned long long dw_live_mask(const RenderParams &P, long long bi, long long step, int chunk, long long ntiles, int lane) {
+    if (!P.skip_masked) return ~0ull;
+    const long long t = bi + ((long long)chunk * 64 + lane) * step;
+    bool live = false;
+    if (t < ntiles) {
+        const long long p0 = t * kTile, pe = p0 + kTile < P.n_points_total ? p0 + kTile : P.n_points_total;
+        for (long long r = p0 / P.S; r <= (pe - 1) / P.S; ++r) live = live || P.keep[r] != 0;
+    }
+    return ballot64(live);
+}
+
 // control words behind the ring: landed[j] = tiles loader j has landed, prog[w] = tiles compute wave w is done with
 template <int KIND, class W>
 NSR_DEV void dw_compute(const RenderParams &P, W &Wv, float *ring, int *ctl, float *img, int wave, int lane, int bi, int nbp) {
@@ -744,11 +765,15 @@ NSR_DEV void dw_compute(const RenderParams &P, W &Wv, float *ring, int *ctl, flo
     // waves per SIMD a 10-wave block implies: 135 us instead of 65, profiles/r03_dw_variants.txt.)
     typename W::Ops ops;
     int k = 0;
+    unsigned long long lm = ~0ull;
     for (long long t = bi; t < ntl; t += step, ++k) {
         loop_fence();
+        if ((k & 63) == 0) lm = dw_live_mask(P, bi, step, k >> 6, ntiles, lane);
         while (flag_load(ctl + (k & 1)) <= (k >> 1)) spin_pause();          // the loader of this tile has landed it
-        Wv.fetch(dw_src<KIND>(ring + (k % kDwRing) * Y::kSlot), lane, ops);
-        Wv.consume(ops, lane, (t == last && ragged) ? ragged : kTile);
+        if ((lm >> (k & 63)) & 1ull) {                                       // (else: the loader left the slot empty)
+            Wv.fetch(dw_src<KIND>(ring + (k % kDwRing) * Y::kSlot), lane, ops);
+            Wv.consume(ops, lane, (t == last && ragged) ? ragged : kTile);
+        }
         flag_store(ctl + kDwLoaders + wave, k + 1);                          // (release: the slot's reads have returned)
     }
     Wv.flush(img, lane);
@@ -760,9 +785,12 @@ NSR_DEV void dw_loader(const RenderParams &P, float *ring, int *ctl, int j, int 
     const long long ntiles = (P.n_points_total + kTile - 1) / kTile;
     const long long step = nbp, ntl = (P.xflags & 64) ? 0 : ntiles;
     int m = 0;                                                               // this loader's m-th tile is the block's tile 2 m + j
+    unsigned long long lm = ~0ull;
+    int chunk = -1;
     for (long long t = bi + j * step; t < ntl; t += kDwLoaders * step, ++m) {
         loop_fence();
         const int k = kDwLoaders * m + j;
+        if ((k >> 6) != chunk) { chunk = k >> 6; lm = dw_live_mask(P, bi, step, chunk, ntiles, lane); }
         if (k >= kDwRing) {                                                  // the slot still holds tile k - kDwRing
             for (;;) {
                 int lo = flag_load(ctl + kDwLoaders);
@@ -772,8 +800,13 @@ NSR_DEV void dw_loader(const RenderParams &P, float *ring, int *ctl, int j, int 
                 spin_pause();
             }
         }
-        dw_issue<KIND>(P, t, ring + (k % kDwRing) * Y::kSlot, lane);
-        if (m >= 1) { dma_wait<Y::NOPS>(); flag_store(ctl + j, m); }          // all but the newest tile's pieces have landed
+        if ((lm >> (k & 63)) & 1ull) {
+            dw_issue<KIND>(P, t, ring + (k % kDwRing) * Y::kSlot, lane);
+            if (m >= 1) { dma_wait<Y::NOPS>(); flag_store(ctl + j, m); }      // all but the newest tile's pieces have landed
+        } else if (m >= 1) {                                                 // a tile without a ray of the batch: nothing to load
+            dma_wait<0>();
+            flag_store(ctl + j, m);
+        }
     }
     dma_wait<0>();
     flag_store(ctl + j, m);

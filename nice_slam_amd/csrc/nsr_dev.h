@@ -32,6 +32,7 @@ NSR_DEV int bid_y() { return (int)blockIdx.y; }
 NSR_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }      // pin a wave-uniform value to an SGPR
 NSR_DEV int nblk_x() { return (int)gridDim.x; }
 
+NSR_DEV unsigned long long ballot64(bool p) { return __ballot(p); }            // bit l = lane l's predicate
 NSR_DEV float shfl(float v, int src) { return __shfl(v, src, 64); }
 NSR_DEV int shfl_i(int v, int src) { return __shfl(v, src, 64); }
 NSR_DEV double shfl_d(double v, int src) { return __shfl(v, src, 64); }
@@ -167,6 +168,18 @@ NSR_DEV unsigned long long atomic_fetch_add_global_u64(unsigned long long *p, un
 // max of non-negative floats (their bit patterns order like unsigned integers)
 NSR_DEV void atomic_max_pos(float *p, float v) {
     __hip_atomic_fetch_max((nsr_guint *)reinterpret_cast<unsigned *>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One byte at a WAVE-UNIFORM address through the scalar cache (s_load_dword of the aligned word): counted by lgkmcnt, not by the
+// in-order vector-memory counter -- a vector load issued behind a wave's scatter atomics could only be waited for together
+// with all of them.  The array must not be written by the launch that reads it this way.
+NSR_DEV unsigned uniform_load_u8(const unsigned char *p) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(a & ~3ull)), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const unsigned long long base = ((unsigned long long)hi << 32) | lo;
+    unsigned w;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(base) : "memory");
+    return (w >> (8u * (__builtin_amdgcn_readfirstlane((unsigned)a) & 3u))) & 255u;
 }
 
 NSR_DEV char *lds_base() {

@@ -33,6 +33,7 @@ NSR_KERNEL void fwd_sample_kernel(const RenderParams P) {
     const int S = P.S;
     double *zw = zs + wave * 64;
     if (ray >= P.n_rays) return;                                     // whole wave (no block barrier below)
+    // (rays the pre-filter removed are placed too: a tile that straddles a removed and a kept ray is evaluated as a whole)
     const bool act = lane < S;
     const int k = act ? lane : 0;
     const bool guided = (P.gt_depth != nullptr) && (P.stage != NSR_STAGE_COARSE);
@@ -119,6 +120,7 @@ NSR_DEV void fwd_pass(const RenderParams &P, int bi, int nbp) {
         if (lane == 0) take = atomic_fetch_add_lds_i(cnt, 1);
         const long long tile = t0 + shfl_i(take, 0);
         if (tile >= t1) break;
+        if (!tile_live(P, tile)) continue;                           // every ray of the tile was removed by the pre-filter
         loop_fence();
         const long long gp = tile * kTile + pt;
         const bool active = gp < P.n_points_total;
@@ -190,7 +192,16 @@ NSR_KERNEL void fwd_composite_kernel(const RenderParams P) {
     const long long rayq = (long long)bid_x() * nw + wave;
     const int S = P.S;
     double lterm = 0.0;
-    if (rayq < P.n_rays) {
+    if (rayq < P.n_rays && !ray_live(P, rayq)) {                     // removed by the pre-filter: no sample was evaluated
+        if (lane == 0) {
+            P.depth[rayq] = 0.0; P.var[rayq] = 0.0;
+            P.rgb[rayq * 3 + 0] = 0.f; P.rgb[rayq * 3 + 1] = 0.f; P.rgb[rayq * 3 + 2] = 0.f;
+            if (P.loss && P.dl_depth) P.dl_depth[rayq] = 0.0;
+            if (P.loss && P.dl_rgb) { P.dl_rgb[rayq * 3 + 0] = 0.f; P.dl_rgb[rayq * 3 + 1] = 0.f; P.dl_rgb[rayq * 3 + 2] = 0.f; }
+        }
+        // its samples inside a tile shared with a kept ray carry no gradient
+        if (P.loss && P.dl_depth && lane < S) st4(P.draw + (rayq * S + lane) * 4, F4{0.f, 0.f, 0.f, 0.f});
+    } else if (rayq < P.n_rays) {
         const bool act = lane < S;
         const long long gq = rayq * S + (act ? lane : 0);
         double qx = 0.0, qy = 0.0, qz = 0.0, zq = 0.0;

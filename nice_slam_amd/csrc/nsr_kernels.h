@@ -96,6 +96,7 @@ struct RenderParams {
     int dw_beg[4];            // dW kernel: blocks [dw_beg[p], dw_beg[p + 1]) = partial images of decoder pass p
     int draw_scaled;          // 1: `draw` already carries nsr_bwd_args.grad_scale (comp_bwd_kernel ran); 0: the forward wrote it
     int xflags;               // measurement switches (NSR_X environment variable; 0 in normal operation)
+    int skip_masked;          // 1 (with keep): rays with keep == 0 are not part of the batch (nsr_render_args.skip_masked)
     int lds_grid_floats;      // > 0 (coarse stage): the gradient grid (this many floats) is accumulated in the dX block's LDS
     float hot_z[4];           // dX kernel, per grid: samples with z below it use the block's hot-voxel table (0: no table)
     int pass_beg[4];          // pass kernels (nsr_fwd2.h): blocks [pass_beg[p], pass_beg[p + 1]) of the launch work on decoder pass p
@@ -104,6 +105,18 @@ struct RenderParams {
     long long n_points;
     float *out_points;
 };
+
+// Does 16-point tile `tile` of the sample list hold a sample of a ray that is part of the batch?  (nsr_render_args.skip_masked:
+// rays the callers' bounding-box pre-filter rejected are removed, like the reference's compaction, src/Mapper.py:471-481.)
+// Wave-uniform; the mask bytes come through the scalar cache.  Forward passes, dX, dW and the compositor apply the same test.
+NSR_DEV bool ray_live(const RenderParams &P, long long ray) { return !P.skip_masked || uniform_load_u8(P.keep + ray) != 0u; }
+NSR_DEV bool tile_live(const RenderParams &P, long long tile) {
+    if (!P.skip_masked) return true;
+    const long long p0 = tile * kTile, pe = p0 + kTile < P.n_points_total ? p0 + kTile : P.n_points_total;
+    bool live = false;
+    for (long long r = p0 / P.S; r <= (pe - 1) / P.S; ++r) live = live || uniform_load_u8(P.keep + r) != 0u;
+    return live;
+}
 
 // ------------------------------------------------------------------------------------------------
 // parameter packing: flat blob -> [aux table | MFMA operand stream]  (what the render kernels copy into LDS, verbatim)

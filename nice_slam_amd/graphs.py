@@ -1,18 +1,18 @@
-"""hipGraph capture of a mapping / tracking iteration.
+"""hipGraph capture of a mapping / tracking iteration (convenience around torch.cuda.CUDAGraph, no kernel of its own).
 
-The render path is two large kernels surrounded by a few dozen tiny ones (index draws, concatenations, the caller's loss
-and its backward, gradient plumbing); run eagerly from Python the iteration is bound by launch overhead (≈0.7 ms on
-MI355X for the Replica mapping iteration, whose kernels take 0.4 ms).  Everything this package launches is capturable:
-no host synchronisation, no data-dependent shapes, workspaces and gradient blobs at stable addresses.  ``CapturedStep``
-wraps the usual torch recipe (warm-up on a side stream, capture, replay):
+A fused mapping iteration (``mapping_loss`` + ``backward``) is seven launches of 5-100 us (zero fill, window kernel, decoder
+passes, compositor, dX, dW, finalize), a tracking iteration nine of 5-30 us: launched eagerly from Python the host sets the pace
+(~10 us per launch), replayed from a graph the GPU runs them back to back.  Everything this package launches is capturable: no
+host synchronisation, no data-dependent shapes, workspaces / packed decoder buffers / gradient blobs / the in-kernel pixel
+draw's state at stable addresses.  ``CapturedStep`` wraps the usual torch recipe (warm-up on a side stream, capture, replay):
 
     step = nice_slam_amd.graphs.CapturedStep(one_iteration)     # one_iteration(): no arguments, static shapes,
     for _ in range(n): step()                                   # reads its inputs from tensors it closes over
 
 What the closure must respect is torch's, not ours: no ``.item()`` / boolean-mask indexing inside (use
-``nice_slam_amd.aabb_keep`` instead of the compaction of Mapper.py:471-481), optimisers with ``capturable=True`` (or
-``MaskedGridAdam``, whose step scalars are host-side and therefore belong outside the captured region), and fresh inputs
-are written INTO the closed-over tensors (``t.copy_(new)``) before each replay.
+``nice_slam_amd.aabb_keep`` or the fused losses instead of the compaction of Mapper.py:471-481), optimisers with
+``capturable=True`` (``MaskedGridAdam(capturable=True)`` keeps its step counts on the device), and fresh inputs are written INTO
+the closed-over tensors (``t.copy_(new)``) before each replay.
 """
 from __future__ import annotations
 

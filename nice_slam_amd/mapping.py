@@ -260,8 +260,12 @@ class _MappingLossFn(torch.autograd.Function):
             a.n_surface = 0
         a.depth, a.var, a.rgb, a.raw, a.zvals = depth.data_ptr(), var.data_ptr(), rgb.data_ptr(), raw.data_ptr(), zvals.data_ptr()
         if track is None:                                       # the mapper's L1 loss is accumulated by the forward kernel itself
-            a.gt_color, a.keep, a.loss, a.w_color = gt_color.data_ptr(), keep.data_ptr(), loss.data_ptr(), float(w_color)
+            a.gt_color, a.loss, a.w_color = gt_color.data_ptr(), loss.data_ptr(), float(w_color)
             a.dl_depth, a.dl_rgb = dl_depth.data_ptr(), dl_rgb.data_ptr()
+        # the rays the bounding-box pre-filter rejects: masked out of the loss, and -- like the reference, which removes them from
+        # the batch (Mapper.py:471-481, Tracker.py:95-104) -- not rendered at all unless Renderer.skip_masked_rays is off
+        a.keep = keep.data_ptr()
+        a.skip_masked = 1 if (renderer.skip_masked_rays and need_bwd) else 0
         acts = renderer._attach_acts(a, stage, N, S, dev, masks_only=not any(need_par)) if need_bwd else None
         if need_bwd and acts is None:
             raise _capi.NsrError("nice_slam_amd: the activation buffer of a %d-ray fused iteration does not fit (Renderer."
@@ -360,3 +364,20 @@ def tracking_loss(renderer, c, decoders, c2w: torch.Tensor, depth: torch.Tensor,
                    (renderer.decoder_grads is None or s in renderer.decoder_grads)) for s in slots]
     meta = (renderer, decoders, "color", wmeta, w_color, None, out, (bool(handle_dynamic), bool(use_color)))
     return _MappingLossFn.apply(meta, *c2ws, *[grids[s] for s in slots], *gates)
+
+
+_ONES = {}
+
+
+def backward(loss: torch.Tensor, retain_graph: bool = False):
+    """``loss.backward()`` for a scalar loss without the fill kernel with which autograd creates the root gradient on every call
+    (``torch.ones_like(loss)``: one launch, ~5 us of a 230 us mapping iteration): the root gradient is a constant 1 kept per
+    (device, dtype).  Same gradients as ``loss.backward()``."""
+    key = (loss.device, loss.dtype)
+    one = _ONES.get(key)
+    if one is None:
+        if torch.cuda.is_available() and loss.is_cuda and torch.cuda.is_current_stream_capturing():
+            return loss.backward(retain_graph=retain_graph)          # first use under capture: the plain path (allocates inside the graph)
+        one = _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    torch.autograd.backward(loss, grad_tensors=one.expand_as(loss) if loss.dim() else one, retain_graph=retain_graph)
+

@@ -382,6 +382,10 @@ class Renderer(object):
         # (_chunked_backward: per chunk a forward that saves, then the split backward).
         self.max_saved_activation_bytes = 64 << 30
         self.acts_memory_fraction = 0.6
+        # Fused iterations (mapping_loss / tracking_loss): the rays the callers' bounding-box pre-filter rejects are removed from the
+        # batch like the reference's compaction does (Mapper.py:471-481, Tracker.py:95-104) -- no decoder evaluation, outputs 0, no
+        # gradient -- instead of being rendered and masked out of the loss (False: render them, e.g. to look at their outputs).
+        self.skip_masked_rays = True
         # Optional: restrict parameter gradients to these decoders, e.g. ("color",).  The reference's autograd
         # produces dW for every decoder in every stage although src/Mapper.py:335-341 only ever steps the colour
         # decoder (and the fine one when fix_fine is False); None = reference semantics (requires_grad decides).

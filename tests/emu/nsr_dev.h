@@ -142,6 +142,13 @@ inline T shfl_any(T v, int src) {
     const emu::Slot *buf = emu::exchange(&v, sizeof(T));
     return emu::slot_get<T>(buf, src & 63);
 }
+NSR_DEV unsigned long long ballot64(bool p) {
+    int v = p ? 1 : 0;
+    const emu::Slot *buf = emu::exchange(&v, sizeof(int));
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) if (emu::slot_get<int>(buf, l)) m |= 1ull << l;
+    return m;
+}
 NSR_DEV int flag_load(const int *p) { return shfl_any(*p, 0); }
 NSR_DEV float shfl(float v, int src) { return shfl_any(v, src); }
 NSR_DEV int shfl_i(int v, int src) { return shfl_any(v, src); }
@@ -170,7 +177,9 @@ NSR_DEV void block_sync() { emu::block_sync_impl(); }
 NSR_DEV void prefetch_line(const float *, float *) {}
 NSR_DEV void dma16(const float *gsrc, float *lds_base, int lane) { std::memcpy(lds_base + lane * 4, gsrc, 16); }
 template <int N> NSR_DEV void dma_wait() {}
-NSR_DEV void flag_store(int *p, int v) { *p = v; }
+// (a wave's lanes run in lock step on the device: everything the wave did before the flag store has been done by ALL its lanes --
+//  the fibers rendezvous here, else the first lane to arrive would publish the flag ahead of its siblings' copies)
+NSR_DEV void flag_store(int *p, int v) { emu::wave_sync(); *p = v; }
 NSR_DEV int flag_load(const int *p);                  // (below shfl_any: every lane of the wave sees lane 0's reading)
 NSR_DEV void spin_pause() { emu::wave_sync(); }       // a polling wave lets the block's other waves run
 NSR_DEV void atomic_add_global(float *p, float v) {
@@ -199,6 +208,7 @@ NSR_DEV void atomic_max_pos(float *p, float v) {
     while (old < nw && !__atomic_compare_exchange_n(u, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
 }
 
+NSR_DEV unsigned uniform_load_u8(const unsigned char *p) { return *p; }
 NSR_DEV char *lds_base() { return emu::B->lds; }
 
 struct Stream { const float *base; };

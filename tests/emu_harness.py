@@ -143,6 +143,7 @@ class HostScene:
             keep += [gcol, kp]
             a.gt_color, a.keep, a.loss, a.w_color = ptr(gcol), ptr(kp), ptr(out["loss"]), float(fused_loss.get("w_color", 0.2))
             a.dl_depth, a.dl_rgb = ptr(out["dl_depth"]), ptr(out["dl_rgb"])
+            a.skip_masked = 1 if fused_loss.get("skip_masked") else 0        # masked rays removed from the batch (nsr_render_args.skip_masked)
         self.lib.check(self.lib.nsr_render_fwd(C.byref(a), None), "fwd")
         out["_ctx"] = (a, keep, rays_o, rays_d, gt, S)
         return out
@@ -189,6 +190,7 @@ class HostScene:
             b.d_rays_o, b.d_rays_d = ptr(res["d_rays_o"]), ptr(res["d_rays_d"])
         nws = self.lib.nsr_bwd_workspace_floats(_capi.STAGE_ID[stage], n, S, max_blocks)
         ws = np.full(max(nws, 1), np.nan, dtype=np.float32)
+        self.last_ws = ws
         b.workspace, b.workspace_floats, b.max_blocks = ptr(ws), nws, max_blocks
         b.overwrite_dparams = 1 if overwrite_dparams else 0
         gs = None if grad_scale is None else np.array([grad_scale], dtype=np.float64)

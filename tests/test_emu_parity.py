@@ -782,3 +782,35 @@ def test_fused_forward_leaves_d_raw_for_the_split_backward(emu, stage):
     edited = sc.backward(stage, fwd, None, None, None, in_place=True, grad_scale=1.75)
     for k, v in res["comp_bwd"].items():
         assert rel_err(edited[k], -3.0 * v) < 1e-5, (stage, k)
+
+
+@pytest.mark.parametrize("stage,n_surface", [("coarse", 16), ("middle", 16), ("color", 16), ("color", 5)])
+def test_masked_rays_are_removed_from_the_batch(emu, stage, n_surface):
+    """nsr_render_args.skip_masked: the rays the bounding-box pre-filter rejects (keep == 0) are not rendered -- what the
+    reference's compaction does (Mapper.py:471-481) -- in the forward passes, the compositor, dX and dW alike: the loss and every
+    gradient equal those of the run that renders them and masks the loss (their terms are exact zeros there), the kept rays'
+    outputs are bit-identical, the removed rays' outputs are 0.  n_surface = 5: 37 samples per ray, tiles that straddle two rays
+    (a tile is skipped only if BOTH are removed); long runs of removed rays: whole tiles, whole dW ring slots stay empty."""
+    s = make_scene(seed=123, n_rays=53, small=True)
+    g = torch.Generator().manual_seed(9)
+    keep = (torch.rand((53,), generator=g) < 0.7).numpy().astype(np.uint8)
+    keep[10:25] = 0                                    # a run of removed rays
+    keep[40] = 1
+    res = {}
+    for skip in (False, True):
+        sc = _host_scene(emu, s["grids"], s["params"], s["bound"].numpy())
+        sc.n_surface = n_surface
+        fl = {"gt_color": s["gt_color"].numpy(), "keep": keep, "w_color": 0.2, "skip_masked": skip}
+        fwd = sc.forward(stage, s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy(), fused_loss=fl)
+        bwd = sc.backward(stage, fwd, None, None, None, from_forward=True, grad_scale=0.5, max_blocks=3)
+        res[skip] = (fwd, bwd)
+    f0, f1 = res[False][0], res[True][0]
+    k = keep.astype(bool)
+    assert abs(f0["loss"][0] - f1["loss"][0]) <= 1e-12 * abs(f0["loss"][0]) and f0["loss"][0] > 0
+    for key in ("depth", "var", "rgb"):
+        assert np.array_equal(f0[key][k], f1[key][k]), key
+        assert not np.any(f1[key][~k]), key
+    assert set(res[False][1]) == set(res[True][1])
+    for key, v in res[False][1].items():
+        assert rel_err(res[True][1][key], v) < 1e-5, (stage, key)
+

@@ -448,16 +448,20 @@ def test_fused_losses_are_ordinary_autograd_nodes():
         for p in dec.parameters():
             p.requires_grad_(True); p.grad = None
         loss = nsa.mapping_loss(renderer, c, dec, frames, n, "color", w_color=0.2, indices=idx)
-        (loss if w is None else (loss * w + 1.0) / 2.0).backward()
+        if w == "helper":
+            nsa.backward(loss)                       # loss.backward() without autograd's ones_like fill
+        else:
+            (loss if w is None else (loss * w + 1.0) / 2.0).backward()
         g = {k: v.grad.clone() for k, v in c.items() if v.grad is not None}
         g.update({k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None})
         g.update({f"pose{k}": f[0].grad.clone() for k, f in enumerate(frames)})
         assert len(g) >= 3 + 30 + K
         return g
 
-    g1, g3 = run(None), run(-3.0)
+    g1, g3, gh = run(None), run(-3.0), run("helper")
     for k in g1:
         assert rel_err(g3[k], -1.5 * g1[k]) < 2e-5, k
+        assert rel_err(gh[k], g1[k]) < 2e-5, k
     c2w = sc["c2w"][:3].clone().to(DEV).requires_grad_(True)
     lt = nsa.tracking_loss(renderer, grids_dev, dec, c2w, sc["depth_img"].to(DEV), sc["color_img"].to(DEV), 150, 4, 4, indices=idx[:150] % ((H - 8) * (W - 8)))
     (0.25 * lt).backward()

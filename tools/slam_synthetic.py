@@ -329,7 +329,7 @@ class MiniSLAM:
             loss = nsa.tracking_loss(ops.renderer, ops.c_track, ops.decoders_track, c2w, ft["depth"], ft["color"], tc["pixels"],
                                      tc["ignore_edge_H"], tc["ignore_edge_W"], w_color=tc["w_color_loss"],
                                      handle_dynamic=tc["handle_dynamic"], use_color=tc["use_color_in_tracking"])
-            loss.backward()
+            nsa.backward(loss)
             opt.step()
             with torch.no_grad():
                 ft["hist"].index_copy_(0, ft["i"], torch.cat([loss.detach().reshape(1).float(), cam.detach()]).reshape(1, 8))
@@ -529,7 +529,7 @@ class MiniSLAM:
             poses = nsa.get_camera_from_tensor(cam_all).unbind(0) if BA else ()     # one launch each way for the whole window
             fr = [(poses[cam_of[f]] if f in cam_of else c2w, d, c) for f, d, c, c2w in data]
             loss = nsa.mapping_loss(ops.renderer, ops.c, ops.decoders, fr, pix, stage, w_color=mc["w_color_loss"])
-            loss.backward()
+            nsa.backward(loss)
             opt.step()
             st = mc["stage"][stage]
             with torch.no_grad():
@@ -593,7 +593,7 @@ class MiniSLAM:
         def iteration(slot):
             ops.zero_grads()
             loss = nsa.mapping_loss(ops.renderer, ops.c, ops.decoders, fr, pix, "coarse", w_color=mc["w_color_loss"], coarse_mapper=True)
-            loss.backward()
+            nsa.backward(loss)
             with torch.no_grad():
                 gopt.step({"grid_coarse": lr})
             loss_buf[slot:slot + 1].copy_(loss.detach().reshape(1))
