@@ -34,6 +34,9 @@ NEC_MAC = {"coarse": 12352, "middle": 24727, "fine": 59694, "color": 106140}    
 # MACs per sample point a re-run backward would issue (decoder forward + dX + dW of every decoder; SQ_INSTS_VALU_MFMA_MOPS_F32
 # x 512 FLOP of round 2's kernel, profiles/r02_pmc_bench_kernels.txt; coarse: 3 x forward); the split backward issues this minus
 # the forward (FWD_MAC), which is what `executed_frac` below uses
+# of the backward's necessary MACs: the dW part = the weights of the decoder the mapper's optimiser steps in that stage (colour stage: the
+# colour decoder, 32x96 + 3 x 32x32 + 32x128 + 5 x 32x32 + 3x32 = 15 456); the rest is dX (gradients to the stepped grids through all decoders)
+DW_NEC_MAC = {"coarse": 0, "middle": 0, "fine": 0, "color": 15456}
 EXEC_BWD_MAC = {"coarse": 3 * 6176, "middle": 46080, "fine": 102400, "color": 148480}
 
 # ---- BASELINE.json configs ------------------------------------------------------------------------
@@ -76,11 +79,12 @@ _CYCLE = _stage_cycle()
 
 
 class HipEvents:
-    """Raw hipEvent pairs (the kernels run on torch's current stream, recorded inside nsr_render_bwd)."""
+    """Raw hipEvents (the kernels run on torch's current stream; the records happen inside nsr_render_fwd / nsr_render_bwd)."""
 
-    def __init__(self):
+    def __init__(self, n=2):
         self.hip = ctypes.CDLL("libamdhip64.so.7")      # already mapped by torch: same runtime instance
-        self.pairs = {}
+        self.n = n                                      # events per record: 2 = (start, stop); 4 = (start, stop, behind dX, behind dW)
+        self.recs = {}
 
     def new(self):
         e = ctypes.c_void_p()
@@ -88,20 +92,36 @@ class HipEvents:
         return e
 
     def pair_for(self, stage):
-        p = (self.new(), self.new())
-        self.pairs.setdefault(stage, []).append(p)
-        return p[0], p[1]
+        p = tuple(self.new() for _ in range(self.n))
+        self.recs.setdefault(stage, []).append(p)
+        return p
+
+    def _ms(self, a, b):
+        t = ctypes.c_float()
+        return t.value if self.hip.hipEventElapsedTime(ctypes.byref(t), a, b) == 0 else None
 
     def summary(self):
+        """stage -> (mean ms start..stop, count)"""
         out = {}
-        for stage, pairs in self.pairs.items():
-            ms = []
-            for a, b in pairs:
-                t = ctypes.c_float()
-                if self.hip.hipEventElapsedTime(ctypes.byref(t), a, b) == 0:
-                    ms.append(t.value)
+        for stage, recs in self.recs.items():
+            ms = [v for v in (self._ms(r[0], r[1]) for r in recs) if v is not None]
             if ms:
                 out[stage] = (sum(ms) / len(ms), len(ms))
+        return out
+
+    def split(self):
+        """stage -> {"dx": ms, "dw": ms, "finalize": ms} (means; only records whose four events were all reached)"""
+        out = {}
+        for stage, recs in self.recs.items():
+            acc = []
+            for r in recs:
+                if len(r) < 4:
+                    continue
+                v = (self._ms(r[0], r[2]), self._ms(r[2], r[3]), self._ms(r[3], r[1]))
+                if all(x is not None for x in v):
+                    acc.append(v)
+            if acc:
+                out[stage] = {k: sum(a[i] for a in acc) / len(acc) for i, k in enumerate(("dx", "dw", "finalize"))}
         return out
 
 
@@ -379,7 +399,8 @@ def main():
     frames = [(c.to(dev), d.to(dev), col.to(dev)) for c, d, col in sc["frames"]]
     K = len(frames)
     params = list(dec.parameters())
-    ev = HipEvents()
+    ev = HipEvents(4)                       # backward: start, stop, behind dX, behind dW
+    ev_fwd = HipEvents(2)                   # forward: around the decoder-pass kernel
     ev_graph = HipEvents()                  # event pairs captured INTO the replayed graphs (no host launch gaps between the kernels)
     renderer.profile_events = ev.pair_for
     stages_cfg = ("middle", "fine", "color") if C["stages"] == "mix" else tuple(C["stages"])
@@ -422,6 +443,7 @@ def main():
             g.grad = None
         for p in params:
             p.grad = None
+        renderer.profile_fwd_events = ev_fwd.pair_for if timed else None
         if not timed:
             renderer.profile_events = None
         if tracking and not args.unfused:                         # Tracker.optimize_cam_in_batch (Tracker.py:87-125) as one autograd node
@@ -457,6 +479,7 @@ def main():
             loss = nsa.mapping_loss(renderer, grids, dec, frames, per_frame, stage, w_color=0.2, coarse_mapper=(stage == "coarse"))
             nsa.backward(loss)
         renderer.profile_events = ev.pair_for
+        renderer.profile_fwd_events = None
         return stage
 
     # Warm-up: eager iterations.  First untimed ones (code load, allocator, LDS attribute), then 5 per stage with HIP
@@ -613,6 +636,38 @@ def main():
                                if not (args.stepped_grads_only or tracking) else None,
                                "executed_note": "MFMA work the backward actually issues (dX + dW for every decoder -- the reference "
                                                 "autograd's semantics) over the same peak; `frac` counts only the necessary part"}
+        if dom is not None and "roofline" in res:
+            # the kernels of the dominant stage one by one (eager iterations behind a 1 ms wait, like `avg_kernel_ms`), and the whole
+            # iteration: necessary FLOP of forward + backward of the timed stage mix over the wall time of the timed region
+            pts = rays_rank * (32 if dom == "coarse" else 48)
+            ker = {}
+            f = ev_fwd.summary().get(dom)
+            if f:
+                ker["forward_pass"] = {"kernel": f"render_fwd_pass_kernel<{dom}>", "ms": round(f[0], 4), "frac": pts * FWD_MAC[dom] * 2 / (f[0] * 1e-3) / FP32_PEAK}
+            sp = ev.split().get(dom)
+            if sp and dom == "color" and not tracking:
+                dw_nec = DW_NEC_MAC[dom] if not args.stepped_grads_only else DW_NEC_MAC[dom]
+                ker["dx"] = {"kernel": "render_bwd_dx_kernel<color>", "ms": round(sp["dx"], 4),
+                             "frac": pts * (NEC_MAC[dom] - FWD_MAC[dom] - dw_nec) * 2 / (sp["dx"] * 1e-3) / FP32_PEAK,
+                             "executed_frac": pts * 3 * 15360 * 2 / (sp["dx"] * 1e-3) / FP32_PEAK}
+                ker["dw"] = {"kernel": "render_bwd_dw_kernel<color>", "ms": round(sp["dw"], 4),
+                             "frac": pts * dw_nec * 2 / (sp["dw"] * 1e-3) / FP32_PEAK,
+                             "executed_frac": pts * ((14336 if args.stepped_grads_only else 47104)) * 2 / (sp["dw"] * 1e-3) / FP32_PEAK}
+                ker["finalize"] = {"kernel": "bwd_finalize_kernel", "ms": round(sp["finalize"], 4)}
+            elif sp:
+                ker["dx"] = {"ms": round(sp["dx"], 4)}
+                ker["dw"] = {"ms": round(sp["dw"], 4)}
+                ker["finalize"] = {"ms": round(sp["finalize"], 4)}
+            if ker:
+                furthest = min((k for k in ker if "frac" in ker[k]), key=lambda k: ker[k]["frac"], default=None)
+                res["roofline"]["kernels"] = ker
+                res["roofline"]["furthest_from_peak"] = furthest
+            nst = {st_: stages.count(st_) for st_ in set(stages)}
+            flop_iter = sum(cnt * rays_rank * (32 if st_ == "coarse" else 48) * NEC_MAC[st_] * 2 for st_, cnt in nst.items()) / max(1, len(stages))
+            if not tracking:
+                res["roofline"]["iteration"] = {"necessary_flop_per_iteration": flop_iter, "ms": dt / args.steps * 1e3,
+                                                "frac": flop_iter / (dt / args.steps) / FP32_PEAK,
+                                                "note": "forward + backward necessary FLOP of the timed stage mix over the timed region's wall time per iteration"}
         if shard is not None:
             res["config"]["grad_exchange_MB_last_iter"] = round(shard.last_exchange_floats * 4 / 1e6, 2)
             res["rccl_ranks"] = world

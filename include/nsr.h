@@ -110,6 +110,8 @@ typedef struct nsr_render_args {
      * nsr_render_bwd, given the SAME pointer, loads them instead of re-running -- 288 GB of HBM traded for a quarter of the
      * backward's work.  Ignored in the coarse stage. */
     float *acts;
+    void *ev_pass_start;      /* ABI 6, optional hipEvent_t pair recorded on `stream` right before / after the decoder-pass kernel of */
+    void *ev_pass_stop;       /* a differentiated forward (the forward's dominant kernel); NULL = no timing                           */
     int32_t skip_masked;      /* ABI 6, with `keep`: 1 = rays with keep[r] == 0 are REMOVED from the batch like the reference's
                                  compaction does (src/Mapper.py:471-481, src/Tracker.py:95-104: `batch_rays_d[inside_mask]`): no
                                  decoder evaluation, outputs depth = var = rgb = 0, no loss term, no gradient.  Their slots of
@@ -142,6 +144,8 @@ typedef struct nsr_bwd_args {
                                  launch).  0 (default): d_depth / d_var / d_rgb are read as given -- a caller may mask or re-weight
                                  dl_* in place before the backward.  Only grad_scale is applied on top in either case. */
     int32_t pad_;
+    void *ev_dx_done;         /* ABI 6, optional hipEvent_t recorded behind the dX kernel / behind the dW kernel: with ev_start / ev_stop */
+    void *ev_dw_done;         /* they give the time of each kernel of the backward (dX | dW | finalize)                                 */
 } nsr_bwd_args;
 
 int nsr_version(void);

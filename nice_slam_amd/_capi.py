@@ -41,6 +41,7 @@ class NsrRenderArgs(C.Structure):
                 ("zvals", C.c_void_p),
                 ("gt_color", C.c_void_p), ("keep", C.c_void_p), ("loss", C.c_void_p), ("dl_depth", C.c_void_p), ("dl_rgb", C.c_void_p),
                 ("w_color", C.c_float), ("acts_masks_only", C.c_int32), ("acts", C.c_void_p),
+                ("ev_pass_start", C.c_void_p), ("ev_pass_stop", C.c_void_p),
                 ("skip_masked", C.c_int32), ("pad2_", C.c_int32)]
 
 
@@ -50,7 +51,8 @@ class NsrBwdArgs(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
                 ("max_blocks", C.c_int32), ("overwrite_dparams", C.c_int32),
                 ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p), ("grad_scale", C.c_void_p),
-                ("loss_grads_from_forward", C.c_int32), ("pad_", C.c_int32)]
+                ("loss_grads_from_forward", C.c_int32), ("pad_", C.c_int32),
+                ("ev_dx_done", C.c_void_p), ("ev_dw_done", C.c_void_p)]
 
 
 class NsrFrame(C.Structure):

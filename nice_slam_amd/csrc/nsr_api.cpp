@@ -258,6 +258,7 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
         }
 #undef NSR_DX
     }
+    if (b->ev_dx_done) nsr::rt_record(b->ev_dx_done, stream);
     if (any_params) {
         const int lds = nsr::dw_lds_bytes(P.stage >= NSR_STAGE_FINE ? NSR_FINE : NSR_MIDDLE);
         // the passes * nimg blocks (= partial images, the workspace's size) dealt over the decoders that want parameter gradients,
@@ -288,6 +289,7 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
             default: NSR_DW(3) break;
         }
 #undef NSR_DW
+        if (b->ev_dw_done) nsr::rt_record(b->ev_dw_done, stream);
         const int first = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE, last = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : P.stage;
         nsr::FinalParams R;
         R.stride = P.partial_stride; R.overwrite = b->overwrite_dparams ? 1 : 0;
@@ -391,7 +393,9 @@ int nsr_render_fwd(const nsr_render_args *a, void *stream) {
         const dim3 grid(P.pass_beg[3]), block(64 * waves);
 #define NSR_FWP(ST, SV)                                                                                      \
     if (int rc = launch_cfg(nsr::render_fwd_pass_kernel<ST, SV>, lds, "nsr_render_fwd(pass)")) return rc;    \
-    NSR_LAUNCH((nsr::render_fwd_pass_kernel<ST, SV>), grid, block, lds, stream, P);
+    if (a->ev_pass_start) nsr::rt_record(a->ev_pass_start, stream);                                          \
+    NSR_LAUNCH((nsr::render_fwd_pass_kernel<ST, SV>), grid, block, lds, stream, P);                          \
+    if (a->ev_pass_stop) nsr::rt_record(a->ev_pass_stop, stream);
         switch (P.stage) {
             case 0: NSR_FWP(0, true) NSR_LAUNCH(nsr::fwd_composite_kernel<0>, rgrid, rblock, rpb * 8, stream, P); break;
             case 1: NSR_FWP(1, true) NSR_LAUNCH(nsr::fwd_composite_kernel<1>, rgrid, rblock, rpb * 8, stream, P); break;

@@ -266,6 +266,8 @@ class _MappingLossFn(torch.autograd.Function):
         # the batch (Mapper.py:471-481, Tracker.py:95-104) -- not rendered at all unless Renderer.skip_masked_rays is off
         a.keep = keep.data_ptr()
         a.skip_masked = 1 if (renderer.skip_masked_rays and need_bwd) else 0
+        if need_bwd and renderer.profile_fwd_events is not None:
+            a.ev_pass_start, a.ev_pass_stop = renderer.profile_fwd_events(stage)
         acts = renderer._attach_acts(a, stage, N, S, dev, masks_only=not any(need_par)) if need_bwd else None
         if need_bwd and acts is None:
             raise _capi.NsrError("nice_slam_amd: the activation buffer of a %d-ray fused iteration does not fit (Renderer."

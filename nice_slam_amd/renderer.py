@@ -321,8 +321,11 @@ def render_backward(a, meta, kept, need, g_depth, g_var, g_rgb, zero_buf=None, g
         for s in slots:
             a.dec[_SLOT_IDX[s]].dparams = None
     b.max_blocks = renderer.bwd_max_blocks
-    if renderer.profile_events is not None:           # bench.py: hipEvent pair around the main backward kernel
-        b.ev_start, b.ev_stop = renderer.profile_events(stage)
+    if renderer.profile_events is not None:           # bench.py: hipEvents around the backward (start, stop[, behind dX, behind dW])
+        evs = renderer.profile_events(stage)
+        b.ev_start, b.ev_stop = evs[0], evs[1]
+        if len(evs) >= 4:
+            b.ev_dx_done, b.ev_dw_done = evs[2], evs[3]
     lib.check(lib.nsr_render_bwd(C.byref(a), C.byref(b), stream), "nsr_render_bwd")
 
     def publish():
@@ -390,7 +393,8 @@ class Renderer(object):
         # produces dW for every decoder in every stage although src/Mapper.py:335-341 only ever steps the colour
         # decoder (and the fine one when fix_fine is False); None = reference semantics (requires_grad decides).
         self.decoder_grads = None
-        self.profile_events = None              # optional callable(stage) -> (hipEvent_t start, hipEvent_t stop)
+        self.profile_events = None              # optional callable(stage) -> (hipEvent_t start, stop[, behind dX, behind dW]) for the backward
+        self.profile_fwd_events = None          # optional callable(stage) -> (hipEvent_t start, stop) around the forward's decoder-pass kernel
         self._gt_max = None                     # set by the multi-GPU wrapper: batch-global max(gt_depth)
         self._reduce_hook = None
         self._ws = {}                           # per-device backward workspace (not pickled)
@@ -400,6 +404,7 @@ class Renderer(object):
         d["_ws"] = {}
         d["_reduce_hook"] = None
         d["profile_events"] = None
+        d["profile_fwd_events"] = None
         return d
 
     def _workspace(self, nfloats: int, dev) -> torch.Tensor:

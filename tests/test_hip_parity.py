@@ -318,3 +318,65 @@ def test_eval_points_and_render_img():
     ro, rd = orc.pixel_rays(torch.arange(H * W), 0, H, 0, W, *sc["intr"][2:], sc["c2w"], sc["depth_img"], sc["color_img"])[:2]
     dref, uref, cref = orc.render_batch_ray(sc["grids"], sc["params"], rd, ro, "color", sc["depth_img"].reshape(-1), sc["bound"])
     assert rel_err(depth.reshape(-1), dref) < TOL and rel_err(col.reshape(-1, 3), cref) < TOL
+
+
+def test_eval_points_at_mesher_scale():
+    """Renderer.eval_points the way the Mesher calls it (src/utils/Mesher.py:281-319: a dense lattice over the padded bound,
+    stage 'fine' for the occupancy field, 'color' for the vertex colours): 2^20 = 1 048 576 points at Replica room0 shapes,
+    one launch, against the oracle evaluated in 65 536-point chunks (points outside the bound: occupancy 100)."""
+    from oracle import nice_oracle as orc
+    sc = make_scene(seed=31, n_rays=16, scene="replica_room0", fine_scale=1.0)
+    renderer, dec, grids = build_product(sc, "cuda:0")
+    b = sc["bound"]
+    n_ax = (128, 64, 128)                                            # 128 x 64 x 128 lattice, 5 % padding around the bound
+    ax = [torch.linspace(float(b[i, 0] - 0.05 * (b[i, 1] - b[i, 0])), float(b[i, 1] + 0.05 * (b[i, 1] - b[i, 0])), n_ax[i], dtype=torch.float64)
+          for i in range(3)]
+    pts = torch.stack(torch.meshgrid(*ax, indexing="ij"), -1).reshape(-1, 3)
+    assert pts.shape[0] == 1 << 20
+    for stage in ("fine", "color"):
+        got = renderer.eval_points(pts.to("cuda:0"), dec, grids, stage, "cuda:0").cpu()
+        ref = torch.empty_like(got)
+        with torch.no_grad():
+            for i in range(0, pts.shape[0], 65536):
+                ref[i:i + 65536] = orc.eval_points(pts[i:i + 65536], sc["grids"], sc["params"], orc.decoder_bounds(sc["bound"]), sc["bound"], stage)
+        outside = ((pts <= b[:, 0]) | (pts >= b[:, 1])).any(1)
+        assert 0.1 < float(outside.float().mean()) < 0.4 and bool((got[outside, 3] == 100.0).all())
+        assert rel_err(got[:, 3], ref[:, 3]) < TOL, stage
+        if stage == "color":
+            assert rel_err(got[:, :3], ref[:, :3]) < TOL, stage
+        # no point grossly off: per-point error of the occupancy against the oracle's own scale
+        err = (got[:, 3] - ref[:, 3]).abs()
+        assert float(err.max()) < 1e-3 * float(ref[~outside, 3].abs().max() + 1.0), (stage, float(err.max()))
+
+
+def test_render_img_full_frame_against_the_chunked_oracle():
+    """Renderer.render_img (src/utils/Renderer.py:200-255) on a full Replica frame, 680 x 1200 = 816 000 rays in nine batches of
+    ray_batch_size = 100 000 (the last one ragged; each batch takes max(gt_depth) over ITS rays, like the reference): depth,
+    uncertainty and colour of the pixels of three batches (the first, a middle one, the ragged last: 216 000 rays) against the
+    oracle evaluated batch by batch on the CPU (the whole frame would be 3 minutes of CPU time per run)."""
+    from oracle import nice_oracle as orc
+    sc = make_scene(seed=32, n_rays=16, scene="replica_room0", fine_scale=1.0, zero_frac=0.01)
+    renderer, dec, grids = build_product(sc, "cuda:0")
+    H, W = renderer.H, renderer.W
+    assert (H, W) == (680, 1200) and renderer.ray_batch_size == 100000
+    depth, unc, col = renderer.render_img(grids, dec, sc["c2w"].to("cuda:0"), "cuda:0", "color", gt_depth=sc["depth_img"].to("cuda:0"))
+    ro, rd = orc.pixel_rays(torch.arange(H * W), 0, H, 0, W, *sc["intr"][2:], sc["c2w"], sc["depth_img"], sc["color_img"])[:2]
+    gd = sc["depth_img"].reshape(-1)
+    torch.set_num_threads(min(16, __import__("os").cpu_count() or 1))
+    sel, dref, uref, cref = [], [], [], []
+    with torch.no_grad():
+        for i in (0, 400000, 800000):                               # batches 0, 4 and the ragged 8 (16 000 rays): ~40 s of CPU time
+            for j in range(i, min(i + 100000, H * W), 20000):        # (20 000-ray pieces of a batch share the BATCH's depth cap)
+                sl = slice(j, min(j + 20000, i + 100000, H * W))
+                cap = gd[i:i + 100000].max()
+                d_, u_, c_ = orc.render_batch_ray(sc["grids"], sc["params"], torch.cat([rd[sl], rd[:1]]), torch.cat([ro[sl], ro[:1]]), "color",
+                                                  torch.cat([gd[sl], cap.reshape(1)]), sc["bound"])
+                dref.append(d_[:-1]); uref.append(u_[:-1]); cref.append(c_[:-1]); sel.append(torch.arange(sl.start, sl.stop))
+    sel, dref, uref, cref = torch.cat(sel), torch.cat(dref), torch.cat(uref), torch.cat(cref)
+    assert sel.numel() == 216000
+    assert depth.shape == (H, W) and depth.dtype == torch.float64 and col.shape == (H, W, 3)
+    assert bool(torch.isfinite(depth).all()) and bool(torch.isfinite(col).all())
+    assert rel_err(depth.reshape(-1).cpu()[sel], dref) < TOL
+    assert rel_err(unc.reshape(-1).cpu()[sel], uref) < TOL
+    assert rel_err(col.reshape(-1, 3).cpu()[sel], cref) < TOL
+
