@@ -123,6 +123,31 @@ import threading
 restore_device = threading.local()      # .idx: the device common._stream() switched away from for the launch in flight
 
 
+class on_device:
+    """Device guard around an operation that makes SEVERAL library calls (a forward with its packing and window kernels, a
+    backward): the tensors' device is current from entry to exit -- for every launch, the per-device LDS-attribute cache and the
+    event records -- and the caller's device is restored on exit, exceptions included.  Inside the guard ``common._stream`` finds
+    the device already current and arms no restore of its own."""
+
+    def __init__(self, device):
+        self.idx = torch.device(device).index if device is not None else None
+        self.prev = None
+
+    def __enter__(self):
+        if self.idx is not None and torch.cuda.is_available():
+            cur = torch.cuda.current_device()
+            if cur != self.idx:
+                self.prev = cur
+                torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+            self.prev = None
+        return False
+
+
 class Lib:
     """A loaded libnsr with typed entry points; ``check`` turns error codes into exceptions."""
 

@@ -275,7 +275,8 @@ class NICE(nn.Module):
         lib = _capi.get_lib()
         for m in self.children():
             if isinstance(m, _FlatDecoder) and m.flat_params().is_cuda:
-                m.packed_params(lib, _stream(m.flat_params().device))
+                with _capi.on_device(m.flat_params().device):   # (a cached pack makes no library call: nothing else would restore the device)
+                    m.packed_params(lib, _stream(m.flat_params().device))
 
     def share_memory(self):                                  # src/NICE_SLAM.py:88-90
         for m in self.children():

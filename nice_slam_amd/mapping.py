@@ -133,6 +133,11 @@ def _launch_window(indices, K, n, crop, intr, frames, bound6, sbuf, keep, kmax_p
 class _WindowFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, *c2ws):
+        with _capi.on_device(meta[8]):
+            return _WindowFn._forward_impl(ctx, meta, *c2ws)
+
+    @staticmethod
+    def _forward_impl(ctx, meta, *c2ws):
         indices, K, n, crop, intr, depths, colors, bound, dev = meta
         N = K * n
         frames, hold = _frames_block(c2ws, depths, colors, dev)
@@ -207,6 +212,11 @@ class _MappingLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, meta, *tensors):
+        with _capi.on_device(meta[3][8]):
+            return _MappingLossFn._forward_impl(ctx, meta, *tensors)
+
+    @staticmethod
+    def _forward_impl(ctx, meta, *tensors):
         renderer, decoders, stage, wmeta, w_color, sharder, out, track = meta      # track: None | (handle_dynamic, use_color)
         indices, K, n, crop, intr, depths, colors, bound, dev = wmeta
         lib = _capi.get_lib()
@@ -294,6 +304,11 @@ class _MappingLossFn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_loss):
+        with _capi.on_device(g_loss.device):
+            return _MappingLossFn._backward_impl(ctx, g_loss)
+
+    @staticmethod
+    def _backward_impl(ctx, g_loss):
         if ctx.state is None:
             raise RuntimeError("nice_slam_amd: backward through mapping_loss / tracking_loss a second time is not supported (the "
                                "saved buffers are released after the first backward)")

@@ -328,10 +328,11 @@ class ShardedMapping:
             span_arr[i].ptr, span_arr[i].n = t.data_ptr(), t.numel()
         total = n_rows_total * 32 + sum(t.numel() for t in spans)
         buf = torch.empty((total,), dtype=torch.float32, device=dev)
-        stream = _stream(dev)
-        lib.check(lib.nsr_pack_rows(rows_arr, ng, span_arr, len(spans), buf.data_ptr(), 0, stream), "nsr_pack_rows")
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-        lib.check(lib.nsr_pack_rows(rows_arr, ng, span_arr, len(spans), buf.data_ptr(), 1, stream), "nsr_pack_rows")
+        with _capi.on_device(dev):                               # two launches + a collective on the gradients' device
+            stream = _stream(dev)
+            lib.check(lib.nsr_pack_rows(rows_arr, ng, span_arr, len(spans), buf.data_ptr(), 0, stream), "nsr_pack_rows")
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            lib.check(lib.nsr_pack_rows(rows_arr, ng, span_arr, len(spans), buf.data_ptr(), 1, stream), "nsr_pack_rows")
         floats = total
         for g in dense:                                          # grids without a mask: dense, in place (one more collective each)
             _, v, _ = _voxel_rows(g)

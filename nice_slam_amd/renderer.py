@@ -77,7 +77,7 @@ def eval_points_raw(p: torch.Tensor, decoders, c: Dict[str, torch.Tensor], stage
     lib = _capi.get_lib()
     _require_cuda(p, "eval_points: points")
     dev = p.device
-    with torch.no_grad():
+    with torch.no_grad(), _capi.on_device(dev):
         pts = p.detach().to(torch.float64).contiguous()
         grids = _prep_grids({k: v.detach() for k, v in c.items()}, stage, dev)
         stream = _stream(dev)
@@ -111,6 +111,11 @@ class _RenderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, meta, rays_o, rays_d, *tensors):
+        with _capi.on_device(rays_o.device):
+            return _RenderFn._forward_impl(ctx, meta, rays_o, rays_d, *tensors)
+
+    @staticmethod
+    def _forward_impl(ctx, meta, rays_o, rays_d, *tensors):
         renderer, decoders, stage, gt_depth, reduce_hook = meta
         lib = _capi.get_lib()
         slots = stage_slots(stage)
@@ -166,6 +171,11 @@ class _RenderFn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_depth, g_var, g_rgb):
+        with _capi.on_device(g_depth.device):
+            return _RenderFn._backward_impl(ctx, g_depth, g_var, g_rgb)
+
+    @staticmethod
+    def _backward_impl(ctx, g_depth, g_var, g_rgb):
         slots = stage_slots(ctx.meta[2])
         need = (ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3:3 + len(slots)],
                 ctx.needs_input_grad[3 + len(slots):3 + 2 * len(slots)])

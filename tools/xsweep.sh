@@ -21,6 +21,6 @@ for r in rows[:14]:
     print("   %-60s %5d %9.1f us %6.2f %%" % (r["Name"][:60], int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
 PY
   python -c "import json,sys; d=json.load(open('$D.json')); print('   value', round(d['value']), 'ms_per_step', round(d['ms_per_step'],4), d.get('kernel_ms'))" >> "$OUT/summary.txt" 2>&1
-  rm -rf "$D"
+  cp "$STATS" "$OUT/stats$i.csv" 2>/dev/null; rm -rf "$D"
 done
 cat "$OUT/summary.txt"
