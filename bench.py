@@ -614,13 +614,13 @@ def main():
             nec = pts * (NEC_MAC[dom] - FWD_MAC[dom]) * 2
             ach = nec / (ms * 1e-3)
             traffic, tsrc = None, None
-            tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")      # from a separate rocprofv3 --pmc run (tools/pmc_bench.sh)
+            tpath = os.path.join(ROOT, "profiles", "r04_traffic.json")      # from a separate rocprofv3 --pmc run (tools/pmc_bench.sh)
             if os.path.exists(tpath) and args.config == "1" and rays_rank == 1000 and dom == "color":
                 tall = json.load(open(tpath))                 # one entry per kernel: the backward = the sum over its kernels
                 ks = [k for k in tall if any(n_ in k for n_ in ("render_bwd_dx_kernel<3", "render_bwd_dw_kernel<3", "bwd_finalize", "comp_bwd"))]
                 if ks:
                     traffic = sum(tall[k]["hbm_bytes_per_launch"] for k in ks)
-                    tsrc = "profiles/r03_traffic.json (" + " + ".join(k.replace("nsr::", "") for k in ks) + "): " + tall[ks[0]].get("note", "")
+                    tsrc = "profiles/r04_traffic.json (" + " + ".join(k.replace("nsr::", "") for k in ks) + "): " + tall[ks[0]].get("note", "")
             res["roofline"] = {"bound": "mfma",
                                "kernel": f"render backward, stage {dom}: comp_bwd + render_bwd_dx_kernel + render_bwd_dw_kernel + "
                                          "bwd_finalize (split backward over saved activations)",
