@@ -86,8 +86,8 @@ typedef struct nsr_render_args {
     float *rgb;               /* [N][3] */
     float *raw;               /* [N][S][4] decoder output after the out-of-bound override, S = n_samples+n_surface;
                                  written by fwd, read by bwd.  May be NULL for a forward-only call.  */
-    double *zvals;            /* [N][S] sorted sample depths; optional: written by fwd when non-NULL, and when non-NULL in
-                                 bwd they are loaded instead of being recomputed by each decoder pass                  */
+    double *zvals;            /* [N][S] sorted sample depths, written by fwd when non-NULL; required (like acts and raw) by a call
+                                 that will be differentiated                                                            */
     /* --- fused mapping loss (src/Mapper.py:487-493), optional: all NULL / 0 for the plain renderer ------------------
      * fwd with loss != NULL adds   sum over rays r with keep[r] of  [gt_depth[r] > 0] |gt_depth[r] - depth[r]|   (gt_depth
      *                              as passed in this block, also in the coarse stage whose SAMPLING ignores it)
@@ -103,12 +103,12 @@ typedef struct nsr_render_args {
     float w_color;            /* cfg mapping.w_color_loss */
     int32_t acts_masks_only;  /* with `acts`: 1 = the backward will want no parameter gradients (tracking), the forward only
                                  writes the relu masks (1 of the 13 KB per tile and decoder); 0 = everything */
-    /* --- optional (ABI 3): saved decoder activations ---------------------------------------------------------------------
-     * NULL: nsr_render_bwd re-runs the forward of the decoder it differentiates (24 B/point of saved state).  Non-NULL
-     * (nsr_acts_floats(stage, n_rays, n_samples + n_surface) floats, device, uninitialised): nsr_render_fwd also writes the
-     * five hidden states and relu masks of every xyz decoder per sample point (704 B per point and decoder) and
-     * nsr_render_bwd, given the SAME pointer, loads them instead of re-running -- 288 GB of HBM traded for a quarter of the
-     * backward's work.  Ignored in the coarse stage. */
+    /* --- saved decoder activations + workspace of the split backward (ABI 3/4; required for a call that will be differentiated since
+     * ABI 6).  nsr_acts_floats(stage, n_rays, n_samples + n_surface) floats, device, uninitialised: nsr_render_fwd (given acts, zvals
+     * and raw) runs as sample placement -> decoder passes -> compositor and writes, per decoder pass and 16-point tile of the sample list,
+     * the five hidden states, the decoder's grid features and the relu masks (13 KB), the sample positions (fp64 and fp32) and, with the
+     * fused loss, d raw; nsr_render_bwd, given the SAME pointer, runs dX / dW / finalize over them.  NULL: forward only (one launch,
+     * nothing saved); nsr_render_bwd then fails. */
     float *acts;
     void *ev_pass_start;      /* ABI 6, optional hipEvent_t pair recorded on `stream` right before / after the decoder-pass kernel of */
     void *ev_pass_stop;       /* a differentiated forward (the forward's dominant kernel); NULL = no timing                           */
@@ -155,7 +155,7 @@ const char *nsr_last_error(void);
 int64_t nsr_param_count(int slot);
 /* number of floats of the packed operand stream for decoder slot `slot` */
 int64_t nsr_packed_count(int slot);
-/* size of nsr_render_args.acts in floats (0 for the coarse stage; -1 on bad arguments) */
+/* size of nsr_render_args.acts in floats (-1 on bad arguments) */
 int64_t nsr_acts_floats(int stage, int64_t n_rays, int n_samples_total);
 
 /* floats of scratch nsr_render_bwd needs for (stage, n_rays, max_blocks) */
