@@ -240,6 +240,25 @@ typedef struct nsr_adam_grid {
 int nsr_masked_adam_multi(const nsr_adam_grid *grids, int32_t n_grids, float beta1, float beta2, float eps,
                           int32_t zero_grad, float *scratch, void *stream);
 
+/* The dense rest of the callers' optimiser -- torch.optim.Adam over the decoder parameters and the camera tensors
+ * (src/Mapper.py:368-387,504; src/Tracker.py:214-222,127) -- for up to 4 flat fp32 spans (a decoder's parameter blob, an [n,7] pose
+ * tensor) in ONE launch pair with the step counts on the device: the same single-tensor Adam arithmetic as nsr_masked_adam_multi
+ * (lerp / addcmul / addcdiv order, bias corrections formed on the device in fp64; lr == 0 still updates the moments), every element of
+ * every span.  torch's capturable Adam takes ~10 launches per step for the same; together with nsr_masked_adam_multi a whole optimiser
+ * step of a mapping iteration is four launches.  zero_grad != 0 clears the gradient it read.  scratch: 8 device floats. */
+typedef struct nsr_adam_span {
+    float *p;
+    float *g;
+    float *m;
+    float *v;
+    int64_t n;
+    int32_t *step;            /* device counter of this span */
+    float lr;
+    int32_t pad_;
+} nsr_adam_span;
+int nsr_flat_adam(const nsr_adam_span *spans, int32_t n_spans, double beta1, double beta2, double eps, int32_t zero_grad, float *scratch,
+                  void *stream);     /* betas as doubles: 1 - beta is formed in fp64 and then rounded, like torch's `value=1 - beta2` */
+
 /* --- packing for the one-collective gradient exchange -------------------------------------------------------
  * Gathers (unpack = 0) the listed voxel rows (32 floats each, rows[] = voxel indices in [Z][Y][X] raster order) of up to 4
  * channels-last grid-gradient tensors and up to 4 flat spans into `packed` (rows of grid 0, grid 1, ..., then the spans), or

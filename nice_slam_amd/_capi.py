@@ -67,6 +67,11 @@ class NsrSpan(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("n", C.c_int64)]
 
 
+class NsrAdamSpan(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64), ("step", C.c_void_p),
+                ("lr", C.c_float), ("pad_", C.c_int32)]
+
+
 class NsrAdamGrid(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("voxel_mask", C.c_void_p),
                 ("n_voxels", C.c_int64), ("step", C.c_void_p), ("lr", C.c_float), ("pad_", C.c_int32)]
@@ -101,6 +106,7 @@ SYMBOLS = (
                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     ("nsr_masked_adam_multi", C.c_int, [C.POINTER(NsrAdamGrid), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32,
                                         C.c_void_p, C.c_void_p]),
+    ("nsr_flat_adam", C.c_int, [C.POINTER(NsrAdamSpan), C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_void_p]),
     ("nsr_pack_rows", C.c_int, [C.POINTER(NsrRows), C.c_int32, C.POINTER(NsrSpan), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     ("nsr_tracking_loss", C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -620,6 +620,30 @@ int nsr_masked_adam_multi(const nsr_adam_grid *grids, int32_t n_grids, float bet
     return finish("nsr_masked_adam_multi");
 }
 
+int nsr_flat_adam(const nsr_adam_span *spans, int32_t n_spans, double beta1, double beta2, double eps, int32_t zero_grad, float *scratch,
+                  void *stream) {
+    if (n_spans < 0 || n_spans > 4) return fail("nsr_flat_adam: 0..4 spans");
+    if (n_spans == 0) return 0;
+    if (!spans || !scratch) return fail("nsr_flat_adam: null pointer");
+    nsr::AdamMulti A;
+    std::memset(&A, 0, sizeof(A));
+    long long nmax = 0;
+    for (int i = 0; i < n_spans; ++i) {
+        const nsr_adam_span &g = spans[i];
+        if (!g.p || !g.g || !g.m || !g.v || !g.step || g.n < 0) return fail("nsr_flat_adam: bad span entry");
+        A.p[i] = g.p; A.g[i] = g.g; A.m[i] = g.m; A.v[i] = g.v; A.n_vox[i] = g.n; A.step[i] = g.step; A.lr[i] = g.lr;
+        nmax = g.n > nmax ? g.n : nmax;
+    }
+    A.n = n_spans; A.b1 = (float)beta1; A.b2 = (float)beta2; A.eps = (float)eps; A.zero_grad = zero_grad; A.scal = scratch;
+    A.omb1 = (float)(1.0 - beta1); A.omb2 = (float)(1.0 - beta2);
+    NSR_LAUNCH(nsr::adam_tick_kernel, dim3(1), dim3(64), 0, stream, A);
+    if (nmax > 0) {
+        const int tb = 256;
+        NSR_LAUNCH(nsr::flat_adam_kernel, dim3((unsigned)((nmax + tb - 1) / tb), n_spans), dim3(tb), 0, stream, A);
+    }
+    return finish("nsr_flat_adam");
+}
+
 int nsr_pack_rows(const nsr_rows *grids, int32_t n_grids, const nsr_span *spans, int32_t n_spans, float *packed,
                   int32_t unpack, void *stream) {
     if (n_grids < 0 || n_grids > 4 || n_spans < 0 || n_spans > 4) return fail("nsr_pack_rows: at most 4 grids and 4 spans");

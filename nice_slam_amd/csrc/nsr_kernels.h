@@ -1079,6 +1079,7 @@ struct AdamMulti {
     float lr[4];
     int n;
     float b1, b2, eps;
+    float omb1, omb2;         // 1 - beta (flat_adam_kernel: formed in fp64 by the host, like torch's python scalars)
     int zero_grad;
     float *scal;              // [4][2]: step_size, bias2_sqrt
 };
@@ -1110,6 +1111,24 @@ NSR_KERNEL void masked_adam_multi_kernel(const AdamMulti A) {
     st4(A.v[i] + o, v);
     st4(A.p[i] + o, p);
     if (A.zero_grad) st4(A.g[i] + o, F4{0.f, 0.f, 0.f, 0.f});
+}
+
+// Flat spans (decoder parameter blobs, pose tensors): the same arithmetic, one thread per element; span = blockIdx.y.  AdamMulti's
+// n_vox holds the element count, mask is unused.
+NSR_KERNEL void flat_adam_kernel(const AdamMulti A) {
+    const int i = bid_y();
+    const long long e = (long long)bid_x() * nthreads() + tid();
+    if (e >= A.n_vox[i]) return;
+    const float g = A.g[i][e];
+    float m = A.m[i][e], v = A.v[i][e], p = A.p[i][e];
+    const float step = A.scal[2 * i], rs2 = A.scal[2 * i + 1], omb1 = A.omb1, omb2 = A.omb2;
+    m = m + omb1 * (g - m);
+    v = v * A.b2 + (omb2 * g) * g;
+    p = p - step * (m / (sqrtf(v) / rs2 + A.eps));
+    A.m[i][e] = m;
+    A.v[i][e] = v;
+    A.p[i][e] = p;
+    if (A.zero_grad) A.g[i][e] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------

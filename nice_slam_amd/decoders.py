@@ -133,6 +133,12 @@ class _FlatDecoder(nn.Module):
             self._packed = (key, pk)
         return self._packed[1]
 
+    def mark_dirty(self):
+        """The flat blob was written behind autograd's back (nice_slam_amd.optim.FlatAdam: a kernel through the raw pointer, no
+        version counter moves): the next ``packed_params`` re-packs -- into the same buffer, so captured graphs stay valid."""
+        if self._packed is not None:
+            self._packed = (None, self._packed[1])
+
     def share_memory(self):
         self._cross_process = True
         return super().share_memory()

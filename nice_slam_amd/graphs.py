@@ -12,7 +12,10 @@ draw's state at stable addresses.  ``CapturedStep`` wraps the usual torch recipe
 What the closure must respect is torch's, not ours: no ``.item()`` / boolean-mask indexing inside (use
 ``nice_slam_amd.aabb_keep`` or the fused losses instead of the compaction of Mapper.py:471-481), optimisers with
 ``capturable=True`` (``MaskedGridAdam(capturable=True)`` keeps its step counts on the device), and fresh inputs are written INTO
-the closed-over tensors (``t.copy_(new)``) before each replay.
+the closed-over tensors (``t.copy_(new)``) before each replay.  The side-stream warm-up is not optional when a leaf tensor
+(a pose) receives its gradient through autograd's AccumulateGrad: a loss tensor of an EAGER iteration that is still alive keeps
+that node, the node remembers the eager stream, and the captured backward then drags that stream into the capture (on ROCm 7.2
+``hipStreamEndCapture`` dies on it instead of reporting unjoined work; measured, tests/perf/_segv_probe.py).
 """
 from __future__ import annotations
 

@@ -129,3 +129,86 @@ class MaskedGridAdam:
                                           None if mask is None else mask.data_ptr(), n_vox,
                                           float(lrs.get(k, 0.0)) / (1.0 - b1 ** t), b1, b2, self.eps, (1.0 - b2 ** t) ** 0.5,
                                           _stream(g.device)), "nsr_masked_adam")
+
+
+class FlatAdam:
+    """torch.optim.Adam (defaults: no weight decay, no amsgrad) for the dense rest of the callers' optimiser -- the decoder
+    parameters and the camera tensors (src/Mapper.py:368-387,504; src/Tracker.py:214-222,127) -- as ONE launch pair per step with
+    the step counts on the device (capturable: nothing on the host changes between replays of a captured iteration).
+
+    ``entries``: up to four of
+      * a decoder of ``nice_slam_amd.NICE`` (``decoders.color_decoder`` ...): its flat parameter blob is stepped with the flat gradient
+        blob the render backward writes (all of its parameters at once, like a param group holding ``decoder.parameters()``);
+      * a contiguous fp32 leaf tensor on the GPU (a pose tensor ``[7]`` / ``[n, 7]``): stepped with its ``.grad``.
+    ``lr``: one float or one per entry (host values: a captured step has them baked in, one captured graph per stage like the
+    reference's per-stage learning rates).  An entry without a gradient is skipped, like torch skips parameters whose ``.grad`` is
+    None; ``lr = 0`` still updates the moments.  Same numbers as torch.optim.Adam to rounding (tests/test_hip_callers.py)."""
+
+    def __init__(self, entries, lr=1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+        from .decoders import _FlatDecoder
+        self.entries = list(entries)
+        if not 1 <= len(self.entries) <= 4:
+            raise _capi.NsrError("FlatAdam: one to four entries (use several FlatAdam objects for more)")
+        self.betas, self.eps = betas, eps
+        self.lr = list(lr) if isinstance(lr, (list, tuple)) else [float(lr)] * len(self.entries)
+        self._is_dec = [isinstance(e, _FlatDecoder) for e in self.entries]
+        flats = [e.flat_params() if d else e for e, d in zip(self.entries, self._is_dec)]
+        for f in flats:
+            _require_cuda(f, "FlatAdam: parameter")
+            if f.dtype != torch.float32 or not f.is_contiguous():
+                raise _capi.NsrError("FlatAdam: contiguous fp32 tensors only")
+        dev = flats[0].device
+        self.state = [{"exp_avg": torch.zeros_like(f), "exp_avg_sq": torch.zeros_like(f)} for f in flats]
+        self._steps = torch.zeros((len(flats),), dtype=torch.int32, device=dev)
+        self._scratch = torch.zeros((8,), dtype=torch.float32, device=dev)
+
+    def reset_state(self):
+        """Zero moments and step counts in place (a fresh optimiser per frame, Tracker.py:214-222, without new buffers)."""
+        torch._foreach_zero_([t for st in self.state for t in st.values()] + [self._steps])
+
+    def _grad(self, i):
+        e = self.entries[i]
+        if not self._is_dec[i]:
+            return e.grad
+        tgt, mode = e.grad_target()
+        if mode == "accumulate":                     # every .grad is the cached view of the decoder's gradient blob
+            return tgt
+        if mode == "overwrite":                      # every .grad is None: nothing to step
+            return None
+        gs = [p.grad for p in e.parameters()]        # foreign gradient tensors: one concatenation (not capturable-stable)
+        if any(g is None for g in gs):
+            return None
+        return torch.cat([g.reshape(-1) for g in gs])
+
+    def step(self, lr=None, zero_grad: bool = False):
+        lib = _capi.get_lib()
+        lrs = self.lr if lr is None else (list(lr) if isinstance(lr, (list, tuple)) else [float(lr)] * len(self.entries))
+        arr = (_capi.NsrAdamSpan * len(self.entries))()
+        hold, n = [], 0
+        dev = self._steps.device
+        for i, e in enumerate(self.entries):
+            g = self._grad(i)
+            if g is None:
+                continue
+            p = e.flat_params() if self._is_dec[i] else e
+            g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.to(torch.float32).contiguous()
+            hold.append(g)
+            st = self.state[i]
+            arr[n].p, arr[n].g, arr[n].m, arr[n].v = p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            arr[n].n, arr[n].step, arr[n].lr = p.numel(), self._steps.data_ptr() + 4 * i, float(lrs[i])
+            n += 1
+            if self._is_dec[i]:
+                e.mark_dirty()                       # the packed operand streams are re-packed before the next render
+        if n:
+            with _capi.on_device(dev):
+                lib.check(lib.nsr_flat_adam(arr, n, self.betas[0], self.betas[1], self.eps, 1 if zero_grad else 0,
+                                            self._scratch.data_ptr(), _stream(dev)), "nsr_flat_adam")
+
+    def zero_grad(self, set_to_none: bool = True):
+        for e, d in zip(self.entries, self._is_dec):
+            for p in (e.parameters() if d else [e]):
+                if set_to_none:
+                    p.grad = None
+                elif p.grad is not None:
+                    p.grad.zero_()
+

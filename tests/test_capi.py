@@ -90,7 +90,8 @@ def test_ctypes_struct_fields_follow_the_header():
     from nice_slam_amd import _capi
     txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "nsr.h")).read(), flags=re.S)
     for cname, ctype in (("nsr_grid", _capi.NsrGrid), ("nsr_decoder", _capi.NsrDecoder),
-                         ("nsr_render_args", _capi.NsrRenderArgs), ("nsr_bwd_args", _capi.NsrBwdArgs)):
+                         ("nsr_render_args", _capi.NsrRenderArgs), ("nsr_bwd_args", _capi.NsrBwdArgs),
+                         ("nsr_adam_span", _capi.NsrAdamSpan), ("nsr_adam_grid", _capi.NsrAdamGrid)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), txt, re.S).group(1)
         names = []
         for stmt in body.split(";"):

@@ -814,3 +814,35 @@ def test_masked_rays_are_removed_from_the_batch(emu, stage, n_surface):
     for key, v in res[False][1].items():
         assert rel_err(res[True][1][key], v) < 1e-5, (stage, key)
 
+
+def test_flat_adam_is_torch_adam(emu):
+    """nsr_flat_adam (decoder blobs / pose tensors: the dense rest of the callers' optimiser) against torch.optim.Adam on the CPU:
+    three spans of odd lengths, five steps, one span at lr = 0 (moments still move), device-side step counts, zero_grad."""
+    from emu_harness import ptr
+    from nice_slam_amd import _capi
+    g = torch.Generator().manual_seed(11)
+    ns, lrs = [7, 15899, 35], [1e-3, 5e-3, 0.0]
+    ref = [torch.randn(n, generator=g).requires_grad_(True) for n in ns]
+    opt = torch.optim.Adam([{"params": [r], "lr": lr} for r, lr in zip(ref, lrs)])
+    P = [r.detach().numpy().copy() for r in ref]
+    M = [np.zeros_like(p) for p in P]; V = [np.zeros_like(p) for p in P]
+    steps, scratch = np.zeros(3, np.int32), np.zeros(8, np.float32)
+    for t in range(5):
+        G = [(torch.randn(n, generator=g) * (10.0 ** (t - 2))).numpy() for n in ns]
+        for r, gg in zip(ref, G):
+            r.grad = torch.from_numpy(gg.copy())
+        opt.step()
+        Gk = [gg.copy() for gg in G]
+        arr = (_capi.NsrAdamSpan * 3)()
+        for i in range(3):
+            arr[i].p, arr[i].g, arr[i].m, arr[i].v = P[i].ctypes.data, Gk[i].ctypes.data, M[i].ctypes.data, V[i].ctypes.data
+            arr[i].n, arr[i].step, arr[i].lr = ns[i], steps.ctypes.data + 4 * i, lrs[i]
+        emu.check(emu.nsr_flat_adam(arr, 3, 0.9, 0.999, 1e-8, 1 if t == 4 else 0, ptr(scratch), None))
+        for i in range(3):
+            assert np.array_equal(Gk[i], G[i]) if t < 4 else not Gk[i].any()
+    assert steps.tolist() == [5, 5, 5]
+    for i in range(3):
+        assert rel_err(P[i], ref[i].detach().numpy()) < 2e-6, i
+        assert rel_err(M[i], opt.state[ref[i]]["exp_avg"].numpy()) < 2e-6 and rel_err(V[i], opt.state[ref[i]]["exp_avg_sq"].numpy()) < 2e-6
+    assert np.array_equal(P[2], ref[2].detach().numpy())            # lr = 0: parameters untouched, moments moved
+

@@ -313,3 +313,79 @@ def test_captured_iteration_replays_like_eager():
             assert rel_err(g1[k], g0[k]) < 1e-5, k
         for k in p0:
             assert rel_err(p1[k], p0[k]) < 2e-5, k
+
+
+def test_flat_adam_steps_decoder_and_poses_like_torch_adam():
+    """nice_slam_amd.FlatAdam (nsr_flat_adam: one launch pair for the decoder blob + the pose tensors, step counts on the device)
+    against torch.optim.Adam on copies (Mapper.py:368-387,504; Tracker.py:214-222,127): six colour-stage iterations with real
+    render gradients, eager and replayed from a hipGraph; the decoder's packed operand streams follow the stepped parameters
+    (mark_dirty -> re-pack into the same buffer), so the NEXT render agrees too."""
+    import copy
+    import nice_slam_amd as nsa
+    sc = make_scene(seed=12, n_rays=256, small=True)
+    renderer, decA, grids = build_product(sc, DEV)
+    decB = copy.deepcopy(decA)
+    H, W, fx, fy, cx, cy = sc["intr"]
+    g = torch.Generator().manual_seed(4)
+    camA = torch.tensor([[1.0, 0.02, -0.01, 0.03, 0.1, -0.2, 0.05], [0.98, -0.03, 0.02, 0.01, -0.1, 0.1, 0.0]], device=DEV).requires_grad_(True)
+    camB = camA.detach().clone().requires_grad_(True)
+    rays_o = sc["rays_o"].to(DEV); rays_d = sc["rays_d"].to(DEV); gt = sc["gt_depth"].to(DEV)
+    tgt = torch.rand(rays_o.shape[0], 3, generator=g).to(DEV)
+
+    def loss_of(dec, cam):
+        # the poses enter through the ray origins (a translation of the camera centre): gradients for both entries
+        o = rays_o + nsa.get_camera_from_tensor(cam)[0, :3, 3] * 1e-2 + nsa.get_camera_from_tensor(cam)[1, :3, 3] * 1e-2
+        d, u, c = renderer.render_batch_ray(grids, dec, rays_d, o, DEV, "color", gt_depth=gt)
+        return (d - gt).abs().sum() + 0.2 * (c - tgt).abs().sum()
+
+    lrs = [5e-3, 1e-3]
+    flat = nsa.FlatAdam([decA.color_decoder, camA], lr=lrs)
+    ref = torch.optim.Adam([{"params": list(decB.color_decoder.parameters()), "lr": lrs[0]}, {"params": [camB], "lr": lrs[1]}])
+
+    def iter_flat():
+        flat.zero_grad(set_to_none=True)
+        loss = loss_of(decA, camA)
+        loss.backward()
+        flat.step()
+        return loss
+
+    def iter_ref():
+        ref.zero_grad(set_to_none=True)
+        lb = loss_of(decB, camB)
+        lb.backward()
+        ref.step()
+        return float(lb)
+
+    for it in range(2):                                  # eager
+        la, lb = float(iter_flat()), iter_ref()
+        assert abs(la - lb) < 2e-4 * abs(lb), it
+    # torch's capture recipe (warm-up on a side stream: an AccumulateGrad node of the pose tensor that survives from an eager
+    # iteration on the default stream would pull that stream into the capture); the warm-up EXECUTES one iteration
+    step = nsa.graphs.CapturedStep(iter_flat, warmup=1)
+    iter_ref()
+    for it in range(3):                                  # recording executed nothing: three replays
+        la, lb = float(step()), iter_ref()
+        assert abs(la - lb) < 5e-4 * abs(lb), it
+    assert flat._steps.tolist() == [6, 6]
+    fa, fb = decA.color_decoder.flat_params(), torch.cat([p.detach().reshape(-1) for p in decB.color_decoder.parameters()])
+    # Adam turns rounding-level gradient differences of near-zero components into lr-sized steps: the bulk must agree, and every
+    # element to a few steps' worth
+    diff = (fa - fb).abs()
+    assert float(diff.max()) < 6 * lrs[0] and float((diff > 1e-4).float().mean()) < 0.02
+    assert float((camA - camB).abs().max()) < 6 * lrs[1]
+    with torch.no_grad():                                # the re-pack follows the kernel-written blob
+        decB.color_decoder.load_state_dict(decA.color_decoder.state_dict())
+        la, lb = loss_of(decA, camA), loss_of(decB, camA)
+    assert abs(float(la) - float(lb)) < 1e-5 * abs(float(lb))
+    # exactness on identical gradients: both optimisers fed the same tensors
+    x = torch.randn(1001, device=DEV).requires_grad_(True); y = x.detach().clone().requires_grad_(True)
+    fo, to = nsa.FlatAdam([x], lr=3e-3), torch.optim.Adam([y], lr=3e-3)
+    for it in range(4):
+        gr = torch.randn(1001, device=DEV) * 10.0 ** (it - 2)
+        x.grad, y.grad = gr.clone(), gr.clone()
+        fo.step(zero_grad=(it == 3)); to.step()
+    assert rel_err(x.detach().cpu().numpy(), y.detach().cpu().numpy()) < 2e-6
+    assert rel_err(fo.state[0]["exp_avg_sq"].cpu().numpy(), to.state[y]["exp_avg_sq"].cpu().numpy()) < 2e-6
+    assert not x.grad.any()
+    fo.reset_state()
+    assert int(fo._steps[0]) == 0 and not fo.state[0]["exp_avg"].any()

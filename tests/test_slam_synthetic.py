@@ -84,3 +84,24 @@ def test_miniature_slam_run_tracks():
     assert np.isfinite(tr["ate"]["rmse"]) and tr["ate"]["rmse"] < 0.025                  # 1 cm in the pilot run
     assert tr["ate"]["rmse"] < 0.7 * mm["ate"]["rmse"]                                   # pilot: 0.97 cm vs 3.5 cm
     assert tr["raw_translation_error_cm"]["mean"] < mm["raw_translation_error_cm"]["mean"]
+
+
+def test_host_quaternion_is_scipys():
+    """tools/slam_synthetic._cam_np (the fused loop's host-side get_tensor_from_camera, common.py:179-201) against scipy over
+    rotations that visit all four branches; _pose_np inverts it."""
+    from scipy.spatial.transform import Rotation
+    import slam_synthetic as ss
+    rng = np.random.RandomState(5)
+    seen = set()
+    for k in range(400):
+        R = Rotation.from_rotvec(rng.randn(3) * (0.05 if k % 2 else 2.5)).as_matrix()
+        t = R[0, 0] + R[1, 1] + R[2, 2]
+        seen.add(0 if t > 0 else 1 + int(np.argmax(np.diag(R))))
+        m = np.eye(4); m[:3, :3] = R; m[:3, 3] = rng.randn(3)
+        cam = ss._cam_np(m).numpy().astype(np.float64)
+        x, y, z, w = Rotation.from_matrix(R).as_quat()
+        ref = np.array([w, x, y, z])
+        assert min(np.abs(cam[:4] - ref).max(), np.abs(cam[:4] + ref).max()) < 1e-6
+        assert np.abs(ss._pose_np(cam).numpy() - m).max() < 1e-5
+        assert np.abs(ss._inv44(torch.from_numpy(m)).numpy() @ m - np.eye(4)).max() < 1e-5
+    assert seen == {0, 1, 2, 3}

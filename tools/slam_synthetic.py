@@ -26,6 +26,7 @@ oracle as the renderer (test infrastructure); ``ProductOps`` is the nice_slam_am
 from __future__ import annotations
 
 import argparse
+import math
 import json
 import os
 import sys
@@ -79,6 +80,28 @@ def get_tensor_from_camera(c2w: torch.Tensor) -> torch.Tensor:
     return torch.tensor([w, x, y, z, m[0, 3], m[1, 3], m[2, 3]], dtype=torch.float32, device=c2w.device)
 
 
+def _cam_np(c2w) -> torch.Tensor:
+    """get_tensor_from_camera for a pose on the host without scipy's object machinery (Shepperd's branches; the same quaternion
+    up to sign, tests/test_slam_synthetic.py) -> 7 floats on the host."""
+    m = np.asarray(c2w, dtype=np.float64)
+    r00, r11, r22 = m[0, 0], m[1, 1], m[2, 2]
+    t = r00 + r11 + r22
+    if t > 0.0:
+        s = 2.0 * math.sqrt(t + 1.0)
+        q = (0.25 * s, (m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s)
+    elif r00 > r11 and r00 > r22:
+        s = 2.0 * math.sqrt(1.0 + r00 - r11 - r22)
+        q = ((m[2, 1] - m[1, 2]) / s, 0.25 * s, (m[0, 1] + m[1, 0]) / s, (m[0, 2] + m[2, 0]) / s)
+    elif r11 > r22:
+        s = 2.0 * math.sqrt(1.0 + r11 - r00 - r22)
+        q = ((m[0, 2] - m[2, 0]) / s, (m[0, 1] + m[1, 0]) / s, 0.25 * s, (m[1, 2] + m[2, 1]) / s)
+    else:
+        s = 2.0 * math.sqrt(1.0 + r22 - r00 - r11)
+        q = ((m[1, 0] - m[0, 1]) / s, (m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s)
+    n = math.sqrt(sum(v * v for v in q))
+    return torch.tensor([q[0] / n, q[1] / n, q[2] / n, q[3] / n, m[0, 3], m[1, 3], m[2, 3]], dtype=torch.float32)
+
+
 def _pose_np(t7) -> torch.Tensor:
     """get_camera_from_tensor + to44 for a pose on the host, in numpy (one frame's result; common.py:137-176)."""
     q = np.asarray(t7[:4], dtype=np.float64)
@@ -90,6 +113,12 @@ def _pose_np(t7) -> torch.Tensor:
                  [s * (x * z - y * w), s * (y * z + x * w), 1 - s * (x * x + y * y)]]
     m[:3, 3] = t7[4:7]
     return torch.from_numpy(m.astype(np.float32))
+
+
+def _inv44(c2w: torch.Tensor) -> torch.Tensor:
+    """Inverse of a 4x4 pose on the HOST in numpy (what Mapper.py:196-197 does; torch.inverse on the GPU is a rocSOLVER call with
+    a host synchronisation, measured at up to 0.9 s per call on some boxes) -> fp32 tensor on the host."""
+    return torch.from_numpy(np.linalg.inv(to44(c2w.detach()).cpu().double().numpy()).astype(np.float32))
 
 
 def to44(c2w: torch.Tensor) -> torch.Tensor:
@@ -204,7 +233,8 @@ class ProductOps:
             self.decoders_track = copy.deepcopy(self.decoders)
             for p in self.decoders_track.parameters():
                 p.requires_grad_(False)                         # nothing steps them; the reference leaves requires_grad on and discards the grads
-            return
+            self._track_copy_version = None                     # ... and run the refresh once now: the first multi-tensor copy
+                                                                # loads its code object (~40-90 ms, measured), set-up like the capture
         if getattr(self, "_track_copy_version", None) == getattr(self, "map_version", 0):
             return                                              # the mapper did not run since the last refresh
         self._track_copy_version = getattr(self, "map_version", 0)
@@ -312,16 +342,14 @@ class MiniSLAM:
                              "hist": torch.zeros((n_it, 8), dtype=torch.float32, device=self.device),    # loss | pose per iteration
                              "host": torch.zeros(7, dtype=torch.float32).pin_memory(),
                              "hist_host": torch.zeros((n_it, 8), dtype=torch.float32).pin_memory(), "graph": None}
-            ft["opt"] = torch.optim.Adam([ft["cam"]], lr=tc["lr"], capturable=True)
+            ft["opt"] = nsa.FlatAdam([ft["cam"]], lr=tc["lr"])    # Adam of the pose: one launch pair, step count on the device
         cam, opt = ft["cam"], ft["opt"]
 
         def reset():
             ft["host"].copy_(init_cam)
             with torch.no_grad():
                 cam.copy_(ft["host"], non_blocking=True); ft["depth"].copy_(depth); ft["color"].copy_(color); ft["i"].zero_()
-                st = [v for s in opt.state.values() for v in s.values() if torch.is_tensor(v)]
-                if st:
-                    torch._foreach_zero_(st)                    # a fresh optimiser per frame (Tracker.py:214-222)
+                opt.reset_state()                               # a fresh optimiser per frame (Tracker.py:214-222)
 
         def iteration():
             opt.zero_grad(set_to_none=True)
@@ -335,7 +363,9 @@ class MiniSLAM:
                 ft["hist"].index_copy_(0, ft["i"], torch.cat([loss.detach().reshape(1).float(), cam.detach()]).reshape(1, 8))
                 ft["i"] += 1
 
+        t_r = time.perf_counter()
         reset()
+        self.timers["tracking_reset_s"] = self.timers.get("tracking_reset_s", 0.0) + time.perf_counter() - t_r   # host: frame hand-over
         if ft["graph"] is None:                                 # once per run: an eager iteration (optimiser state, code load), the
             iteration()                                         # capture; timed apart (timers["tracking_capture_s"])
             torch.cuda.synchronize()
@@ -345,7 +375,7 @@ class MiniSLAM:
                     iteration()
             reset()
             torch.cuda.synchronize()
-            self.timers["tracking_capture_s"] = time.perf_counter() - t_cap
+            self.timers["tracking_capture_s"] += time.perf_counter() - t_cap
         tp = self.timers
         t_a = time.perf_counter()
         ft["graph"].replay()
@@ -362,17 +392,27 @@ class MiniSLAM:
 
     # -- Tracker.run, one frame (Tracker.py:176-256)
     def track(self, idx, color, depth):
-        tc = self.cfg["tracking"]
+        tc, t_in = self.cfg["tracking"], time.perf_counter()
         pdev = torch.device("cpu") if getattr(self.ops, "fused", False) else self.device    # 4x4 pose algebra: on the host when
         pre = self.est[idx - 1].to(pdev).float()                                             # the iterations are graph replays
         if tc["const_speed_assumption"] and idx - 2 >= 0:
-            delta = pre @ self.est[idx - 2].to(pdev).float().inverse()
+            delta = pre @ _inv44(self.est[idx - 2]).to(pdev)         # (fused: self.est lives on the host, no copies here)
             init = delta @ pre
         else:
             init = pre
         if getattr(self.ops, "fused", False) and tc["iters"] > 0:
+            tp, t_a = self.timers, time.perf_counter()
+            cam0 = _cam_np(init.numpy())
+            t_b = time.perf_counter()
+            first = not hasattr(self.ops, "c_track")
             self.ops.update_tracker_copy()                       # Tracker.update_para_from_mapping (Tracker.py:130-142)
-            best, self.last_track_loss = self._track_fused(get_tensor_from_camera(init), color, depth)
+            t_c = time.perf_counter()
+            if first:                                            # the first call ALLOCATES the tracker's copy (deepcopy of the decoders):
+                tp["tracking_capture_s"] += t_c - t_b            # one-time set-up, reported with the capture
+                t_b = t_c
+            best, self.last_track_loss = self._track_fused(cam0, color, depth)
+            tp["tracking_pose_s"] = tp.get("tracking_pose_s", 0.0) + (t_b - t_a) + (t_a - t_in)    # host: motion model, quaternion
+            tp["tracking_refresh_s"] = tp.get("tracking_refresh_s", 0.0) + t_c - t_b               # host: launching the map copy
             return _pose_np(best), init                          # 4x4 on the host
         cam = get_tensor_from_camera(init.detach()).to(self.device).requires_grad_(True)
         opt = torch.optim.Adam([cam], lr=tc["lr"])
@@ -396,7 +436,7 @@ class MiniSLAM:
         K = torch.tensor([[self.seq.fx, 0.0, self.seq.cx], [0.0, self.seq.fy, self.seq.cy], [0.0, 0.0, 1.0]], device=self.device)
         out = []
         for kid, kf in enumerate(keyframes):
-            w2c = torch.inverse(to44(kf["est_c2w"].to(self.device).float()))
+            w2c = _inv44(kf["est_c2w"]).to(self.device)
             cam = pts @ w2c[:3, :3].T + w2c[:3, 3]
             cam = cam * torch.tensor([-1.0, 1.0, 1.0], device=self.device)
             uv = cam @ K.T
@@ -502,7 +542,6 @@ class MiniSLAM:
         mc, ops, nsa = self.cfg["mapping"], self.ops, self.ops.nsa
         keys = ("grid_middle", "grid_fine", "grid_color")
         gopt = nsa.MaskedGridAdam({k: ops.c[k] for k in keys}, masks, capturable=True)
-        groups = [{"params": ops.color_decoder_params(), "lr": 0.0}]
         cam_all, cam_of = None, {}
         if BA:                                                           # every optimised pose is a row of ONE [n,7] parameter (Adam is
             rows = []                                                    # elementwise: same update as the reference's per-tensor list)
@@ -510,10 +549,11 @@ class MiniSLAM:
                 if f != oldest:
                     c2w = self.keyframe_dict[f]["est_c2w"] if f != -1 else cur_c2w
                     cam_of[f] = len(rows)
-                    rows.append(get_tensor_from_camera(c2w.to(self.device)))
-            cam_all = torch.stack(rows).requires_grad_(True)
-            groups.append({"params": [cam_all], "lr": 0.0})
-        opt = torch.optim.Adam(groups, capturable=True, foreach=True)
+                    rows.append(_cam_np(c2w.detach().cpu().numpy()))
+            cam_all = torch.stack(rows).to(self.device).requires_grad_(True)     # one H2D copy for the window's poses
+        # the dense rest of the reference's optimiser (decoder parameters + pose tensors, Mapper.py:368-387): one launch pair
+        opt = nsa.FlatAdam([ops.decoders.color_decoder] + ([cam_all] if BA else []), lr=0.0)
+        lrs = [0.0, 0.0]
         data = []
         for f in frames:
             if f != -1:
@@ -530,7 +570,7 @@ class MiniSLAM:
             fr = [(poses[cam_of[f]] if f in cam_of else c2w, d, c) for f, d, c, c2w in data]
             loss = nsa.mapping_loss(ops.renderer, ops.c, ops.decoders, fr, pix, stage, w_color=mc["w_color_loss"])
             nsa.backward(loss)
-            opt.step()
+            opt.step(lr=lrs[:len(opt.entries)])
             st = mc["stage"][stage]
             with torch.no_grad():
                 gopt.step({"grid_middle": st["middle_lr"] * lr_factor, "grid_fine": st["fine_lr"] * lr_factor,
@@ -542,9 +582,8 @@ class MiniSLAM:
         for stage, cnt in (("middle", n_mid), ("fine", n_fine), ("color", n_iters - n_mid - n_fine)):
             if cnt <= 0:
                 continue
-            opt.param_groups[0]["lr"] = mc["stage"][stage]["decoders_lr"] * lr_factor
-            if BA and stage == "color":
-                opt.param_groups[1]["lr"] = mc["BA_cam_lr"]
+            lrs[0] = mc["stage"][stage]["decoders_lr"] * lr_factor
+            lrs[1] = mc["BA_cam_lr"] if (BA and stage == "color") else 0.0
             iteration(stage)                                              # eager: also initialises optimiser state
             if cnt > 3:
                 torch.cuda.synchronize()
@@ -560,11 +599,12 @@ class MiniSLAM:
             self.counters["mapping_iters"] += cnt
             self.counters["mapping_rays"] += cnt * pix * len(frames)
         self.last_map_loss = float(loss_buf.item())                      # the only host read of the call
-        if BA:                                                             # Mapper.py:527-541
+        if BA:                                                             # Mapper.py:527-541; one D2H copy of all poses, 4x4s on the host
+            cams = cam_all.detach().cpu().numpy()
             for f in frames:
                 if f in cam_of and f != -1:
-                    self.keyframe_dict[f]["est_c2w"] = to44(get_camera_from_tensor(cam_all[cam_of[f]].detach())).clone()
-            return to44(get_camera_from_tensor(cam_all[cam_of[-1]].detach())).clone()
+                    self.keyframe_dict[f]["est_c2w"] = _pose_np(cams[cam_of[f]])
+            return _pose_np(cams[cam_of[-1]])
         return None
 
     # -- the coarse mapper's optimize_map (Mapper.py:230-545 with coarse_mapper=True): 'global' keyframe selection (:79-80,
@@ -626,7 +666,7 @@ class MiniSLAM:
                 torch.cuda.synchronize()
             t0 = time.perf_counter()
             if idx == 0:
-                self.est[0] = gt_c2w.clone()
+                self.est[0] = gt_c2w.cpu() if getattr(self.ops, "fused", False) else gt_c2w.clone()
             else:
                 c2w, _ = self.track(idx, color, depth)
                 self.est[idx] = c2w.detach()
@@ -645,7 +685,7 @@ class MiniSLAM:
                                         mc["lr_first_factor"] if first else mc["lr_factor"], idx, color, depth, cur)
                 self.ops.map_version = getattr(self.ops, "map_version", 0) + 1
                 if new is not None:
-                    self.est[idx] = new.detach()
+                    self.est[idx] = new.detach()                     # (fused: already on the host)
                 if self.device.type == "cuda":
                     torch.cuda.synchronize()
                 t2 = time.perf_counter()
