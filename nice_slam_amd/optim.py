@@ -149,8 +149,8 @@ class FlatAdam:
         self.entries = list(entries)
         if not 1 <= len(self.entries) <= 4:
             raise _capi.NsrError("FlatAdam: one to four entries (use several FlatAdam objects for more)")
-        self.betas, self.eps = betas, eps
-        self.lr = list(lr) if isinstance(lr, (list, tuple)) else [float(lr)] * len(self.entries)
+        self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
+        self.lr = self._lrs(lr)
         self._is_dec = [isinstance(e, _FlatDecoder) for e in self.entries]
         flats = [e.flat_params() if d else e for e, d in zip(self.entries, self._is_dec)]
         for f in flats:
@@ -158,9 +158,18 @@ class FlatAdam:
             if f.dtype != torch.float32 or not f.is_contiguous():
                 raise _capi.NsrError("FlatAdam: contiguous fp32 tensors only")
         dev = flats[0].device
+        if any(f.device != dev for f in flats):
+            raise _capi.NsrError("FlatAdam: all entries must live on one device")
+        self._ptrs = [f.data_ptr() for f in flats]
         self.state = [{"exp_avg": torch.zeros_like(f), "exp_avg_sq": torch.zeros_like(f)} for f in flats]
         self._steps = torch.zeros((len(flats),), dtype=torch.int32, device=dev)
         self._scratch = torch.zeros((8,), dtype=torch.float32, device=dev)
+
+    def _lrs(self, lr):
+        lrs = [float(v) for v in lr] if isinstance(lr, (list, tuple)) else [float(lr)] * len(self.entries)
+        if len(lrs) != len(self.entries):
+            raise _capi.NsrError("FlatAdam: %d learning rates for %d entries" % (len(lrs), len(self.entries)))
+        return lrs
 
     def reset_state(self):
         """Zero moments and step counts in place (a fresh optimiser per frame, Tracker.py:214-222, without new buffers)."""
@@ -182,7 +191,7 @@ class FlatAdam:
 
     def step(self, lr=None, zero_grad: bool = False):
         lib = _capi.get_lib()
-        lrs = self.lr if lr is None else (list(lr) if isinstance(lr, (list, tuple)) else [float(lr)] * len(self.entries))
+        lrs = self.lr if lr is None else self._lrs(lr)
         arr = (_capi.NsrAdamSpan * len(self.entries))()
         hold, n = [], 0
         dev = self._steps.device
@@ -191,6 +200,11 @@ class FlatAdam:
             if g is None:
                 continue
             p = e.flat_params() if self._is_dec[i] else e
+            if g.device != p.device or g.numel() != p.numel():
+                raise _capi.NsrError("FlatAdam: gradient of entry %d does not match its parameter (device / size)" % i)
+            if p.data_ptr() != self._ptrs[i]:
+                raise _capi.NsrError("FlatAdam: the storage of entry %d moved since the optimiser was built (.to() / .data = ...): "
+                                     "build a new FlatAdam" % i)
             g = g if (g.dtype == torch.float32 and g.is_contiguous()) else g.to(torch.float32).contiguous()
             hold.append(g)
             st = self.state[i]

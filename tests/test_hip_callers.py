@@ -389,3 +389,15 @@ def test_flat_adam_steps_decoder_and_poses_like_torch_adam():
     assert not x.grad.any()
     fo.reset_state()
     assert int(fo._steps[0]) == 0 and not fo.state[0]["exp_avg"].any()
+    from nice_slam_amd._capi import NsrError
+    # loud failures: wrong number of learning rates, a parameter whose storage was replaced, CPU tensors, more than four entries
+    with pytest.raises(NsrError):
+        fo.step(lr=[1e-3, 1e-3])
+    x.data = x.data.clone()
+    x.grad = torch.ones_like(x)
+    with pytest.raises(NsrError):
+        fo.step()
+    with pytest.raises(NsrError):
+        nsa.FlatAdam([torch.zeros(3, requires_grad=True)])
+    with pytest.raises(NsrError):
+        nsa.FlatAdam([torch.zeros(3, device=DEV) for _ in range(5)])
