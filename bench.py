@@ -31,9 +31,10 @@ HBM_PEAK = 8.0e12
 # necessary / executed MAC per sample point, SURVEY §8(d)
 FWD_MAC = {"coarse": 6176, "middle": 15479, "fine": 36078, "color": 51653}
 NEC_MAC = {"coarse": 12352, "middle": 24727, "fine": 59694, "color": 106140}          # fwd + bwd, what the optimiser needs
-# MACs per sample point a re-run backward would issue (decoder forward + dX + dW of every decoder; SQ_INSTS_VALU_MFMA_MOPS_F32
-# x 512 FLOP of round 2's kernel, profiles/r02_pmc_bench_kernels.txt; coarse: 3 x forward); the split backward issues this minus
-# the forward (FWD_MAC), which is what `executed_frac` below uses
+# MACs per sample point of decoder forward + dX + dW of every decoder (SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 FLOP, first measured on
+# round 2's kernel that ran all three, profiles/r02_pmc_bench_kernels.txt; coarse: 3 x forward); the split backward issues this minus
+# the forward (FWD_MAC) -- 7.6e6 MOPS per colour-stage dX launch in profiles/r04_pmc_bench_kernels.txt agree -- which is what
+# `executed_frac` below uses
 # of the backward's necessary MACs: the dW part = the weights of the decoder the mapper's optimiser steps in that stage (colour stage: the
 # colour decoder, 32x96 + 3 x 32x32 + 32x128 + 5 x 32x32 + 3x32 = 15 456); the rest is dX (gradients to the stepped grids through all decoders)
 DW_NEC_MAC = {"coarse": 0, "middle": 0, "fine": 0, "color": 15456}

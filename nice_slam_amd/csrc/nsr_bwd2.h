@@ -1,7 +1,7 @@
 // nsr_bwd2.h -- split backward of the render path over saved activations (third generation), included by nsr_kernels.h.
 //
-// The second-generation kernel (nsr_bwd.h) keeps every parameter-gradient accumulator of a decoder in the registers of
-// ONE wave, which pins it to one wave per SIMD with spills.  When the forward has saved the decoders' activations
+// The second-generation kernel (nsr_bwd.h, removed in round 4) kept every parameter-gradient accumulator of a decoder in the
+// registers of ONE wave, which pinned it to one wave per SIMD with spills.  Over the decoders' activations that the forward saves
 // (nsr_render_args.acts: hidden states, relu masks, grid features), the backward is four launches instead:
 //   comp_bwd_kernel        one wave per ray: d raw per sample from the output gradients (compositor backward), the sample's
 //                          fp64 position and its bound test                                  (common.py:231-244 differentiated)

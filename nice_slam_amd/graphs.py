@@ -15,7 +15,7 @@ What the closure must respect is torch's, not ours: no ``.item()`` / boolean-mas
 the closed-over tensors (``t.copy_(new)``) before each replay.  The side-stream warm-up is not optional when a leaf tensor
 (a pose) receives its gradient through autograd's AccumulateGrad: a loss tensor of an EAGER iteration that is still alive keeps
 that node, the node remembers the eager stream, and the captured backward then drags that stream into the capture (on ROCm 7.2
-``hipStreamEndCapture`` dies on it instead of reporting unjoined work; measured, tests/perf/_segv_probe.py).
+``hipStreamEndCapture`` dies on it instead of reporting unjoined work; measured, tests/perf/capture_segv_probe.py).
 """
 from __future__ import annotations
 

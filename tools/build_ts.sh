@@ -1,6 +1,6 @@
 #!/bin/sh
 # Measurement tooling, not part of the product: libnsr with s_memtime stamps at the phase boundaries of the backward
-# kernel (-DNSR_TS, see Dbg in nsr_dev.h).  Used by tests/perf/ts_probe.py through NSR_LIB_PATH.
+# kernel (-DNSR_TS, see Dbg in nsr_dev.h).  Used by tests/perf/ts_dx.py / ts_fwd.py through NSR_LIB_PATH.
 #   sh tools/build_ts.sh [name [extra -D flags]]     -> nice_slam_amd/_ab/libnsr_<name>.so   (default name: ts)
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
