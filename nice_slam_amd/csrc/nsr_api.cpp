@@ -293,6 +293,8 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
         const int first = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE, last = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : P.stage;
         nsr::FinalParams R;
         R.stride = P.partial_stride; R.overwrite = b->overwrite_dparams ? 1 : 0;
+        static const int x_fin = env_int("NSR_X_FIN", 0);
+        R.x = x_fin;
         int rows = 0, nblocks = 0;
         for (int s = first; s <= last; ++s) {
             if (!P.dec[s].dparams) continue;
@@ -303,7 +305,7 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
             J.params = P.dec[s].params; J.dparams = P.dec[s].dparams;
             J.kind = s; J.nimg = P.dw_beg[pass + 1] - P.dw_beg[pass]; J.ndx = G.nb;
             const int dbeg = s == NSR_COARSE ? 0 : nsr::xyz_w(nsr::cdim_of(s), 0);
-            const int nb = (nsr::param_total(s) - dbeg + 63) / 64 + 5 + (s == NSR_COARSE ? 0 : 5 * nsr::cdim_of(s) / 4);
+            const int nb = (nsr::param_total(s) - dbeg + 63) / 64 + 5 + (s == NSR_COARSE ? 0 : 5 * nsr::cdim_of(s) / 4 + 5);
             nblocks = nb > nblocks ? nb : nblocks;
         }
         for (int r = rows; r < 3; ++r) R.job[r] = nsr::FinalJob{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};

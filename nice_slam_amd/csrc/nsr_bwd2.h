@@ -854,7 +854,8 @@ NSR_KERNEL NSR_BOUNDS(64 * kDwWaves) void render_bwd_dw_kernel(const RenderParam
 //   blocks [0, nd):        64 directly accumulated parameters each (pts_linears, output_linear; everything for MLP_no_xyz)
 //   blocks [nd, nd + 5):   d embedder._B from the dX kernel's partials (64 each)
 //   blocks [nd + 5, + 5 c_dim / 4):  fc_c.i, four feature columns each: dU_i = W_{i+1}^T G_{i+1} (G summed from the images,
-//                          where it sits in dU_i's place), dv_i = W_{i+1}^T db_{i+1};  i = 4: Wo^T g_out, Wo^T d bo
+//                          where it sits in dU_i's place);  i = 4: Wo^T g_out
+//   the next 5 blocks:     dv_i = W_{i+1}^T db_{i+1};  i = 4: Wo^T d bo
 // ------------------------------------------------------------------------------------------------
 struct FinalJob {
     const float *images;     // [nimg][stride]
@@ -866,6 +867,7 @@ struct FinalJob {
 struct FinalParams {
     FinalJob job[3];
     int stride, overwrite;
+    int x;                   // measurement switches (NSR_X_FIN): 1 = no plain-sum blocks, 2 = no fc_c blocks
 };
 NSR_DEV void final_store(const FinalParams &R, float *p, float v) { *p = R.overwrite ? v : *p + v; }
 // sum of p[k * stride] over k = first, first + step, ... < n, in that order, with sixteen loads in flight at a time (the kernel
@@ -893,6 +895,7 @@ NSR_KERNEL void bwd_finalize_kernel(const FinalParams R) {
     const int lane = t & 63, slice = t >> 6, nslice = nt >> 6;
     if (b < nd + 5) {
         // plain sums: 64 parameters x nslice slices of the image list
+        if (R.x & 1) return;
         const bool isB = b >= nd;
         if (isB && !xyz) return;
         const int e = (isB ? (b - nd) : b) * 64 + lane;             // element within the region
@@ -914,10 +917,14 @@ NSR_KERNEL void bwd_finalize_kernel(const FinalParams R) {
         }
         return;
     }
-    if (!xyz) return;
+    if (!xyz || (R.x & 2)) return;
     // fc_c layer i, feature columns [4 chunk, 4 chunk + 4): S[o][c] = sum over the images of G (rows o < nrow of dU_i's place),
     // 128 elements x 8 slices of the image list; chunk 0 also forms the bias sums db (32 slices) and dv_i
-    const int per = cd / 4, i = (b - nd - 5) / per, chunk = (b - nd - 5) % per;
+    // (the bias sums db_{i+1} and dv_i = W_{i+1}^T db_{i+1} have blocks of their own, behind the 5 per chunk blocks: inside chunk 0 their
+    //  loads were issued behind the G sums -- a second memory round trip in the kernel's longest block; 13.4 -> see profiles/r04_dx_experiments.txt)
+    const int per = cd / 4, q5 = b - nd - 5;
+    const bool bias_blk = q5 >= 5 * per;
+    const int i = bias_blk ? q5 - 5 * per : q5 / per, chunk = bias_blk ? -1 : q5 % per;
     if (i > 4) return;                                              // (grid sized for the largest decoder of the stage)
     // the colour decoder's 4th output is discarded (decoder.py:341): three rows
     const int nrow = i < 4 ? 32 : (nout == 1 ? 1 : 3), goff = xyz_fcw(cd, i);
@@ -928,17 +935,30 @@ NSR_KERNEL void bwd_finalize_kernel(const FinalParams R) {
     const int wstr = i < 4 ? xyz_in(i + 1) : 32;
     float *wl = red + 2048 + 32;                                    // [32][32]
     for (int q = t; q < 1024; q += nt) wl[q] = (q >> 5) < nrow ? J.params[woff + (q >> 5) * wstr + (q & 31)] : 0.f;
-    {
-        float sg = 0.f;
-        if (o < nrow) sg = strided_sum(J.images + goff + o * cd + c, R.stride, sl, nsl, J.nimg);
-        red[t] = sg;
-    }
-    if (chunk == 0) {
+    if (bias_blk) {
         const int ob = t & 31, sb = t >> 5;                         // 32 bias elements x nt / 32 slices
         const int boff = i < 4 ? xyz_b(cd, i + 1) : xyz_bo(cd, nout);
         float sbv = 0.f;
         if (ob < nrow) sbv = strided_sum(J.images + boff + ob, R.stride, sb, nt >> 5, J.nimg);
         red[1024 + t] = sbv;
+        block_sync();
+        if (t < 32) {
+            float sv = 0.f;
+            for (int k = 0; k < (nt >> 5); ++k) sv += red[1024 + k * 32 + t];
+            red[2048 + t] = sv;
+        }
+        block_sync();
+        if (t < 32) {
+            float sv = 0.f;
+            for (int oo = 0; oo < nrow; ++oo) sv = fmaf(wl[oo * 32 + t], red[2048 + oo], sv);
+            final_store(R, J.dparams + xyz_fcb(cd, i) + t, sv);
+        }
+        return;
+    }
+    {
+        float sg = 0.f;
+        if (o < nrow) sg = strided_sum(J.images + goff + o * cd + c, R.stride, sl, nsl, J.nimg);
+        red[t] = sg;
     }
     block_sync();
     if (t < 128) {
@@ -946,22 +966,12 @@ NSR_KERNEL void bwd_finalize_kernel(const FinalParams R) {
         for (int k = 1; k < nsl; ++k) sg += red[k * 128 + t];
         red[t] = sg;
     }
-    if (chunk == 0 && t >= 256 && t < 288) {
-        float sbv = 0.f;
-        for (int k = 0; k < (nt >> 5); ++k) sbv += red[1024 + k * 32 + (t - 256)];
-        red[2048 + (t - 256)] = sbv;
-    }
     block_sync();
     if (t < 128) {
         const int k = t >> 2, cc = t & 3;
         float sv = 0.f;
         for (int oo = 0; oo < nrow; ++oo) sv = fmaf(wl[oo * 32 + k], red[oo * 4 + cc], sv);
         final_store(R, J.dparams + goff + k * cd + 4 * chunk + cc, sv);
-    } else if (chunk == 0 && t >= 256 && t < 288) {
-        const int k = t - 256;
-        float sv = 0.f;
-        for (int oo = 0; oo < nrow; ++oo) sv = fmaf(wl[oo * 32 + k], red[2048 + oo], sv);
-        final_store(R, J.dparams + xyz_fcb(cd, i) + k, sv);
     }
 }
 
