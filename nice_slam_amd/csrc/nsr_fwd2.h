@@ -204,6 +204,12 @@ NSR_KERNEL void fwd_composite_kernel(const RenderParams P) {
     } else if (rayq < P.n_rays) {
         const bool act = lane < S;
         const long long gq = rayq * S + (act ? lane : 0);
+        // the loss epilogue's inputs are requested HERE, with the sample data: behind the stores below the compiler may not move them
+        // (the pointers could alias), and they were a second memory round trip in an 8 us kernel
+        const bool kp = !P.loss || !P.keep || P.keep[rayq];
+        const float gd = (P.loss && P.loss_depth) ? P.loss_depth[rayq] : 0.f;
+        float gtc[3] = {0.f, 0.f, 0.f};
+        if (P.loss && STAGE == NSR_STAGE_COLOR && P.gt_color) { gtc[0] = P.gt_color[rayq * 3 + 0]; gtc[1] = P.gt_color[rayq * 3 + 1]; gtc[2] = P.gt_color[rayq * 3 + 2]; }
         double qx = 0.0, qy = 0.0, qz = 0.0, zq = 0.0;
         F4 rw = F4{0.f, 0.f, 0.f, 0.f};
         bool ins = true;
@@ -231,8 +237,6 @@ NSR_KERNEL void fwd_composite_kernel(const RenderParams P) {
         if (P.loss) {
             // Mapper.py:487-493 on the rays the pre-filter keeps, and its derivative w.r.t. this ray's outputs (see
             // render_fwd_kernel: the same expressions)
-            const bool kp = !P.keep || P.keep[rayq];
-            const float gd = P.loss_depth ? P.loss_depth[rayq] : 0.f;
             double gD = 0.0;
             float g3[3] = {0.f, 0.f, 0.f};
             if (kp && gd > 0.f) {
@@ -241,7 +245,7 @@ NSR_KERNEL void fwd_composite_kernel(const RenderParams P) {
                 gD = df > 0.0 ? 1.0 : (df < 0.0 ? -1.0 : 0.0);
             }
             if (kp && STAGE == NSR_STAGE_COLOR && P.gt_color) {
-                const float e[3] = {cr - P.gt_color[rayq * 3 + 0], cg - P.gt_color[rayq * 3 + 1], cb - P.gt_color[rayq * 3 + 2]};
+                const float e[3] = {cr - gtc[0], cg - gtc[1], cb - gtc[2]};
                 lterm += (double)(P.w_color * ((fabsf(e[0]) + fabsf(e[1])) + fabsf(e[2])));
 #pragma unroll
                 for (int q = 0; q < 3; ++q) g3[q] = e[q] > 0.f ? P.w_color : (e[q] < 0.f ? -P.w_color : 0.f);

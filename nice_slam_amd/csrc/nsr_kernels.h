@@ -1242,6 +1242,13 @@ NSR_KERNEL void get_samples_window_kernel(const WindowParams P) {
     const int k = bid_y();
     if (i < P.n) {
     const long long t = (long long)k * P.n + i;
+    // the frame's pose is requested first, with the draw's state: behind the index store below the compiler may not move the loads
+    float Rm[3][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float *R = P.c2w[k] + a * P.c2w_stride[k];
+        Rm[a][0] = R[0]; Rm[a][1] = R[1]; Rm[a][2] = R[2]; Rm[a][3] = R[3];
+    }
     long long idx;
     if (P.indices) {
         idx = P.indices[t];
@@ -1254,15 +1261,16 @@ NSR_KERNEL void get_samples_window_kernel(const WindowParams P) {
     const int row = (int)(idx / P.crop_w) + P.H0, col = (int)(idx % P.crop_w) + P.W0;
     const long long pix = (long long)row * P.W_full + col;
     const float gd = P.depth[k][pix];
+    const float c0 = P.color[k][pix * 3 + 0], c1 = P.color[k][pix * 3 + 1], c2 = P.color[k][pix * 3 + 2];    // (all four in flight together)
     P.out_depth[t] = gd;
-    P.out_color[t * 3 + 0] = P.color[k][pix * 3 + 0];
-    P.out_color[t * 3 + 1] = P.color[k][pix * 3 + 1];
-    P.out_color[t * 3 + 2] = P.color[k][pix * 3 + 2];
+    P.out_color[t * 3 + 0] = c0;
+    P.out_color[t * 3 + 1] = c1;
+    P.out_color[t * 3 + 2] = c2;
     const float dx = ((float)col - P.cx) / P.fx, dy = -(((float)row - P.cy) / P.fy), dzv = -1.f;
     double tb = 0.0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float *R = P.c2w[k] + a * P.c2w_stride[k];
+        const float *R = Rm[a];
         const float d = (dx * R[0] + dy * R[1]) + dzv * R[2];       // common.py:87: products, then left-to-right sum
         const float o = R[3];
         P.rays_d[t * 3 + a] = d;
