@@ -698,7 +698,8 @@ int nsr_tracking_loss(int64_t n_rays, const float *gt_depth, const float *gt_col
     P.loss = loss; P.dl_depth = dl_depth; P.dl_rgb = dl_rgb;
     const int tb = n_rays <= 256 ? 256 : 1024;                       // one block: the median is a property of the whole batch
     const int key_cap = (handle_dynamic && n_rays <= 4096) ? (int)n_rays : 0;      // tmp bit patterns cached in LDS (<= 32 KB), else recomputed
-    NSR_LAUNCH(nsr::tracking_loss_kernel, dim3(1), dim3(tb), 1024 + 32 + tb * 8 + key_cap * 8, stream, P, key_cap);
+    // (key slots for every thread of the block: the one-ray-per-thread path of n <= tb pads the key list with skip marks)
+    NSR_LAUNCH(nsr::tracking_loss_kernel, dim3(1), dim3(tb), 1024 + 32 + tb * 8 + (key_cap > 0 && key_cap < tb ? tb : key_cap) * 8, stream, P, key_cap);
     return finish("nsr_tracking_loss");
 }
 

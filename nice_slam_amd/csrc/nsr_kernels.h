@@ -1503,6 +1503,69 @@ NSR_KERNEL void tracking_loss_kernel(const TrackLossParams P, const int key_cap)
     constexpr unsigned long long kSkip = ~0ull;                    // not kept: above every finite / inf / NaN pattern of a non-negative double
     double thr = 0.0;
     bool use_thr = false;
+    if (P.handle_dynamic && cached && P.n <= nt) {
+        // The tracker's own batch (200 rays): one ray per thread, everything stays in registers -- one round of loads (the colour
+        // term's included), one sqrt / divide, the rank of the thread's key by counting (two keys per 16-byte LDS read), then mask,
+        // derivative and loss from the same registers.  Same expressions and the same summation order as the general path below.
+        const long long i = t;
+        const bool in = i < P.n;
+        const bool k = in && (!P.keep || P.keep[i]);
+        const float gd = in ? P.gt_depth[i] : 0.f;
+        const double dep = in ? P.depth[i] : 0.0, vr = in ? P.var[i] : 0.0;
+        float gc[3] = {0.f, 0.f, 0.f}, rc[3] = {0.f, 0.f, 0.f};
+        if (P.use_color && in) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { gc[a] = P.gt_color[i * 3 + a]; rc[a] = P.rgb[i * 3 + a]; }
+        }
+        const double diff = (double)gd - dep, rs = sqrt(vr + 1e-10);
+        const double v = fabs(diff) / rs;
+        const unsigned long long ki = k ? __builtin_bit_cast(unsigned long long, v) : kSkip;
+        if (t < 4) ctl[t] = 0;
+        if (t == 0) pre[0] = 0ull;
+        keys[t] = in ? ki : kSkip;                              // (key_cap >= n; the slots up to nt exist: see the launch)
+        block_sync();
+        if (k) atomic_add_lds_i(ctl + 0, 1);
+        if (k && v != v) atomic_add_lds_i(ctl + 1, 1);
+        int rank = 0;
+        const int n2 = ((int)P.n + 1) & ~1;
+        for (int j = 0; j < n2; j += 2) {
+            const unsigned long long k0 = keys[j], k1 = keys[j + 1];
+            rank += (k0 < ki || (k0 == ki && j < t)) ? 1 : 0;
+            rank += (k1 < ki || (k1 == ki && j + 1 < t)) ? 1 : 0;
+        }
+        block_sync();
+        const int n_kept = ctl[0], n_nan = ctl[1];
+        thr = __builtin_nan("");
+        if (n_kept > 0 && n_nan == 0) {
+            if (k && rank == (n_kept - 1) / 2) pre[0] = ki;
+            block_sync();
+            thr = 10.0 * __builtin_bit_cast(double, pre[0]);
+        }
+        bool m = k && gd > 0.f;
+        m = m && (v < thr);
+        double part = 0.0, cpart = 0.0;
+        if (in) {
+            P.dl_depth[i] = m ? (diff > 0.0 ? -1.0 : (diff < 0.0 ? 1.0 : 0.0)) / rs : 0.0;
+            if (m) part += v;
+            if (P.use_color) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float dc = gc[a] - rc[a];
+                    P.dl_rgb[i * 3 + a] = m ? (dc > 0.f ? -P.w_color : (dc < 0.f ? P.w_color : 0.f)) : 0.f;
+                    if (m) cpart += (double)fabsf(dc);
+                }
+            }
+        }
+        const double mine = wave_sum_d(part + (double)P.w_color * cpart);
+        if ((t & 63) == 0) red[t >> 6] = mine;
+        block_sync();
+        if (t == 0) {
+            double s = 0.0;
+            for (int w = 0; w < (nt >> 6); ++w) s += red[w];
+            atomic_add_global_d(P.loss, s);
+        }
+        return;
+    }
     if (P.handle_dynamic) {
         if (t < 4) ctl[t] = 0;
         if (t == 0) { pre[0] = 0ull; pre[1] = 0ull; }

@@ -577,8 +577,9 @@ def test_masked_adam_multi_and_pack_rows(emu):
     assert np.array_equal(flat * 0.5 * 2, flat) and np.array_equal(pose, want[-48:] * 2)
 
 
-@pytest.mark.parametrize("n,dyn,col", [(203, True, True), (1, True, True), (2, True, False), (1500, True, True), (5000, True, True), (64, False, True),
-                                       (300, False, False)])       # <= 1024: rank by counting; <= 4096: radix select on cached keys; above: recomputed
+@pytest.mark.parametrize("n,dyn,col", [(203, True, True), (1, True, True), (2, True, False), (255, True, False), (256, True, True), (300, True, True),
+                                       (1024, True, True), (1500, True, True), (5000, True, True), (64, False, True),
+                                       (300, False, False)])       # <= block size: one ray per thread, rank by counting; <= 4096: radix select on cached keys; above: recomputed
 def test_tracking_loss_matches_the_reference_expression(emu, n, dyn, col):
     """nsr_tracking_loss vs Tracker.optimize_cam_in_batch's loss (src/Tracker.py:108-124) on the COMPACTED batch, with autograd
     for d loss / d depth and d loss / d rgb: the median of `tmp` (lower middle element) is found without a sort."""

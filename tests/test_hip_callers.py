@@ -401,3 +401,53 @@ def test_flat_adam_steps_decoder_and_poses_like_torch_adam():
         nsa.FlatAdam([torch.zeros(3, requires_grad=True)])
     with pytest.raises(NsrError):
         nsa.FlatAdam([torch.zeros(3, device=DEV) for _ in range(5)])
+
+
+@pytest.mark.parametrize("n,dyn,col", [(1, True, True), (2, True, False), (200, True, True), (255, True, False), (256, True, True), (300, True, True),
+                                       (1024, True, True), (1500, True, True), (5000, True, True), (300, False, True)])
+def test_tracking_loss_kernel_against_the_reference_expression(n, dyn, col):
+    """nsr_tracking_loss on the device (through the C ABI) vs Tracker.optimize_cam_in_batch's loss on the COMPACTED batch
+    (src/Tracker.py:92-124) and autograd's d loss / d depth, d loss / d rgb, over the kernel's three median paths: one ray per thread
+    (n <= block size), radix select on cached keys (<= 4096), recomputed keys (above)."""
+    import ctypes as C
+    from nice_slam_amd import _capi
+    lib = _capi.get_lib()
+    g = torch.Generator().manual_seed(100 + n)
+    gd = (torch.rand((n,), generator=g) * 4 + 0.5).float()
+    gd[torch.rand((n,), generator=g) < 0.1] = 0.0
+    depth = gd.double() + torch.randn((n,), generator=g).double() * 0.3
+    depth[torch.rand((n,), generator=g) < 0.05] *= 3.0
+    if n > 10:
+        depth[5] = gd[5].double()
+    var = torch.rand((n,), generator=g).double() * 0.2
+    rgb, gc = torch.rand((n, 3), generator=g), torch.rand((n, 3), generator=g)
+    keep = torch.rand((n,), generator=g) < 0.85
+    if n <= 2:
+        keep[:] = True
+    w = 0.5
+    d_l, r_l = depth[keep].clone().requires_grad_(True), rgb[keep].clone().requires_grad_(True)
+    g_k, c_k, v_k = gd[keep], gc[keep], var[keep]
+    tmp = torch.abs(g_k - d_l) / torch.sqrt(v_k + 1e-10)
+    mask = ((tmp < 10 * tmp.median()) & (g_k > 0)) if dyn else (g_k > 0)
+    ref = tmp[mask].sum()
+    if col:
+        ref = ref + w * torch.abs(c_k - r_l)[mask].sum()
+    ref.backward()
+    want_d = torch.zeros(n, dtype=torch.float64); want_d[keep] = d_l.grad
+    want_r = torch.zeros((n, 3)); want_r[keep] = r_l.grad if r_l.grad is not None else torch.zeros_like(r_l)
+    dev = torch.device(DEV)
+    t = [x.to(dev).contiguous() for x in (gd, gc, keep.to(torch.uint8), depth, var, rgb)]
+    loss = torch.zeros(1, dtype=torch.float64, device=dev)
+    dld = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+    dlr = torch.full((n, 3), float("nan"), dtype=torch.float32, device=dev)
+    with _capi.on_device(dev):
+        lib.check(lib.nsr_tracking_loss(n, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(), t[5].data_ptr(),
+                                        int(dyn), int(col), w, loss.data_ptr(), dld.data_ptr(), dlr.data_ptr() if col else None,
+                                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "nsr_tracking_loss")
+    torch.cuda.synchronize()
+    # (the reference's colour term is an fp32 sum; the kernel accumulates both terms in fp64)
+    assert abs(float(loss) - float(ref.detach())) <= (1e-6 if col else 1e-9) * abs(float(ref.detach())) + 1e-12
+    got_d = dld.cpu()
+    assert torch.equal(got_d == 0, want_d == 0) and torch.allclose(got_d, want_d, rtol=1e-14, atol=0)
+    if col:
+        assert torch.equal(dlr.cpu(), want_r)
