@@ -400,10 +400,11 @@ def main():
     frames = [(c.to(dev), d.to(dev), col.to(dev)) for c, d, col in sc["frames"]]
     K = len(frames)
     params = list(dec.parameters())
-    ev = HipEvents(4)                       # backward: start, stop, behind dX, behind dW
+    ev = HipEvents(4)                       # backward, kernel by kernel: start, stop, behind dX, behind dW
+    ev_tot = HipEvents(2)                   # backward as a whole: start, stop only (every event record between two kernels costs
+                                            # 3-5 us of its own: with four events the sum read 196 us where rocprofv3 had 179)
     ev_fwd = HipEvents(2)                   # forward: around the decoder-pass kernel
-    ev_graph = HipEvents()                  # event pairs captured INTO the replayed graphs (no host launch gaps between the kernels)
-    renderer.profile_events = ev.pair_for
+    renderer.profile_events = None
     stages_cfg = ("middle", "fine", "color") if C["stages"] == "mix" else tuple(C["stages"])
     if args.stage:
         stages_cfg = (args.stage,)
@@ -444,9 +445,8 @@ def main():
             g.grad = None
         for p in params:
             p.grad = None
-        renderer.profile_fwd_events = ev_fwd.pair_for if timed else None
-        if not timed:
-            renderer.profile_events = None
+        renderer.profile_fwd_events = ev_fwd.pair_for if timed == "split" else None
+        renderer.profile_events = None if not timed else (ev.pair_for if timed == "split" else ev_tot.pair_for)
         if tracking and not args.unfused:                         # Tracker.optimize_cam_in_batch (Tracker.py:87-125) as one autograd node
             cam.grad = None
             loss = nsa.tracking_loss(renderer, grids, dec, cam, frames[0][1], frames[0][2], rays_rank, crop, crop, w_color=0.5)
@@ -479,7 +479,7 @@ def main():
         else:                                                      # Mapper.py:437-503 as one autograd node (mapping.py)
             loss = nsa.mapping_loss(renderer, grids, dec, frames, per_frame, stage, w_color=0.2, coarse_mapper=(stage == "coarse"))
             nsa.backward(loss)
-        renderer.profile_events = ev.pair_for
+        renderer.profile_events = None
         renderer.profile_fwd_events = None
         return stage
 
@@ -490,12 +490,13 @@ def main():
         step(reps[i % len(reps)], False)
     torch.cuda.synchronize()
     for st_i in reps:
-        for _ in range(5):
+        for j in range(8):
             # the GPU idles for ~1 ms first, so that the host has the whole iteration enqueued before the first kernel starts:
             # the events inside nsr_render_bwd then bracket the backward's kernels running back to back (as they do in the
-            # replayed graphs of the timed region), not the host's launch pace
+            # replayed graphs of the timed region), not the host's launch pace.  Four iterations with (start, stop) around the
+            # whole backward, four with an event behind every kernel (+ around the forward's pass kernel)
             torch.cuda._sleep(2_000_000)
-            step(st_i, True)
+            step(st_i, "total" if j < 4 else "split")
     torch.cuda.synchronize()
     # RCCL collectives are capturable too; NSR_DIST_GRAPH=0 forces the eager path for multi-rank runs
     use_graph = not args.eager and ((not sharded) or os.environ.get("NSR_DIST_GRAPH", "1") == "1") \
@@ -518,10 +519,8 @@ def main():
                 gph = torch.cuda.CUDAGraph()
                 if shard is not None:                            # the ranks' own pixel generator takes part in the capture
                     gph.register_generator_state(shard.generator(dev))
-                renderer.profile_events = ev_graph.pair_for      # event-record nodes around the backward kernels
                 with torch.cuda.graph(gph):
                     st_name = step(st_i, False)
-                renderer.profile_events = None
                 graphs[st_name] = gph
             torch.cuda.synchronize()
             for gph in graphs.values():                 # first replays pay the one-time upload of the executable graph:
@@ -574,13 +573,8 @@ def main():
         shard_check = verify_shards(nsa, shard, renderer, grids, dec, frames, per_frame, stages_cfg[-1], H, W, world, rank, dev)
 
     if rank == 0:
-        ksum = ev.summary()
-        ksum_graph = ev_graph.summary() if use_graph else {}     # elapsed time between the event nodes of the LAST replay of each graph
+        ksum = ev_tot.summary()
         events_from = "eager iterations of this process, each enqueued behind a 1 ms GPU-side wait (kernels back to back, like in the replayed graphs)"
-        if rank == 0 and use_graph:
-            print(f"[bench] event nodes in the replayed graphs: {ksum_graph}", file=sys.stderr)
-        if ksum_graph and all(0.0 < v[0] < 1e4 for v in ksum_graph.values()) and set(ksum_graph) == set(ksum):
-            ksum, events_from = ksum_graph, "event-record nodes inside the replayed hipGraphs (the timed region's own launches)"
         dom = "color" if "color" in ksum else (list(ksum)[-1] if ksum else None)
         res = {
             "metric": "rendered rays/sec (fwd+bwd) per mapping iter", "value": rays_iter * args.steps / dt, "unit": "rays/s",
@@ -662,6 +656,9 @@ def main():
             if ker:
                 furthest = min((k for k in ker if "frac" in ker[k]), key=lambda k: ker[k]["frac"], default=None)
                 res["roofline"]["kernels"] = ker
+                res["roofline"]["kernels_note"] = ("separate eager iterations with a HIP event behind every kernel: each bracket carries the 3-5 us "
+                                                   "of its own event records (rocprofv3 of the same command reads 5-10 % less per kernel); "
+                                                   "`avg_kernel_ms` / `frac` come from iterations with (start, stop) only")
                 res["roofline"]["furthest_from_peak"] = furthest
             nst = {st_: stages.count(st_) for st_ in set(stages)}
             flop_iter = sum(cnt * rays_rank * (32 if st_ == "coarse" else 48) * NEC_MAC[st_] * 2 for st_, cnt in nst.items()) / max(1, len(stages))
