@@ -339,7 +339,7 @@ NSR_DEV void dx_pass(const RenderParams &P) {
 #pragma unroll
                     for (int q = 0; q < 6; ++q) v[q] += shfl_xor_d(v[q], m);
                 if (lane == 0 && active) {
-                    const long long ray = gp / P.S;
+                    const long long ray = (long long)((unsigned)gp / (unsigned)P.S);
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         atomic_add_global(P.d_rays_o + ray * 3 + q, (float)v[q]);
@@ -347,7 +347,7 @@ NSR_DEV void dx_pass(const RenderParams &P) {
                     }
                 }
             } else if (mine) {
-                const long long ray = gp / P.S;
+                const long long ray = (long long)((unsigned)gp / (unsigned)P.S);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     atomic_add_global(P.d_rays_o + ray * 3 + q, (float)v[q]);
@@ -745,8 +745,8 @@ NSR_DEV unsigned long long dw_live_mask(const RenderParams &P, long long bi, lon
     const long long t = bi + ((long long)chunk * 64 + lane) * step;
     bool live = false;
     if (t < ntiles) {
-        const long long p0 = t * kTile, pe = p0 + kTile < P.n_points_total ? p0 + kTile : P.n_points_total;
-        for (long long r = p0 / P.S; r <= (pe - 1) / P.S; ++r) live = live || P.keep[r] != 0;
+        const unsigned p0 = (unsigned)t * kTile, np = (unsigned)P.n_points_total, pe = p0 + kTile < np ? p0 + kTile : np, S = (unsigned)P.S;   // (< 2^25 points per call)
+        for (unsigned r = p0 / S; r <= (pe - 1) / S; ++r) live = live || P.keep[r] != 0;
     }
     return ballot64(live);
 }

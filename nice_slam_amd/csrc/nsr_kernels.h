@@ -112,9 +112,11 @@ struct RenderParams {
 NSR_DEV bool ray_live(const RenderParams &P, long long ray) { return !P.skip_masked || uniform_load_u8(P.keep + ray) != 0u; }
 NSR_DEV bool tile_live(const RenderParams &P, long long tile) {
     if (!P.skip_masked) return true;
-    const long long p0 = tile * kTile, pe = p0 + kTile < P.n_points_total ? p0 + kTile : P.n_points_total;
+    // (32-bit: a call holds fewer than 2^25 sample points, nsr_api.cpp; the 64-bit form was two software divisions, ~700 scalar
+    //  instructions per claimed tile)
+    const unsigned p0 = (unsigned)tile * kTile, np = (unsigned)P.n_points_total, pe = p0 + kTile < np ? p0 + kTile : np, S = (unsigned)P.S;
     bool live = false;
-    for (long long r = p0 / P.S; r <= (pe - 1) / P.S; ++r) live = live || uniform_load_u8(P.keep + r) != 0u;
+    for (unsigned r = p0 / S; r <= (pe - 1) / S; ++r) live = live || uniform_load_u8(P.keep + r) != 0u;
     return live;
 }
 
