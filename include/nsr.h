@@ -14,6 +14,8 @@
  *   nsr_eval_points_fwd  <- src/utils/Renderer.py:23-61   Renderer.eval_points (forward only)
  *   nsr_masked_adam      <- src/Mapper.py:368-379,394-401,504,511-519  masked write-back + Adam on one feature grid
  *   nsr_masked_adam_multi <- the same for all grids of a stage, step counts on the device (capturable)
+ *   nsr_flat_adam        <- src/Mapper.py:368-387,504, src/Tracker.py:214-222,127  torch.optim.Adam on the dense rest of the
+ *                           callers' optimiser (decoder parameter blobs, camera tensors), one launch pair, capturable
  *   nsr_get_samples_window <- src/Mapper.py:437-481  sampling loop over the mapping window + bounding-box pre-filter
  *   nsr_pose_grad        <- autograd of src/common.py:74-88 for that window (local BA, src/Mapper.py:417-419)
  *   nsr_pack_rows        <- (none) gather / scatter of the voxel rows + blobs that travel in the multi-GPU all-reduce
