@@ -185,22 +185,27 @@ def cpu_baseline(sc, n_rays, stages, weights, track_crop=None):
             tt = (sc["bound"].unsqueeze(0) - o.detach().unsqueeze(-1)) / d.detach().unsqueeze(-1)
             inside = torch.min(torch.max(tt, dim=2)[0], dim=1)[0] >= gd
         o, d, gd, gc = o[inside], d[inside], gd[inside], gc[inside]
+        kept_n.append(int(inside.sum()))
         depth, unc, col = orc.render_batch_ray(grids, params, d, o, "color", gd, sc["bound"])
         unc = unc.detach()
         tmp = torch.abs(gd - depth) / torch.sqrt(unc + 1e-10)
         mask = (tmp < 10 * tmp.median()) & (gd > 0)
         (tmp[mask].sum() + 0.5 * torch.abs(gc - col)[mask].sum()).backward()
 
+    kept_n = []
     if track_crop is not None:
         once_track(64)
+        kept_n.clear()
         t0 = time.perf_counter()
         reps = 10
         for _ in range(reps):
             once_track(n)
         dt = (time.perf_counter() - t0) / reps
-        return {"value": n / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+        nk = sum(kept_n) / max(1, len(kept_n))
+        return {"value": nk / dt, "unit": "rays/s", "sampled_rays_per_s": n / dt, "cores": cores, "kind": "port",
                 "sample": "oracle (grid_sampler_3d mode) tracking iteration (sampling, pre-filter, colour-stage render, loss, backward to the "
-                          "pose), %d rays, mean of %d iterations (%.0f ms each)" % (n, reps, dt * 1e3)}
+                          "pose), %d sampled / %.0f rendered rays, mean of %d iterations (%.0f ms each); `value` counts rendered rays like the "
+                          "GPU line" % (n, nk, reps, dt * 1e3)}
 
     def once(stage, m):
         G = {k: v.clone().requires_grad_(True) for k, v in grids.items()}
@@ -210,6 +215,7 @@ def cpu_baseline(sc, n_rays, stages, weights, track_crop=None):
             tt = (sc["bound"].unsqueeze(0) - o.unsqueeze(-1)) / d.unsqueeze(-1)
             inside = torch.min(torch.max(tt, dim=2)[0], dim=1)[0] >= gd
         o, d, gd, gc = o[inside], d[inside], gd[inside], gc[inside]
+        kept_n.append(int(inside.sum()))
         depth, _, col = orc.render_batch_ray(G, P, d, o, stage, gd, sc["bound"])
         loss = (torch.abs(gd - depth) * (gd > 0)).sum()
         if stage == "color":
@@ -220,6 +226,7 @@ def cpu_baseline(sc, n_rays, stages, weights, track_crop=None):
     reps = 3
     for stage in stages:
         once(stage, 64)                                        # warm-up
+        kept_n.clear()
         ts = []
         for _ in range(reps):
             t0 = time.perf_counter()
@@ -227,9 +234,11 @@ def cpu_baseline(sc, n_rays, stages, weights, track_crop=None):
             ts.append(time.perf_counter() - t0)
         t[stage] = sorted(ts)[reps // 2]
     mix = sum(weights[s] * t[s] for s in stages) / sum(weights.values())
-    return {"value": n / mix, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": "oracle (grid_sampler_3d mode) pre-filter + fwd+bwd, %d sampled rays, median of %d iterations per stage (%s), weighted like the GPU run"
-                      % (n, reps, ", ".join(f"{s} {t[s]*1e3:.0f} ms" for s in stages)),
+    nk = kept_n[-1] if kept_n else n                            # the same pixels every time: the same rays survive the pre-filter
+    return {"value": nk / mix, "unit": "rays/s", "sampled_rays_per_s": n / mix, "cores": cores, "kind": "port",
+            "sample": "oracle (grid_sampler_3d mode) pre-filter + fwd+bwd, %d sampled / %d rendered rays, median of %d iterations per stage (%s), weighted "
+                      "like the GPU run; `value` counts rendered rays like the GPU line"
+                      % (n, nk, reps, ", ".join(f"{s} {t[s]*1e3:.0f} ms" for s in stages)),
             "port_vs_reference": "calibrated in the build container, where both run (tools/calibrate_cpu_baseline.py, "
                                  "profiles/README.md, 1000 rays at Replica shapes): this port takes 0.87 / 0.72 / 0.97 x the time of "
                                  "the reference's own Renderer + NICE modules (middle / fine / colour stage), i.e. the reference "
@@ -316,75 +325,18 @@ def spawn_ranks(n):
     return rc
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="1", choices=sorted(CONFIGS), help="BASELINE.json configuration (default 1 = the headline one)")
-    ap.add_argument("--windows", type=int, default=3, help="the K timed steps are run this many times; the median window is reported")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--stage", default=None, help="pin every step to one stage (profiling)")
-    ap.add_argument("--rays", type=int, default=None, help="rays per iteration (default: the configuration's)")
-    ap.add_argument("--verify-shards", action="store_true", default=None,
-                    help="multi-GPU self check after the timed region: one iteration with shared fixed pixel draws, the all-reduced "
-                         "loss / grid / decoder / pose gradients against a single-GPU evaluation of the union batch on every rank "
-                         "(default: on whenever more than one rank runs)")
-    ap.add_argument("--no-verify-shards", dest="verify_shards", action="store_false")
-    ap.add_argument("--eager", action="store_true", help="do not capture the iteration in a hipGraph")
-    ap.add_argument("--unfused", action="store_true", help="the drop-in call sequence (get_samples per frame, render_batch_ray, torch loss) instead of mapping_loss")
-    ap.add_argument("--stepped-grads-only", action="store_true",
-                    help="parameter gradients only for the decoder the reference's optimiser steps (colour); default: all, like the reference autograd")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
-                    help="multi-GPU: weak = the configuration's rays per GPU, strong = in total (default: strong for config 3 / 4, else weak)")
-    ap.add_argument("--render-masked", action="store_true",
-                    help="render the rays the bounding-box pre-filter rejects too and only mask them out of the loss (default: they are "
-                         "removed from the batch like the reference's compaction does, Mapper.py:471-481)")
-    ap.add_argument("--dense-exchange", action="store_true",
-                    help="multi-GPU: all-reduce the whole feature-grid gradients instead of the frustum-selected voxel rows")
-    args = ap.parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus))                          # `python bench.py --gpus N`: launch the N ranks ourselves
-    if "WORLD_SIZE" in os.environ and args.gpus > 1 and int(os.environ["WORLD_SIZE"]) != args.gpus:
-        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}")
-
-    # stdout carries exactly ONE line, the result JSON: anything a library prints there (RCCL's version banner, ...) is
-    # sent to stderr by pointing file descriptor 1 at it; the JSON goes to the saved original descriptor at the end
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.verify_shards is None:
-        args.verify_shards = world > 1
-    if world > 1:
-        import signal
-        signal.alarm(int(os.environ.get("NSR_BENCH_DEADLINE_S", "900")))   # a wedged collective must not hang the node: die loudly
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("NSR_SINGLE_DEVICE") == "1":                # CI on a 1-GPU box: every rank on device 0 (with gloo, see below)
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    force_dist = os.environ.get("NSR_FORCE_SHARDED") == "1"        # exercise the RCCL path with a single rank (CI on a 1-GPU box)
-    sharded = world > 1 or force_dist
-    if sharded:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        backend = os.environ.get("NSR_DIST_BACKEND", "nccl")       # "nccl" = RCCL; "gloo" only to exercise the multi-rank
-        if backend == "nccl":                                      # code path where RCCL cannot run (ranks sharing one GPU)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
+def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", rays_override=None, stage_override=None):
+    """Time one BASELINE configuration and return its result record on rank 0 (None elsewhere).  role "headline": the full line
+    (roofline block, per-kernel events, cpu_baseline); role "strong": the short record of the strong-scaling configuration that
+    rides in the same line (no CPU baseline, no per-kernel events)."""
     import nice_slam_amd as nsa
     from nice_slam_amd.parallel import ShardedMapping
 
-    C = CONFIGS[args.config]
-    scaling = args.scaling or ("strong" if args.config in ("3", "4") else "weak")
-    rays_cfg = args.rays or C["rays"]
+    C = CONFIGS[cfg_id]
+    headline = role == "headline"
+    rays_cfg = rays_override or C["rays"]
     n_total = rays_cfg * world if scaling == "weak" else rays_cfg      # weak: fixed rays per GPU; strong: fixed batch
-    sc = build_scene(args.config, dev)                              # same seed -> identical scene on every rank
+    sc = build_scene(cfg_id, dev)                              # same seed -> identical scene on every rank
     renderer, dec = sc["renderer"], sc["dec"]
     grids = {k: v.requires_grad_(True) for k, v in sc["grids"].items()}
     tracking = C["kind"] == "tracking"
@@ -406,9 +358,9 @@ def main():
     ev_fwd = HipEvents(2)                   # forward: around the decoder-pass kernel
     renderer.profile_events = None
     stages_cfg = ("middle", "fine", "color") if C["stages"] == "mix" else tuple(C["stages"])
-    if args.stage:
-        stages_cfg = (args.stage,)
-    mix = {s: _CYCLE.count(s) for s in stages_cfg} if C["stages"] == "mix" and not args.stage else {s: 1 for s in stages_cfg}
+    if stage_override:
+        stages_cfg = (stage_override,)
+    mix = {s: _CYCLE.count(s) for s in stages_cfg} if C["stages"] == "mix" and not stage_override else {s: 1 for s in stages_cfg}
 
     def stage_of(it):
         if len(stages_cfg) == 1:
@@ -490,7 +442,7 @@ def main():
         step(reps[i % len(reps)], False)
     torch.cuda.synchronize()
     for st_i in reps:
-        for j in range(8):
+        for j in range(8 if headline else 4):         # (the short record: start / stop events only)
             # the GPU idles for ~1 ms first, so that the host has the whole iteration enqueued before the first kernel starts:
             # the events inside nsr_render_bwd then bracket the backward's kernels running back to back (as they do in the
             # replayed graphs of the timed region), not the host's launch pace.  Four iterations with (start, stop) around the
@@ -560,14 +512,25 @@ def main():
         windows.append(dt)
     dt = sorted(windows)[len(windows) // 2]
     rays_iter = rays_rank * world
+    # What share of the sampled rays passes the bounding-box pre-filter, i.e. is RENDERED (the others are removed from the batch
+    # like the reference's compaction does, Mapper.py:471-481): the mean over 16 untimed draws of this rank (the keep bytes of
+    # the window kernel; no_grad: no decoder work).  Every FLOP count of the roofline block is priced on these rays.
     kept_frac = None
-    if not args.unfused and shard is None:                          # what share of the sampled rays passes the pre-filter (one extra iteration, untimed)
-        info = {}
-        if tracking:
-            nsa.tracking_loss(renderer, grids, dec, cam, frames[0][1], frames[0][2], rays_rank, crop, crop, w_color=0.5, out=info)
-        else:
-            nsa.mapping_loss(renderer, grids, dec, frames, per_frame, stages_cfg[-1], w_color=0.2, coarse_mapper=(stages_cfg[-1] == "coarse"), out=info)
-        kept_frac = float(info["keep"].float().mean().item())
+    if not args.unfused:
+        acc = torch.zeros((), device=dev)
+        with torch.no_grad():
+            for _ in range(16):
+                info = {}
+                if tracking:
+                    nsa.tracking_loss(renderer, grids, dec, cam, frames[0][1], frames[0][2], rays_rank, crop, crop, w_color=0.5, out=info)
+                elif shard is not None:
+                    shard.mapping_loss(grids, dec, frames, per_frame, stages_cfg[-1], out=info)
+                else:
+                    nsa.mapping_loss(renderer, grids, dec, frames, per_frame, stages_cfg[-1], w_color=0.2, coarse_mapper=(stages_cfg[-1] == "coarse"), out=info)
+                acc += info["keep"].float().mean()
+        kept_frac = float(acc.item()) / 16
+    removed = not (args.render_masked or args.unfused)                # are the rejected rays removed from the batch (default) or rendered?
+    rendered_frac = kept_frac if (removed and kept_frac is not None) else 1.0
     shard_check = None
     if args.verify_shards and shard is not None:
         shard_check = verify_shards(nsa, shard, renderer, grids, dec, frames, per_frame, stages_cfg[-1], H, W, world, rank, dev)
@@ -577,16 +540,21 @@ def main():
         events_from = "eager iterations of this process, each enqueued behind a 1 ms GPU-side wait (kernels back to back, like in the replayed graphs)"
         dom = "color" if "color" in ksum else (list(ksum)[-1] if ksum else None)
         res = {
-            "metric": "rendered rays/sec (fwd+bwd) per mapping iter", "value": rays_iter * args.steps / dt, "unit": "rays/s",
+            "metric": "rendered rays/sec (fwd+bwd) per mapping iter", "value": rays_iter * rendered_frac * args.steps / dt, "unit": "rays/s",
+            "value_counts": "rays RENDERED per second: the sampled rays that pass the callers' bounding-box pre-filter (what the reference hands "
+                            "to render_batch_ray, Mapper.py:471-482); `sampled_rays_per_s` counts the pixels drawn per iteration instead "
+                            "(the number rounds 1-4 reported as `value`)",
+            "rendered_rays_per_s": rays_iter * rendered_frac * args.steps / dt, "sampled_rays_per_s": rays_iter * args.steps / dt,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32 (f64 sample placement / depth)",
             "data": "synthetic",
             "config": {"workload": C["name"] + ": grids " + " / ".join("x".join(str(v) for v in grids[k].shape[2:]) for k in grids) +
                                    f", 32 ch fp32, random-init decoders, {H}x{W} synthetic RGB-D, {K}x{per_frame} pixels/iter/GPU, S=32+16",
                        "rays_per_gpu": rays_rank, "rays_per_iteration": rays_iter,
+                       "rays_rendered_per_iteration": round(rays_iter * rendered_frac, 1),
                        "rays_kept_by_prefilter": kept_frac,
-                       "prefilter": ("rays whose depth lies outside the bound (Mapper.py:471-481 / Tracker.py:95-104) are sampled and counted in "
-                                     "`value`, then " + ("rendered and masked out of the loss (--render-masked)" if args.render_masked or args.unfused else
+                       "prefilter": ("rays whose depth lies outside the bound (Mapper.py:471-481 / Tracker.py:95-104) are sampled (counted in "
+                                     "`sampled_rays_per_s`), then " + ("rendered and masked out of the loss (--render-masked)" if args.render_masked or args.unfused else
                                                          "removed from the batch like the reference's boolean-mask compaction does: no decoder work, no gradient")),
                        "stage_mix": {s: stages.count(s) for s in sorted(set(stages))},
                        "timed_region": (("get_samples (crop) + bounding-box mask + render_batch_ray(color) + tracking loss (torch) + backward to the pose"
@@ -605,17 +573,17 @@ def main():
         }
         if dom is not None:
             ms, cnt = ksum[dom]
-            pts = rays_rank * (32 if dom == "coarse" else 48)
+            pts = rays_rank * rendered_frac * (32 if dom == "coarse" else 48)     # sample points of the rays that are rendered
             nec = pts * (NEC_MAC[dom] - FWD_MAC[dom]) * 2
             ach = nec / (ms * 1e-3)
             traffic, tsrc = None, None
-            tpath = os.path.join(ROOT, "profiles", "r04_traffic.json")      # from a separate rocprofv3 --pmc run (tools/pmc_bench.sh)
-            if os.path.exists(tpath) and args.config == "1" and rays_rank == 1000 and dom == "color":
+            tpath = next((p_ for p_ in (os.path.join(ROOT, "profiles", n_) for n_ in ("r05_traffic.json", "r04_traffic.json")) if os.path.exists(p_)), None)
+            if tpath and cfg_id == "1" and rays_rank == 1000 and dom == "color":       # from a separate rocprofv3 --pmc run (tools/pmc_bench.sh)
                 tall = json.load(open(tpath))                 # one entry per kernel: the backward = the sum over its kernels
                 ks = [k for k in tall if any(n_ in k for n_ in ("render_bwd_dx_kernel<3", "render_bwd_dw_kernel<3", "bwd_finalize", "comp_bwd"))]
                 if ks:
                     traffic = sum(tall[k]["hbm_bytes_per_launch"] for k in ks)
-                    tsrc = "profiles/r04_traffic.json (" + " + ".join(k.replace("nsr::", "") for k in ks) + "): " + tall[ks[0]].get("note", "")
+                    tsrc = "profiles/" + os.path.basename(tpath) + " (" + " + ".join(k.replace("nsr::", "") for k in ks) + "): " + tall[ks[0]].get("note", "")
             res["roofline"] = {"bound": "mfma",
                                "kernel": f"render backward, stage {dom}: comp_bwd + render_bwd_dx_kernel + render_bwd_dw_kernel + "
                                          "bwd_finalize (split backward over saved activations)",
@@ -626,6 +594,8 @@ def main():
                                "measured": "HIP events recorded inside nsr_render_bwd on the launch stream around its kernels "
                                            "(compositor backward, dX, dW, finalize): " + events_from,
                                "algorithmic_flop_per_launch": nec,
+                               "priced_on": "the %.1f rays per launch that are rendered (%d sampled x kept share %.3f) x %d sample points" %
+                                            (rays_rank * rendered_frac, rays_rank, rendered_frac, 32 if dom == "coarse" else 48),
                                "executed_frac": (pts * (EXEC_BWD_MAC[dom] - FWD_MAC[dom]) * 2
                                                  / (ms * 1e-3)) / FP32_PEAK
                                if not (args.stepped_grads_only or tracking) else None,
@@ -634,14 +604,13 @@ def main():
         if dom is not None and "roofline" in res:
             # the kernels of the dominant stage one by one (eager iterations behind a 1 ms wait, like `avg_kernel_ms`), and the whole
             # iteration: necessary FLOP of forward + backward of the timed stage mix over the wall time of the timed region
-            pts = rays_rank * (32 if dom == "coarse" else 48)
             ker = {}
             f = ev_fwd.summary().get(dom)
             if f:
                 ker["forward_pass"] = {"kernel": f"render_fwd_pass_kernel<{dom}>", "ms": round(f[0], 4), "frac": pts * FWD_MAC[dom] * 2 / (f[0] * 1e-3) / FP32_PEAK}
             sp = ev.split().get(dom)
             if sp and dom == "color" and not tracking:
-                dw_nec = DW_NEC_MAC[dom] if not args.stepped_grads_only else DW_NEC_MAC[dom]
+                dw_nec = DW_NEC_MAC[dom]
                 ker["dx"] = {"kernel": "render_bwd_dx_kernel<color>", "ms": round(sp["dx"], 4),
                              "frac": pts * (NEC_MAC[dom] - FWD_MAC[dom] - dw_nec) * 2 / (sp["dx"] * 1e-3) / FP32_PEAK,
                              "executed_frac": pts * 3 * 15360 * 2 / (sp["dx"] * 1e-3) / FP32_PEAK}
@@ -661,7 +630,7 @@ def main():
                                                    "`avg_kernel_ms` / `frac` come from iterations with (start, stop) only")
                 res["roofline"]["furthest_from_peak"] = furthest
             nst = {st_: stages.count(st_) for st_ in set(stages)}
-            flop_iter = sum(cnt * rays_rank * (32 if st_ == "coarse" else 48) * NEC_MAC[st_] * 2 for st_, cnt in nst.items()) / max(1, len(stages))
+            flop_iter = sum(cnt * rays_rank * rendered_frac * (32 if st_ == "coarse" else 48) * NEC_MAC[st_] * 2 for st_, cnt in nst.items()) / max(1, len(stages))
             if not tracking:
                 res["roofline"]["iteration"] = {"necessary_flop_per_iteration": flop_iter, "ms": dt / args.steps * 1e3,
                                                 "frac": flop_iter / (dt / args.steps) / FP32_PEAK,
@@ -673,8 +642,100 @@ def main():
         if shard_check is not None:
             res["shard_check"] = shard_check
         res["kernel_ms"] = {f"render_bwd<{s}>": round(v[0], 4) for s, v in ksum.items()}
-        if not args.no_cpu_baseline and world == 1:
+        if headline and not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(sc, rays_rank, stages_cfg, mix, crop if tracking else None)
+        if not headline:                                          # the short record that rides in the headline's line
+            keep_keys = ("value", "unit", "rendered_rays_per_s", "sampled_rays_per_s", "n_gpus", "steps", "ms_per_step", "scaling", "shard_check",
+                         "graph_capture", "rccl_ranks", "kernel_ms")
+            short = {k: res[k] for k in keep_keys if k in res}
+            short["config"] = {k: res["config"][k] for k in ("workload", "rays_per_gpu", "rays_per_iteration", "rays_rendered_per_iteration",
+                                                              "rays_kept_by_prefilter", "stage_mix", "launch", "timed_windows_ms", "parallelism")
+                               if k in res["config"]}
+            if "roofline" in res:
+                short["roofline"] = {k: res["roofline"][k] for k in ("frac", "avg_kernel_ms", "kernel") if k in res["roofline"]}
+                if "iteration" in res["roofline"]:
+                    short["roofline"]["iteration_frac"] = res["roofline"]["iteration"]["frac"]
+            res = short
+        return res
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="1", choices=sorted(CONFIGS), help="BASELINE.json configuration (default 1 = the headline one)")
+    ap.add_argument("--windows", type=int, default=3, help="the K timed steps are run this many times; the median window is reported")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage", default=None, help="pin every step to one stage (profiling)")
+    ap.add_argument("--rays", type=int, default=None, help="rays per iteration (default: the configuration's)")
+    ap.add_argument("--verify-shards", action="store_true", default=None,
+                    help="multi-GPU self check after the timed region: one iteration with shared fixed pixel draws, the all-reduced "
+                         "loss / grid / decoder / pose gradients against a single-GPU evaluation of the union batch on every rank "
+                         "(default: on whenever more than one rank runs)")
+    ap.add_argument("--no-verify-shards", dest="verify_shards", action="store_false")
+    ap.add_argument("--eager", action="store_true", help="do not capture the iteration in a hipGraph")
+    ap.add_argument("--unfused", action="store_true", help="the drop-in call sequence (get_samples per frame, render_batch_ray, torch loss) instead of mapping_loss")
+    ap.add_argument("--stepped-grads-only", action="store_true",
+                    help="parameter gradients only for the decoder the reference's optimiser steps (colour); default: all, like the reference autograd")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="multi-GPU: weak = the configuration's rays per GPU, strong = in total (default: strong for config 3 / 4, else weak)")
+    ap.add_argument("--render-masked", action="store_true",
+                    help="render the rays the bounding-box pre-filter rejects too and only mask them out of the loss (default: they are "
+                         "removed from the batch like the reference's compaction does, Mapper.py:471-481)")
+    ap.add_argument("--strong-record", dest="strong_record", action="store_true", default=None,
+                    help="after the timed configuration also time BASELINE configs[3] (Apartment, 5000 rays per iteration split over the "
+                         "GPUs: strong scaling) and report it as `strong` in the same line (default: on for the default configuration)")
+    ap.add_argument("--no-strong-record", dest="strong_record", action="store_false")
+    ap.add_argument("--dense-exchange", action="store_true",
+                    help="multi-GPU: all-reduce the whole feature-grid gradients instead of the frustum-selected voxel rows")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))                          # `python bench.py --gpus N`: launch the N ranks ourselves
+    if "WORLD_SIZE" in os.environ and args.gpus > 1 and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}")
+
+    # stdout carries exactly ONE line, the result JSON: anything a library prints there (RCCL's version banner, ...) is
+    # sent to stderr by pointing file descriptor 1 at it; the JSON goes to the saved original descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.verify_shards is None:
+        args.verify_shards = world > 1
+    if world > 1:
+        import signal
+        signal.alarm(int(os.environ.get("NSR_BENCH_DEADLINE_S", "900")))   # a wedged collective must not hang the node: die loudly
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("NSR_SINGLE_DEVICE") == "1":                # CI on a 1-GPU box: every rank on device 0 (with gloo, see below)
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    force_dist = os.environ.get("NSR_FORCE_SHARDED") == "1"        # exercise the RCCL path with a single rank (CI on a 1-GPU box)
+    sharded = world > 1 or force_dist
+    if sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        backend = os.environ.get("NSR_DIST_BACKEND", "nccl")       # "nccl" = RCCL; "gloo" only to exercise the multi-rank
+        if backend == "nccl":                                      # code path where RCCL cannot run (ranks sharing one GPU)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    scaling = args.scaling or ("strong" if args.config in ("3", "4") else "weak")
+    res = measure(args, args.config, scaling, world, rank, dev, sharded, "headline", rays_override=args.rays, stage_override=args.stage)
+    # north_star's second target is written on STRONG scaling of the mapping ray batch (BASELINE configs[3]: Apartment, 5000 rays
+    # per iteration split over the GPUs): that measurement rides in the same line as `strong`, so that the driver's N = 1, 2, 4, 8
+    # runs of the default command give the weak-scaling curve of config 1 (`value`) AND the strong-scaling curve (`strong.value`).
+    want_strong = args.strong_record if args.strong_record is not None else (args.config == "1" and not args.stage and not args.rays and not args.unfused)
+    if want_strong:
+        st = measure(args, "3", "strong", world, rank, dev, sharded, "strong")
+        if res is not None:
+            res["strong"] = st
+    if res is not None:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     if sharded:

@@ -253,15 +253,62 @@ def trilinear(grid: torch.Tensor, p: torch.Tensor, bound: torch.Tensor, lo=F32) 
 # --------------------------------------------------------------------------------------------
 # a8-a10: decoders   (decoder.py:17-30,177-203,262-274,312-342)
 # --------------------------------------------------------------------------------------------
+# How the fp32 matrix products are evaluated.  "mm" = ATen's matmul (what the reference calls; its accumulation order is the host
+# BLAS's).  The other modes exist for ONE purpose -- tools/reference_fp32_ambiguity.py measures how far two LEGITIMATE fp32
+# evaluations of the reference's own operators are apart on a given scene (the floor under any parity gate):
+#   LINEAR_IMPL  "rounded_once": every dot product of a Linear layer accumulated in fp64 and rounded to fp32 once (the most
+#                accurate fp32 evaluation there is; autograd then differentiates through the casts, i.e. the backward products
+#                are rounded once as well)
+#   EMBED_IMPL   "fma_k" / "fma_k_rev": p @ B as an explicit fused-multiply-add chain over the three coordinates in the order
+#                x, y, z (what the HIP kernels do, and bit for bit what MKL's sgemm does for this shape on the build container)
+#                or z, y, x; "product_sum": three rounded products summed left to right (no fused multiply-add).  Forward
+#                values only differ; the backward is autograd's through an identical graph (custom Function below).
+LINEAR_IMPL = "mm"
+EMBED_IMPL = "mm"
+
+
 def _lin(x, P, prefix):
+    if LINEAR_IMPL == "rounded_once" and x.dtype == F32:
+        return (x.to(F64) @ P[prefix + ".weight"].to(F64).t() + P[prefix + ".bias"].to(F64)).to(F32)
     return x @ P[prefix + ".weight"].to(x.dtype).t() + P[prefix + ".bias"].to(x.dtype)
+
+
+def _fma32(a, b, c):
+    """fl32(a * b + c) for fp32 tensors: the product of two fp32 numbers is exact in fp64; the sum is rounded to fp64 and then to
+    fp32 (a double rounding that differs from a true fused multiply-add on ~2^-29 of the inputs: fine for a noise study)"""
+    return (a.to(F64) * b.to(F64) + c.to(F64)).to(F32)
+
+
+class _EmbedArg(torch.autograd.Function):
+    """p @ B with a chosen fp32 evaluation order of the three-term dot products; backward = that of the matmul."""
+
+    @staticmethod
+    def forward(ctx, p, B, impl):
+        ctx.save_for_backward(p, B)
+        x, y, z = p[:, 0:1], p[:, 1:2], p[:, 2:3]
+        bx, by, bz = B[0:1], B[1:2], B[2:3]
+        if impl == "fma_k":
+            return _fma32(z, bz, _fma32(y, by, x * bx))
+        if impl == "fma_k_rev":
+            return _fma32(x, bx, _fma32(y, by, z * bz))
+        if impl == "product_sum":
+            return (x * bx + y * by) + z * bz
+        raise ValueError(impl)
+
+    @staticmethod
+    def backward(ctx, g):
+        p, B = ctx.saved_tensors
+        return g @ B.t(), p.t() @ g, None
 
 
 def mlp_xyz(p: torch.Tensor, c: torch.Tensor, P: Dict[str, torch.Tensor], name: str, lo=F32):
     """``MLP.forward`` (decoder.py:177-203) given the already-sampled feature ``c``.
     h_i = relu(W_i h + b_i) + (U_i c + v_i); after i == 2 the embedding is concatenated in front."""
     pre = name + "_decoder."
-    e = torch.sin(p.to(lo) @ P[pre + "embedder._B"].to(lo))          # decoder.py:26-30,189-191
+    if EMBED_IMPL != "mm" and lo == F32:
+        e = torch.sin(_EmbedArg.apply(p.to(lo), P[pre + "embedder._B"].to(lo), EMBED_IMPL))
+    else:
+        e = torch.sin(p.to(lo) @ P[pre + "embedder._B"].to(lo))      # decoder.py:26-30,189-191
     h = e
     for i in range(5):
         h = torch.relu(_lin(h, P, pre + f"pts_linears.{i}"))

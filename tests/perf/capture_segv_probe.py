@@ -1,3 +1,11 @@
+"""Measurement tooling (not a test, not collected by pytest): the minimal reproducer behind the warning in nice_slam_amd/graphs.py.
+On ROCm 7.2 / torch 2.10 ``hipStreamEndCapture`` dies with SIGSEGV -- instead of reporting unjoined work -- when a captured backward
+reaches an AccumulateGrad node that an EAGER iteration created on another stream (a leaf pose tensor whose loss tensor is still alive).
+    python tests/perf/capture_segv_probe.py <variant>
+<variant> is a string of flags, tested by substring: nocam | onecam | plaincam (which pose leaves feed the rays; default: two cameras
+through get_camera_from_tensor), allzero, nostep, deepcopy, ref (a torch.optim.Adam twin stepped alongside), float (print the losses),
+captured (wrap the iteration in graphs.CapturedStep instead of running it eagerly).  Each flag narrows which leaf drags the eager
+stream into the capture.  Runs on the GPU box only; a variant either finishes or dies (faulthandler shows where)."""
 import sys, os, copy
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

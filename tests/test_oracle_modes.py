@@ -1,0 +1,61 @@
+"""CPU: the facts the large-scene parity gate rests on (tools/reference_fp32_ambiguity.py measures them in full and writes
+profiles/r05_reference_self_disagreement.json).
+ * ATen's ``p @ B`` (decoder.py:29) on this host IS the x,y,z fused-multiply-add chain the HIP kernels evaluate -- bit for bit, at
+   ScanNet-size arguments (|p.B| ~ 1e3 rad, where one fp32 ulp of the argument is 6e-5 in the sine).  A host BLAS with another order
+   would make the oracle a different function: this test says so before a GPU run is spent on it.
+ * The kernel sources under the emulator, ScanNet bound, fine stage (the one case whose gradients miss 1e-4 against the fp32 oracle
+   on the GPU): outputs at the primary gate, every gradient within the absolute cap of the secondary gate."""
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from scene_util import SECONDARY_ABS_CAP, make_scene, oracle_render
+from oracle import nice_oracle as orc
+
+
+def test_aten_embedding_product_is_the_kernels_fma_chain():
+    sc = make_scene(seed=22, n_rays=2000, scene="scannet_0000", fine_scale=1.0)
+    z = torch.linspace(0.1, 6.0, 48, dtype=torch.float64)
+    p = (sc["rays_o"][:, None, :].double() + sc["rays_d"][:, None, :].double() * z[None, :, None]).reshape(-1, 3).float()
+    B = sc["params"]["fine_decoder.embedder._B"]
+    mm = p @ B
+    assert float(mm.abs().max()) > 500.0                                  # ScanNet-size arguments
+    chain = orc._EmbedArg.apply(p, B, "fma_k")
+    assert int((mm != chain).sum()) == 0
+    rev = orc._EmbedArg.apply(p, B, "fma_k_rev")                          # (and the check has teeth: another order differs in ~45 % of the elements)
+    assert int((mm != rev).sum()) > mm.numel() // 10
+
+
+def test_oracle_modes_leave_the_default_untouched():
+    sc = make_scene(seed=3, n_rays=40, small=True)
+    a = oracle_render(sc, "color", backward=True)
+    for emb, lin in (("fma_k", "mm"), ("mm", "rounded_once")):
+        try:
+            orc.EMBED_IMPL, orc.LINEAR_IMPL = emb, lin
+            b = oracle_render(sc, "color", backward=True)
+        finally:
+            orc.EMBED_IMPL, orc.LINEAR_IMPL = "mm", "mm"
+        for k in a:
+            assert rel_err(b[k], a[k]) < 1e-4, (emb, lin, k)
+    c = oracle_render(sc, "color", backward=True)
+    for k in a:
+        assert rel_err(c[k], a[k]) < 1e-6, k                              # (the scatter-add of the grid gradients is not run-to-run deterministic)
+
+
+def test_kernel_sources_at_scannet_bounds_fine_stage():
+    import os
+    if not (os.path.exists("/opt/rocm/lib/llvm/bin/clang++") or shutil.which("clang++")):
+        pytest.skip("no host clang++ for the emulator build")
+    from emu_harness import HostScene, emu_lib
+    s = make_scene(seed=22, n_rays=1500, scene="scannet_0000", fine_scale=1.0)
+    sc = HostScene(emu_lib(), s["grids"], s["params"], s["bound"].numpy())
+    fwd = sc.forward("fine", s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy())
+    res = sc.backward("fine", fwd, s["w"]["depth"].numpy(), s["w"]["var"].numpy(), s["w"]["rgb"].numpy())
+    ref = oracle_render(s, "fine", backward=True)
+    for k in ("depth", "var", "rgb"):
+        assert rel_err(fwd[k], ref[k]) < 1e-4, k
+    worst = max((rel_err(res[k], v), k) for k, v in ref.items() if k not in ("depth", "var", "rgb"))
+    assert worst[0] < SECONDARY_ABS_CAP, worst
