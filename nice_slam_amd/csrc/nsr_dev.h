@@ -63,6 +63,10 @@ NSR_DEV void sched_fence_emb() {
 // keep a loaded value (and thereby its load) alive up to this point without doing anything with it
 NSR_DEV void keep_alive(float v) { asm volatile("" ::"v"(v)); }
 NSR_DEV void keep_alive_d(double v) { asm volatile("" ::"v"(v)); }
+// an opaque copy of a per-lane integer: what is derived from it inside a loop body is recomputed there instead of being hoisted out of
+// the loop and kept in registers across it (the dX kernel's scatter: seven lane-dependent LDS addresses hoisted out of the tile loop
+// were spilled and re-loaded from scratch -- behind `s_waitcnt vmcnt(0)`, i.e. behind all of the previous tile's atomics)
+NSR_DEV int opaque_i(int v) { asm volatile("" : "+v"(v)); return v; }
 // compiler-only memory clobber: stops loop-invariant code motion of loads across loop iterations
 NSR_DEV void loop_fence() { asm volatile("" ::: "memory"); }
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter

@@ -172,6 +172,7 @@ NSR_DEV void sched_fence_emb() {}
 NSR_DEV void keep_alive(float) {}
 NSR_DEV void keep_alive_d(double) {}
 NSR_DEV void loop_fence() {}
+NSR_DEV int opaque_i(int v) { return v; }
 NSR_DEV void block_sync() { emu::block_sync_impl(); }
 
 NSR_DEV void prefetch_line(const float *, float *) {}
