@@ -78,7 +78,9 @@ SplitGeo split_geo(int stage, long long n_rays, int S, int max_blocks) {
     int per_pass = cap / passes;
     if (per_pass < 1) per_pass = 1;
     long long w = (tiles + per_pass - 1) / per_pass;
-    G.waves = (int)(w < 1 ? 1 : (w > nsr::kDxMaxWaves ? nsr::kDxMaxWaves : w));
+    static const int wave_cap = env_int("NSR_DX_MAX_WAVES", nsr::kDxMaxWaves);      // (measurement: fewer waves per dX block)
+    const int wcap = wave_cap < 1 ? 1 : (wave_cap > nsr::kDxMaxWaves ? nsr::kDxMaxWaves : wave_cap);
+    G.waves = (int)(w < 1 ? 1 : (w > wcap ? wcap : w));
     const long long nb = (tiles + G.waves - 1) / G.waves;
     G.nb = (int)(nb < 1 ? 1 : (nb > per_pass ? per_pass : nb));
     long long ni = (long long)per_pass * (dw_mult < 1 ? 1 : dw_mult);
@@ -383,7 +385,9 @@ int nsr_render_fwd(const nsr_render_args *a, void *stream) {
             }
             P.pass_beg[p + 1] = P.pass_beg[p] + nbp;
         }
-        const int waves = (int)(most > nsr::kDxMaxWaves ? nsr::kDxMaxWaves : most);
+        static const int fwd_cap = env_int("NSR_FWD_MAX_WAVES", nsr::kDxMaxWaves);   // (measurement: fewer waves per pass-kernel block)
+        const int fcap = fwd_cap < 1 ? 1 : (fwd_cap > nsr::kDxMaxWaves ? nsr::kDxMaxWaves : fwd_cap);
+        const int waves = (int)(most > fcap ? fcap : most);
         const dim3 rgrid((unsigned)((P.n_rays + rpb - 1) / rpb)), rblock(64 * rpb);
         NSR_LAUNCH(nsr::fwd_sample_kernel, rgrid, rblock, rpb * 64 * 8, stream, P);
         int lds = 0;

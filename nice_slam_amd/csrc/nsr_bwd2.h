@@ -30,8 +30,8 @@ namespace nsr {
 
 constexpr int kDySlots = 10;                  // dY_i k-tile T at slot 2 i + T (same [n_points][16] form as the activation slots)
 constexpr int kDxMaxWaves = 12;
-// per-wave LDS staging of the dX kernel (floats): Tx[16][kTxS] | tab[kScTab] (grid scatter) | P[3][16] | DP[3][16]
-constexpr int kDxTx = 0, kDxTab = kTile * kTxS, kDxP = kDxTab + kScTab, kDxDP = kDxP + 48, kDxStg = kDxDP + 48;
+// per-wave LDS staging of the dX kernel (floats): Tx[16][kTxS] | tab[256] (grid scatter) | P[3][16] | DP[3][16]
+constexpr int kDxTx = 0, kDxTab = kTile * kTxS, kDxP = kDxTab + 256, kDxDP = kDxP + 48, kDxStg = kDxDP + 48;
 static_assert(kDxStg % 4 == 0, "staging regions must stay 16-byte aligned");
 constexpr int kDbPart = 288;                  // d _B partial image of a dX block: [3][96]
 // ------------------------------------------------------------------------------------------------

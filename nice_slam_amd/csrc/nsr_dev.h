@@ -64,8 +64,8 @@ NSR_DEV void sched_fence_emb() {
 NSR_DEV void keep_alive(float v) { asm volatile("" ::"v"(v)); }
 NSR_DEV void keep_alive_d(double v) { asm volatile("" ::"v"(v)); }
 // an opaque copy of a per-lane integer: what is derived from it inside a loop body is recomputed there instead of being hoisted out of
-// the loop and kept in registers across it (the dX kernel's scatter: seven lane-dependent LDS addresses hoisted out of the tile loop
-// were spilled and re-loaded from scratch -- behind `s_waitcnt vmcnt(0)`, i.e. behind all of the previous tile's atomics)
+// the loop and kept in registers across it (the forward's pass kernel at its 168-register cap: lane-dependent LDS / shuffle indices
+// hoisted out of the tile loop were spilled and re-loaded from scratch inside it: 60 -> 28 B of scratch)
 NSR_DEV int opaque_i(int v) { asm volatile("" : "+v"(v)); return v; }
 // compiler-only memory clobber: stops loop-invariant code motion of loads across loop iterations
 NSR_DEV void loop_fence() { asm volatile("" ::: "memory"); }

@@ -103,8 +103,7 @@ NSR_DEV void fwd_pass(const RenderParams &P, int bi, int nbp) {
     float *aux = reinterpret_cast<float *>(lds_base());
     float *wl = aux + AUX_FLOATS;
     int *cnt = reinterpret_cast<int *>(wl + packed_total(KIND));
-    const int lane = tid() & 63, wave = tid() >> 6;
-    const int pt = lane & 15, g = lane >> 4;
+    const int lane0 = tid() & 63, wave = tid() >> 6;
     const DecDev &D = P.dec[KIND];
     const Dbg dbg{P.dbg ? P.dbg + ((long long)bid_x() * 12 + wave) * 64 : nullptr};
     dbg.stamp(0);
@@ -117,11 +116,12 @@ NSR_DEV void fwd_pass(const RenderParams &P, int bi, int nbp) {
     const long long t0 = ntiles * bi / nbp, t1 = ntiles * (bi + 1) / nbp;
     for (;;) {
         int take = 0;
-        if (lane == 0) take = atomic_fetch_add_lds_i(cnt, 1);
+        if (lane0 == 0) take = atomic_fetch_add_lds_i(cnt, 1);
         const long long tile = t0 + shfl_i(take, 0);
         if (tile >= t1) break;
         if (!tile_live(P, tile)) continue;                           // every ray of the tile was removed by the pre-filter
         loop_fence();
+        const int lane = opaque_i(lane0), pt = lane & 15, g = lane >> 4;      // (lane-dependent addresses formed per tile: see opaque_i)
         const long long gp = tile * kTile + pt;
         const bool active = gp < P.n_points_total;
         const double *pp = P.pd + (active ? gp : 0) * 4;

@@ -511,128 +511,12 @@ NSR_DEV void scatter_walk(const GridDev &G, int lane, const float *Tx, const flo
         }
     }
 }
-// ---- round 5: the run sums on the matrix cores ----------------------------------------------------------------------------
-// The walk above spends ~1 200 instructions per tile (profiles/r05_dx_isa.txt: per class 32 LDS reads with their address adds, a
-// dependent select / fma chain over the 16 points and sixteen predicated blocks of exec-mask bookkeeping) to form ~44 run sums.
-// The same sums are ONE small matrix product per parity class:
-//     S_cls[run][ch] = sum_p M_cls[run][p] dc[p][ch],      M_cls[run][p] = w_cls[p] if point p belongs to run `run` of the class, else 0
-// -- 8 v_mfma_f32_16x16x4_f32 per class (four k-steps over the points x two channel tiles), the B operand (dc in "lane = channel"
-// form, read from Tx) shared by all eight classes.  The products with the zero entries are exact and the k-steps run in point
-// order, so a run's sum is the same fma chain as the walk's (first point: w x, then fma).  The result lands as
-// S[run 4 r + g][channel 16 T + j] in element r of lane (j, g): sixteen lanes cover one 64-byte line of a voxel row, the four
-// lane groups four different runs, and runs are numbered so that the first four runs of a class sit in element 0 -- one atomic
-// instruction per (element, channel tile) carries up to four full lines, and an element none of whose runs exists is skipped
-// wave-uniformly.  Run numbers come from ONE ballot per class pair: lane (pt, g) compares the voxel of classes 2 g, 2 g + 1 at its
-// point with the previous point's, and the population count of the start flags below it is the point's run.
-//   tab (ints / floats, per wave): vt[16][8] voxel per (point, class) | wt[8][16] weight | rid[8][16] run of the point |
-//                                  vx[8][16] voxel of run (or -1); the [16] axes of wt / rid are ordered [p & 3][p >> 2] (= the
-//                                  lane group and k-step that read them), of vx [run & 3][run >> 2] (= lane group and element)
-constexpr int kScTab = 512;
-NSR_DEV void scatter_stage_runs(const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab, bool hot) {
-    const int pt = lane & 15, g = lane >> 4;
-    int *vt = reinterpret_cast<int *>(tab);
-    float *wt = tab + 128;
-    int *rid = reinterpret_cast<int *>(tab) + 256, *vx = reinterpret_cast<int *>(tab) + 384;
-    const int pos = (pt & 3) * 4 + (pt >> 2);
-    tx_store(Tx, dc, pt, g);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int k = 2 * g + c, cls = k ^ L.par;
-        vt[pt * 8 + cls] = active ? (corner_vox(L, k) | (hot ? kHotBit : 0)) : -1;
-        wt[cls * 16 + pos] = corner_w(L, k);
-    }
-    wave_fence();
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int cls = 2 * g + c;
-        const int v = vt[pt * 8 + cls], vp = vt[(pt > 0 ? pt - 1 : 0) * 8 + cls];
-        const bool start = pt == 0 || v != vp;
-        const unsigned row = (unsigned)(ballot64(start) >> (16 * g)) & 0xffffu;          // the class's start flags, bit = point
-        const int n = __builtin_popcount(row & ((2u << pt) - 1u)) - 1, nruns = __builtin_popcount(row);
-        rid[cls * 16 + pos] = n;
-        if (start) vx[cls * 16 + (n & 3) * 4 + (n >> 2)] = v;
-        if (pt >= nruns) vx[cls * 16 + pos] = -1;                                           // run slots beyond the last run
-    }
-}
-NSR_DEV void scatter_emit(const GridDev &G, int v, float s0, float s1, int j, int lds_grid, const HotTab &hot) {
-    const int vox = v & ~kHotBit;
-    if (lds_grid >= 0) {
-        float *t = reinterpret_cast<float *>(lds_base()) + lds_grid + vox * kC + j;
-        atomic_add_lds(t, s0);
-        atomic_add_lds(t + 16, s1);
-        return;
-    }
-    if (hot.off >= 0 && (v & kHotBit)) {
-        const int slot = (int)(((unsigned)vox * 2654435761u) >> 26);                     // kHotSlots = 64
-        int tg = lds_load_i(hot_tag(hot) + slot);
-        if (tg == -1) { const int old = atomic_cas_lds_i(hot_tag(hot) + slot, -1, vox); tg = old == -1 ? vox : old; }
-        if (tg == vox) {
-            atomic_add_lds(hot_val(hot) + slot * kC + j, s0);
-            atomic_add_lds(hot_val(hot) + slot * kC + 16 + j, s1);
-            return;
-        }
-    }
-    float *t = G.dfeat + (long long)vox * kC + j;
-    atomic_add_global(t, s0);
-    atomic_add_global(t + 16, s1);
-}
-struct RunSums { f32x4 s0, s1; F4 vv; };
-NSR_DEV RunSums run_sums(const float *tab, int cls, int g, int nrow, const float (&b)[4][2]) {
-    const float *wt = tab + 128, *rid = tab + 256, *vx = tab + 384;
-    const F4 rr = ld4(rid + cls * 16 + 4 * g), ww = ld4(wt + cls * 16 + 4 * g);
-    RunSums R;
-    R.vv = ld4(vx + cls * 16 + 4 * g);
-    const int r4[4] = {__builtin_bit_cast(int, rr.x), __builtin_bit_cast(int, rr.y), __builtin_bit_cast(int, rr.z), __builtin_bit_cast(int, rr.w)};
-    const float w4[4] = {ww.x, ww.y, ww.z, ww.w};
-    R.s0 = f4zero(); R.s1 = f4zero();
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const float a = r4[ks] == nrow ? w4[ks] : 0.f;
-        R.s0 = mfma16(a, b[ks][0], R.s0);
-        R.s1 = mfma16(a, b[ks][1], R.s1);
-    }
-    return R;
-}
-NSR_DEV void run_emit(const GridDev &G, const RunSums &R, int j, int lds_grid, const HotTab &hot) {
-    const int v4[4] = {__builtin_bit_cast(int, R.vv.x), __builtin_bit_cast(int, R.vv.y), __builtin_bit_cast(int, R.vv.z), __builtin_bit_cast(int, R.vv.w)};
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (v4[r] >= 0) scatter_emit(G, v4[r], R.s0[r], R.s1[r], j, lds_grid, hot);
-}
-NSR_DEV void scatter_runs(const GridDev &G, int lane, const float *Tx, const float *tab, int lds_grid, const HotTab &hot) {
-    const int j = lane & 15, g = lane >> 4;
-    float b[4][2];                                          // dc[point 4 ks + g][channel 16 T + j]
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) { b[ks][0] = Tx[(4 * ks + g) * kTxS + j]; b[ks][1] = Tx[(4 * ks + g) * kTxS + 16 + j]; }
-    const int nrow = 4 * (j & 3) + (j >> 2);                // the run output row j stands for (see the element order above)
-    // one class ahead: the atomics of class c are issued under the matrix products of class c + 1 (a rolled loop: unrolled eight
-    // times the scheduler hoists every table read and product chain to the top and the kernel spills)
-    RunSums cur = run_sums(tab, 0, g, nrow, b);
-#pragma unroll 1
-    for (int cls = 1; cls < 8; ++cls) {
-        const RunSums nxt = run_sums(tab, cls, g, nrow, b);
-        run_emit(G, cur, j, lds_grid, hot);
-        cur = nxt;
-    }
-    run_emit(G, cur, j, lds_grid, hot);
-}
 NSR_DEV void scatter_merged(const GridDev &G, const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab,
                             int lds_grid = -1, HotTab hot = HotTab{-1}, bool hot_pt = false) {
-#if defined(NSR_X_SCATTER_WALK)            // A/B build: the round-4 walk (tools/build_ts.sh ... -DNSR_X_SCATTER_WALK)
     scatter_stage(L, lane, dc, active, Tx, tab, hot.off >= 0 && hot_pt);
     wave_fence();
     scatter_walk(G, lane, Tx, tab, lds_grid, hot);
     wave_fence();
-#else
-    lane = opaque_i(lane);                      // (the lane-dependent table addresses are formed here, per tile: see opaque_i)
-    const bool use_hot = hot.off >= 0 && hot_pt && active;
-    scatter_stage_runs(L, lane, dc, active, Tx, tab, use_hot);
-    wave_fence();
-    // two tiles of three hold no sample near a camera: their runs skip the table probe altogether (wave-uniform)
-    if (hot.off >= 0 && ballot64(use_hot) != 0ull) scatter_runs(G, lane, Tx, tab, lds_grid, hot);
-    else scatter_runs(G, lane, Tx, tab, lds_grid, HotTab{-1});
-    wave_fence();
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------

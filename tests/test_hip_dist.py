@@ -235,3 +235,11 @@ def test_bench_gpus_2_spawns_two_ranks_and_checks_its_shards():
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak", d
     assert d["shard_check"]["ok"], d["shard_check"]
     assert d["config"]["rays_per_iteration"] == 2 * d["config"]["rays_per_gpu"]
+    # `value` counts the rays that are rendered (the pre-filter's kept share of the sampled ones); the sampled rate rides beside it
+    assert 0.5 < d["config"]["rays_kept_by_prefilter"] <= 1.0
+    assert abs(d["value"] - d["sampled_rays_per_s"] * d["config"]["rays_kept_by_prefilter"]) <= 1e-6 * d["value"]
+    # the strong-scaling record of the same line (north_star: BASELINE configs[3], the Apartment batch of 5000 rays SPLIT over the GPUs)
+    st = d["strong"]
+    assert st["scaling"] == "strong" and st["n_gpus"] == 2 and st["config"]["rays_per_iteration"] == 5000 and st["config"]["rays_per_gpu"] == 2500, st
+    assert st["shard_check"]["ok"], st["shard_check"]
+    assert st["value"] > 0 and st["ms_per_step"] > 0
