@@ -295,8 +295,6 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
         const int first = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE, last = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : P.stage;
         nsr::FinalParams R;
         R.stride = P.partial_stride; R.overwrite = b->overwrite_dparams ? 1 : 0;
-        static const int x_fin = env_int("NSR_X_FIN", 0);
-        R.x = x_fin;
         int rows = 0, nblocks = 0;
         for (int s = first; s <= last; ++s) {
             if (!P.dec[s].dparams) continue;
@@ -304,16 +302,15 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
             nsr::FinalJob &J = R.job[rows++];
             J.images = P.partials + (long long)P.dw_beg[pass] * P.partial_stride;
             J.dbpart = P.dbpart + (long long)pass * G.nb * nsr::kDbPart;
-            J.params = P.dec[s].params; J.dparams = P.dec[s].dparams;
+            J.dparams = P.dec[s].dparams;
             J.kind = s; J.nimg = P.dw_beg[pass + 1] - P.dw_beg[pass]; J.ndx = G.nb;
-            const int dbeg = s == NSR_COARSE ? 0 : nsr::xyz_w(nsr::cdim_of(s), 0);
-            const int nb = (nsr::param_total(s) - dbeg + 63) / 64 + 5 + (s == NSR_COARSE ? 0 : 5 * nsr::cdim_of(s) / 4 + 5);
+            const int nb = (nsr::param_total(s) + 63) / 64;
             nblocks = nb > nblocks ? nb : nblocks;
         }
-        for (int r = rows; r < 3; ++r) R.job[r] = nsr::FinalJob{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+        for (int r = rows; r < 3; ++r) R.job[r] = nsr::FinalJob{nullptr, nullptr, nullptr, 0, 0, 0};
         // (512 threads = four resident blocks per CU instead of two was measured: 17.4 vs 15.1 us -- the kernel is a chain of round trips, not a queue of blocks)
         static const int fin_threads = env_int("NSR_FIN_THREADS", 1024);
-        NSR_LAUNCH(nsr::bwd_finalize_kernel, dim3(nblocks, rows), dim3(fin_threads), (2048 + 32 + 1024) * 4, stream, R);
+        NSR_LAUNCH(nsr::bwd_finalize_kernel, dim3(nblocks, rows), dim3(fin_threads), fin_threads * 4, stream, R);
     }
     if (b->ev_stop) nsr::rt_record(b->ev_stop, stream);
     return finish("nsr_render_bwd(split)");

@@ -624,8 +624,75 @@ struct DwXyzWave {
         }
     }
     static constexpr int hid_of(int j) { return j == 1 ? XW1 : (j == 2 ? XW2 : (j == 3 ? XW3H : XW4)); }
-    static constexpr int u_of(int j) { return j == 1 ? XU0 : (j == 2 ? XU1 : (j == 3 ? XU2 : XU3)); }      // G_j sits where dU_{j-1} lives
-    NSR_DEV void flush(float *img, int lane) {
+    // ---- flush.  Round 5: the fc_c gradients leave the block finished.  dU_{j-1} = W_j^T G_j and dv_{j-1} = W_j^T db_j used to be
+    // formed by the finalize kernel from the SUMMED G / db (its 45 fc_c blocks per decoder fetched 16 of every 64 bytes and were its
+    // longest chain); the product is linear, so every block applies W_j^T to its own partial G / db here -- 16 + 8 MFMAs per wave,
+    // once per block -- and finalize is a plain full-line sum over the images.  Row tile ROW of G_j (this wave's accumulators) is a
+    // K-slice of the product: D[k][c] = sum_o W_j[16 ROW + o][k] G[o][c].  With the K index ordered o = 4 g + s the B operand of
+    // k-step s is the accumulator element s the lane already holds (no shuffle); the A operand W_j[16 ROW + 4 g + s][16 Tk + i] comes
+    // straight from the parameter blob.  The two row tiles of a layer meet through LDS (the ring is free by then: block barrier).
+    static constexpr int wt_off(int j) { return xyz_w(CD, j) + (j == 3 ? kE : 0); }      // pts_linears.j weight, hidden-state columns
+    struct WtA { float a[2][4]; };
+    NSR_DEV static WtA wt_load(const float *params, int j, int row, int i, int g) {
+        WtA A;
+#pragma unroll
+        for (int Tk = 0; Tk < 2; ++Tk)
+#pragma unroll
+            for (int sI = 0; sI < 4; ++sI) A.a[Tk][sI] = params[wt_off(j) + (16 * row + 4 * g + sI) * xyz_in(j) + 16 * Tk + i];
+        return A;
+    }
+    // LDS scratch of the flush (floats from the ring's base): [layer j - 1][Tk][Tc][lane][4] products of row tile 1 | [j - 1][32] dv
+    static constexpr int kCombB = 4 * 2 * NC * 256;
+    // dv partial of layer j from this wave's bias sums `db` (every lane (i, *) holds db[16 row + i]): column 0 of the same product
+    NSR_DEV static void dv_part(const WtA &A, float db, int lane, f32x4 (&out)[2]) {
+        const int i = lane & 15, g = lane >> 4;
+        out[0] = f4zero(); out[1] = f4zero();
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) {
+            const float bsel = shfl(db, 4 * g + sI);              // db[16 row + 4 g + s], wanted in column 0 only
+            const float bv = i == 0 ? bsel : 0.f;
+            out[0] = mfma16(A.a[0][sI], bv, out[0]);
+            out[1] = mfma16(A.a[1][sI], bv, out[1]);
+        }
+    }
+    f32x4 pu[2][4];            // W_GJ^T G_GJ, this wave's row-tile share: [Tk][Tc]
+    f32x4 pv[2], pv2[2];       // W^T db shares of the layers whose bias sums this wave owns (WJ, W2J)
+    NSR_DEV void flush_products(const float *params, float *comb, int lane) {
+        const int i = lane & 15, g = lane >> 4;
+        const WtA A = wt_load(params, GJ, ROW, i, g);
+#pragma unroll
+        for (int Tk = 0; Tk < 2; ++Tk)
+#pragma unroll
+            for (int Tc = 0; Tc < NC; ++Tc) {
+                f32x4 acc = f4zero();
+#pragma unroll
+                for (int sI = 0; sI < 4; ++sI) acc = mfma16(A.a[Tk][sI], gg[Tc][sI], acc);
+                pu[Tk][Tc] = acc;
+            }
+        if (WJ) {                                                   // (WJ == GJ where it is set: the same operand)
+            const float db = red_g4(vb);
+            dv_part(A, db, lane, pv);
+        }
+        if (W2J) {
+            const WtA A2 = wt_load(params, W2J, ROW, i, g);
+            const float db2 = red_g4(vb2);
+            dv_part(A2, db2, lane, pv2);
+        }
+        if (ROW == 1) {                                             // hand the share to the wave of row tile 0
+#pragma unroll
+            for (int Tk = 0; Tk < 2; ++Tk)
+#pragma unroll
+                for (int Tc = 0; Tc < NC; ++Tc) st4(comb + (((GJ - 1) * 2 + Tk) * NC + Tc) * 256 + lane * 4, to_F4(pu[Tk][Tc]));
+            if (i == 0) {
+#pragma unroll
+                for (int Tk = 0; Tk < 2; ++Tk) {
+                    if (WJ) st4(comb + kCombB + (WJ - 1) * 32 + 16 * Tk + 4 * g, to_F4(pv[Tk]));
+                    if (W2J) st4(comb + kCombB + (W2J - 1) * 32 + 16 * Tk + 4 * g, to_F4(pv2[Tk]));
+                }
+            }
+        }
+    }
+    NSR_DEV void flush(float *img, const float *params, const float *comb, int lane) {
         const int i = lane & 15, g = lane >> 4;
         if (kWe) {
             img_tile(img, xyz_mat(CD, XW0), 0, WAVE, we[0], i, g); img_tile(img, xyz_mat(CD, XW0), 1, WAVE, we[1], i, g);
@@ -645,21 +712,67 @@ struct DwXyzWave {
             const float v = red_g4(vb2);
             if (g == 0) img[bias_off(KIND, W2J) + 16 * ROW + i] = v;
         }
+        if (ROW == 0) {
+            // dU_{GJ-1} = this share + row tile 1's: fc_c.(GJ-1).weight[k = 16 Tk + 4 g + r][c = 16 Tc + i]
 #pragma unroll
-        for (int Tc = 0; Tc < NC; ++Tc) img_tile(img, xyz_mat(CD, u_of(GJ)), ROW, Tc, gg[Tc], i, g);
+            for (int Tk = 0; Tk < 2; ++Tk)
+#pragma unroll
+                for (int Tc = 0; Tc < NC; ++Tc) {
+                    const f32x4 o = pu[Tk][Tc] + to_v(ld4(comb + (((GJ - 1) * 2 + Tk) * NC + Tc) * 256 + lane * 4));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) img[xyz_fcw(CD, GJ - 1) + (16 * Tk + 4 * g + r) * CD + 16 * Tc + i] = o[r];
+                }
+            if (i == 0) {
+#pragma unroll
+                for (int Tk = 0; Tk < 2; ++Tk) {
+                    if (WJ) {
+                        const f32x4 o = pv[Tk] + to_v(ld4(comb + kCombB + (WJ - 1) * 32 + 16 * Tk + 4 * g));
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) img[xyz_fcb(CD, WJ - 1) + 16 * Tk + 4 * g + r] = o[r];
+                    }
+                    if (W2J) {
+                        const f32x4 o = pv2[Tk] + to_v(ld4(comb + kCombB + (W2J - 1) * 32 + 16 * Tk + 4 * g));
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) img[xyz_fcb(CD, W2J - 1) + 16 * Tk + 4 * g + r] = o[r];
+                    }
+                }
+            }
+        }
         if (kOut) {
+            float gsum[NO][NC], bsum[NO];
 #pragma unroll
             for (int n = 0; n < NO; ++n) {
 #pragma unroll
                 for (int T = 0; T < 2; ++T) { const float v = red_g4(wo[n][T]); if (g == 0) img[wo_off(KIND) + n * 32 + 16 * T + i] = v; }
                 // every lane of a point group summed the same d_out: one lane per group
-                const float vbo = red_g4(bo[n]);
-                if (lane == 0) img[bo_off(KIND) + n] = vbo;
+                bsum[n] = red_g4(bo[n]);
+                if (lane == 0) img[bo_off(KIND) + n] = bsum[n];
 #pragma unroll
-                for (int Tc = 0; Tc < NC; ++Tc) { const float v = red_g4(go[n][Tc]); if (g == 0) img[xyz_fcw(CD, 4) + n * CD + 16 * Tc + i] = v; }
+                for (int Tc = 0; Tc < NC; ++Tc) gsum[n][Tc] = red_g4(go[n][Tc]);       // g_out[n][c = 16 Tc + i], in every lane group
             }
             if (NOUT == 4 && lane < 32) img[wo_off(KIND) + 3 * 32 + lane] = 0.f;      // decoder.py:341: the 4th colour output is discarded
             if (NOUT == 4 && lane == 0) img[bo_off(KIND) + 3] = 0.f;
+            // fc_c.4: dU_4 = Wo^T g_out, dv_4 = Wo^T d bo (the output layer has <= 3 live rows: plain fma, lane group g takes rows 8 g .. 8 g + 7)
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int k = 8 * g + kk;
+                float wk[NO];
+#pragma unroll
+                for (int n = 0; n < NO; ++n) wk[n] = params[wo_off(KIND) + n * 32 + k];
+#pragma unroll
+                for (int Tc = 0; Tc < NC; ++Tc) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int n = 0; n < NO; ++n) v = fmaf(wk[n], gsum[n][Tc], v);
+                    img[xyz_fcw(CD, 4) + k * CD + 16 * Tc + i] = v;
+                }
+                if (i == 0) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int n = 0; n < NO; ++n) v = fmaf(wk[n], bsum[n], v);
+                    img[xyz_fcb(CD, 4) + k] = v;
+                }
+            }
         }
     }
 };
@@ -715,7 +828,8 @@ struct DwNoxWave {
             for (int q = 0; q < 4; ++q) { wo[0] = fmaf(o.dn[q], o.x[0][q], wo[0]); wo[1] = fmaf(o.dn[q], o.x[1][q], wo[1]); bo += o.dn[q]; }
         }
     }
-    NSR_DEV void flush(float *img, int lane) {
+    NSR_DEV void flush_products(const float *, float *, int) {}
+    NSR_DEV void flush(float *img, const float *, const float *, int lane) {
         const int i = lane & 15, g = lane >> 4;
         if (kMat) {
             const Mat m = nox_mat(WAVE);
@@ -776,7 +890,12 @@ NSR_DEV void dw_compute(const RenderParams &P, W &Wv, float *ring, int *ctl, flo
         }
         flag_store(ctl + kDwLoaders + wave, k + 1);                          // (release: the slot's reads have returned)
     }
-    Wv.flush(img, lane);
+    // flush: every wave of the block is done with the ring (barrier), the row-tile pairs exchange their W^T products through it
+    // (barrier), the images are written.  The loader waves take part in both barriers (dw_loader).
+    block_sync();
+    Wv.flush_products(P.dec[KIND].params, ring, lane);
+    block_sync();
+    Wv.flush(img, P.dec[KIND].params, ring, lane);
 }
 
 template <int KIND>
@@ -810,6 +929,8 @@ NSR_DEV void dw_loader(const RenderParams &P, float *ring, int *ctl, int j, int 
     }
     dma_wait<0>();
     flag_store(ctl + j, m);
+    block_sync();                                                            // the compute waves' flush (dw_compute)
+    block_sync();
 }
 
 template <int KIND>
@@ -850,24 +971,20 @@ NSR_KERNEL NSR_BOUNDS(64 * kDwWaves) void render_bwd_dw_kernel(const RenderParam
 }
 
 // ------------------------------------------------------------------------------------------------
-// finalize: dparams (+)= f(sum of the partial images).  grid = (blocks, decoders with gradients), 1024 threads.
-//   blocks [0, nd):        64 directly accumulated parameters each (pts_linears, output_linear; everything for MLP_no_xyz)
-//   blocks [nd, nd + 5):   d embedder._B from the dX kernel's partials (64 each)
-//   blocks [nd + 5, + 5 c_dim / 4):  fc_c.i, four feature columns each: dU_i = W_{i+1}^T G_{i+1} (G summed from the images,
-//                          where it sits in dU_i's place);  i = 4: Wo^T g_out
-//   the next 5 blocks:     dv_i = W_{i+1}^T db_{i+1};  i = 4: Wo^T d bo
+// finalize: dparams (+)= sum of the partial images.  grid = (blocks, decoders with gradients), 1024 threads: block b owns the 64
+// parameters [64 b, 64 b + 64) of the flat blob, its 16 waves take slices of the image list.  Every parameter is a plain sum over the
+// dW blocks' images (round 5: the dW blocks apply W^T to their G / db shares themselves, see DwXyzWave::flush_products) except
+// embedder._B, whose partials come from the dX blocks ([ndx][3][96]).
 // ------------------------------------------------------------------------------------------------
 struct FinalJob {
     const float *images;     // [nimg][stride]
     const float *dbpart;     // [ndx][kDbPart]
-    const float *params;     // flat parameter blob (the 32x32 matrices of the transforms)
     float *dparams;
     int kind, nimg, ndx;
 };
 struct FinalParams {
     FinalJob job[3];
     int stride, overwrite;
-    int x;                   // measurement switches (NSR_X_FIN): 1 = no plain-sum blocks, 2 = no fc_c blocks
 };
 NSR_DEV void final_store(const FinalParams &R, float *p, float v) { *p = R.overwrite ? v : *p + v; }
 // sum of p[k * stride] over k = first, first + step, ... < n, in that order, with sixteen loads in flight at a time (the kernel
@@ -886,92 +1003,28 @@ NSR_DEV float strided_sum(const float *p, long long stride, int first, int step,
 
 NSR_KERNEL void bwd_finalize_kernel(const FinalParams R) {
     const FinalJob J = R.job[bid_y()];
-    float *red = reinterpret_cast<float *>(lds_base());            // [2048 + 32 + 1024] floats
-    const int kind = J.kind, cd = cdim_of(kind), nout = nout_of(kind);
-    const bool xyz = kind != NSR_COARSE;
-    const int dbeg = xyz ? xyz_w(cd, 0) : 0, total = param_total(kind);
-    const int nd = (total - dbeg + 63) / 64;
-    const int b = bid_x(), t = tid(), nt = nthreads();
+    float *red = reinterpret_cast<float *>(lds_base());            // [nthreads]
+    const int kind = J.kind, cd = cdim_of(kind);
+    const int total = param_total(kind);
+    const int t = tid(), nt = nthreads();
     const int lane = t & 63, slice = t >> 6, nslice = nt >> 6;
-    if (b < nd + 5) {
-        // plain sums: 64 parameters x nslice slices of the image list
-        if (R.x & 1) return;
-        const bool isB = b >= nd;
-        if (isB && !xyz) return;
-        const int e = (isB ? (b - nd) : b) * 64 + lane;             // element within the region
-        const int n = isB ? 3 * kE : total - dbeg;
-        float s = 0.f;
-        if (e < n) {
-            if (isB) {
-                const int d = e / kE, ch = e - d * kE;
-                s = strided_sum(J.dbpart + d * 96 + ch, kDbPart, slice, nslice, J.ndx);
-            } else {
-                s = strided_sum(J.images + dbeg + e, R.stride, slice, nslice, J.nimg);
-            }
+    const int e = bid_x() * 64 + lane;                             // parameter index in the flat blob
+    if (bid_x() * 64 >= total) return;                             // (grid sized for the largest decoder of the stage)
+    float s = 0.f;
+    if (e < total) {
+        const int rb = kind != NSR_COARSE ? e - xyz_B(cd) : -1;    // embedder._B[d][ch] sits at xyz_B + d * 93 + ch
+        if (rb >= 0 && rb < 3 * kE) {
+            const int d = rb / kE, ch = rb - d * kE;
+            s = strided_sum(J.dbpart + d * 96 + ch, kDbPart, slice, nslice, J.ndx);
+        } else {
+            s = strided_sum(J.images + e, R.stride, slice, nslice, J.nimg);
         }
-        red[t] = s;
-        block_sync();
-        if (slice == 0 && e < n) {
-            for (int k = 1; k < nslice; ++k) s += red[k * 64 + lane];
-            final_store(R, J.dparams + (isB ? xyz_B(cd) : dbeg) + e, s);
-        }
-        return;
     }
-    if (!xyz || (R.x & 2)) return;
-    // fc_c layer i, feature columns [4 chunk, 4 chunk + 4): S[o][c] = sum over the images of G (rows o < nrow of dU_i's place),
-    // 128 elements x 8 slices of the image list; chunk 0 also forms the bias sums db (32 slices) and dv_i
-    // (the bias sums db_{i+1} and dv_i = W_{i+1}^T db_{i+1} have blocks of their own, behind the 5 per chunk blocks: inside chunk 0 their
-    //  loads were issued behind the G sums -- a second memory round trip in the kernel's longest block; 13.4 -> see profiles/r04_dx_experiments.txt)
-    const int per = cd / 4, q5 = b - nd - 5;
-    const bool bias_blk = q5 >= 5 * per;
-    const int i = bias_blk ? q5 - 5 * per : q5 / per, chunk = bias_blk ? -1 : q5 % per;
-    if (i > 4) return;                                              // (grid sized for the largest decoder of the stage)
-    // the colour decoder's 4th output is discarded (decoder.py:341): three rows
-    const int nrow = i < 4 ? 32 : (nout == 1 ? 1 : 3), goff = xyz_fcw(cd, i);
-    const int e = t & 127, o = e >> 2, c = 4 * chunk + (e & 3), sl = t >> 7, nsl = nt >> 7;       // 128 elements x nsl slices
-    // W[o][k]: pts_linears.(i+1).weight (hidden-state columns) or output_linear.weight -- staged in LDS while the image sums
-    // are in flight (read straight from memory inside the 32-step product it was 32 dependent L2 round trips: ~10 us)
-    const int woff = i < 4 ? xyz_w(cd, i + 1) + (i == 2 ? kE : 0) : xyz_wo(cd);
-    const int wstr = i < 4 ? xyz_in(i + 1) : 32;
-    float *wl = red + 2048 + 32;                                    // [32][32]
-    for (int q = t; q < 1024; q += nt) wl[q] = (q >> 5) < nrow ? J.params[woff + (q >> 5) * wstr + (q & 31)] : 0.f;
-    if (bias_blk) {
-        const int ob = t & 31, sb = t >> 5;                         // 32 bias elements x nt / 32 slices
-        const int boff = i < 4 ? xyz_b(cd, i + 1) : xyz_bo(cd, nout);
-        float sbv = 0.f;
-        if (ob < nrow) sbv = strided_sum(J.images + boff + ob, R.stride, sb, nt >> 5, J.nimg);
-        red[1024 + t] = sbv;
-        block_sync();
-        if (t < 32) {
-            float sv = 0.f;
-            for (int k = 0; k < (nt >> 5); ++k) sv += red[1024 + k * 32 + t];
-            red[2048 + t] = sv;
-        }
-        block_sync();
-        if (t < 32) {
-            float sv = 0.f;
-            for (int oo = 0; oo < nrow; ++oo) sv = fmaf(wl[oo * 32 + t], red[2048 + oo], sv);
-            final_store(R, J.dparams + xyz_fcb(cd, i) + t, sv);
-        }
-        return;
-    }
-    {
-        float sg = 0.f;
-        if (o < nrow) sg = strided_sum(J.images + goff + o * cd + c, R.stride, sl, nsl, J.nimg);
-        red[t] = sg;
-    }
+    red[t] = s;
     block_sync();
-    if (t < 128) {
-        float sg = red[t];
-        for (int k = 1; k < nsl; ++k) sg += red[k * 128 + t];
-        red[t] = sg;
-    }
-    block_sync();
-    if (t < 128) {
-        const int k = t >> 2, cc = t & 3;
-        float sv = 0.f;
-        for (int oo = 0; oo < nrow; ++oo) sv = fmaf(wl[oo * 32 + k], red[oo * 4 + cc], sv);
-        final_store(R, J.dparams + goff + k * cd + 4 * chunk + cc, sv);
+    if (slice == 0 && e < total) {
+        for (int k = 1; k < nslice; ++k) s += red[k * 64 + lane];
+        final_store(R, J.dparams + e, s);
     }
 }
 
