@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define NSR_VERSION 6
+#define NSR_VERSION 7
 
 /* stages of NICE.forward (decoder.py:312-342) */
 enum { NSR_STAGE_COARSE = 0, NSR_STAGE_MIDDLE = 1, NSR_STAGE_FINE = 2, NSR_STAGE_COLOR = 3 };
@@ -204,6 +204,20 @@ int nsr_get_samples_window_draw(int64_t *indices_out, uint64_t *rng_state, int32
                                 int32_t W1, int32_t W_full, float fx, float fy, float cx, float cy, const nsr_frame *frames,
                                 float *rays_o, float *rays_d, float *out_depth, float *out_color,
                                 const double *bound_lo, const double *bound_hi, uint8_t *keep, float *kept_max, void *stream);
+/* The window kernel as the FIRST launch of a fused iteration (ABI 7): beside the sampling it zero-fills the iteration's gradient
+ * buffer -- x-blocks of its own that store zeros over zero[0 .. zero_floats) (16-byte aligned) while the others place the rays:
+ * the fill is bandwidth, the sampling a chain of latencies, side by side they cost the longer of the two instead of two launches
+ * (src/Mapper.py:503: `loss.backward()` accumulates into zeroed .grad tensors; Mapper.py:437-481 for the sampling) -- and its last
+ * block to finish writes the iteration's 16-byte header {loss accumulator (fp64) = 0, kept_max, 0.f}: nothing has to be zeroed
+ * before the launch.  indices: [K * n] or NULL (then drawn as in nsr_get_samples_window_draw and written to indices_out).
+ * state: four uint64 on the device -- {seed, calls so far, 0, 0} -- owned by the caller; words 2 and 3 are the launch's hand-off
+ * (blocks done, bit pattern of the running maximum) and are zero again when it ends; two launches that share a state must not
+ * overlap.  K, n >= 1. */
+int nsr_get_samples_window_fused(const int64_t *indices, int64_t *indices_out, uint64_t *state, int32_t K, int64_t n, int32_t H0, int32_t H1,
+                                 int32_t W0, int32_t W1, int32_t W_full, float fx, float fy, float cx, float cy, const nsr_frame *frames,
+                                 float *rays_o, float *rays_d, float *out_depth, float *out_color,
+                                 const double *bound_lo, const double *bound_hi, uint8_t *keep, float *header,
+                                 float *zero, int64_t zero_floats, void *stream);
 /* gradient of the K poses from the ray gradients of such a window (autograd of src/common.py:74-88; local BA,
  * src/Mapper.py:417-419,441-453): d_c2w + k * out_stride holds rows 0..2 of pose k's gradient, row-major (12 floats;
  * out_stride = 12 for 3x4 poses, 16 for 4x4 ones whose last row the caller zero-fills). */

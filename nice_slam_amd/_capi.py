@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401  -- must be loaded first: libnsr.so binds to the HIP runtime (libamdhip64.so.7) torch already mapped
 
 MAX_SAMPLES = 64
-ABI_VERSION = 6
+ABI_VERSION = 7
 STAGE_ID = {"coarse": 0, "middle": 1, "fine": 2, "color": 3}
 SLOT_NAMES = ("coarse", "middle", "fine", "color")
 
@@ -102,6 +102,10 @@ SYMBOLS = (
                                               C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(NsrFrame),
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("nsr_get_samples_window_fused", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                               C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(NsrFrame),
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     ("nsr_pose_grad", C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     ("nsr_masked_adam_multi", C.c_int, [C.POINTER(NsrAdamGrid), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32,

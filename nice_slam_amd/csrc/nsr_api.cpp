@@ -537,7 +537,8 @@ namespace {
 int window_launch(const int64_t *indices, int64_t *indices_out, uint64_t *rng, int32_t K, int64_t n, int32_t H0, int32_t H1, int32_t W0, int32_t W1,
                   int32_t W_full, float fx, float fy, float cx, float cy, const nsr_frame *frames,
                   float *rays_o, float *rays_d, float *out_depth, float *out_color,
-                  const double *bound_lo, const double *bound_hi, uint8_t *keep, float *kept_max, void *stream) {
+                  const double *bound_lo, const double *bound_hi, uint8_t *keep, float *kept_max, void *stream,
+                  float *hdr = nullptr, float *zero = nullptr, int64_t zero_floats = 0) {
     if (K < 0 || K > NSR_MAX_WINDOW) return fail("nsr_get_samples_window: K must be in [0, 32]");
     if (n < 0 || H1 <= H0 || W1 <= W0 || W_full < W1) return fail("nsr_get_samples_window: bad crop");
     if (K == 0 || n == 0) return 0;
@@ -560,7 +561,18 @@ int window_launch(const int64_t *indices, int64_t *indices_out, uint64_t *rng, i
     for (int a = 0; a < 3; ++a) { P.lo[a] = bound_lo[a]; P.hi[a] = bound_hi[a]; }
     P.keep = keep; P.kept_max = kept_max;
     const int tb = 256;
-    NSR_LAUNCH(nsr::get_samples_window_kernel, dim3((unsigned)((n + tb - 1) / tb), K), dim3(tb), 0, stream, P);
+    const long long sbx = (n + tb - 1) / tb;
+    P.sample_bx = (int)sbx;
+    long long fbx = 0;
+    if (hdr) {
+        // fill blocks beside the sampling blocks: 32 KB each (eight 16-byte stores per thread), at most ~2048 over the K grid rows
+        if (zero_floats < 0 || (zero_floats > 0 && (!zero || (reinterpret_cast<uintptr_t>(zero) & 15)))) return fail("nsr_get_samples_window_fused: zero span must be 16-byte aligned");
+        P.hdr = hdr; P.zero = zero; P.zero_n = zero_floats;
+        long long want = (zero_floats * 4 + 32767) / 32768;
+        if (want > 2048) want = 2048;
+        fbx = (want + K - 1) / K;
+    }
+    NSR_LAUNCH(nsr::get_samples_window_kernel, dim3((unsigned)(sbx + fbx), K), dim3(tb), 0, stream, P);
     return finish("nsr_get_samples_window");
 }
 }  // namespace
@@ -581,6 +593,18 @@ int nsr_get_samples_window_draw(int64_t *indices_out, uint64_t *rng_state, int32
                                 const double *bound_lo, const double *bound_hi, uint8_t *keep, float *kept_max, void *stream) {
     return window_launch(nullptr, indices_out, rng_state, K, n, H0, H1, W0, W1, W_full, fx, fy, cx, cy, frames, rays_o, rays_d, out_depth,
                          out_color, bound_lo, bound_hi, keep, kept_max, stream);
+}
+
+int nsr_get_samples_window_fused(const int64_t *indices, int64_t *indices_out, uint64_t *state, int32_t K, int64_t n, int32_t H0, int32_t H1,
+                                 int32_t W0, int32_t W1, int32_t W_full, float fx, float fy, float cx, float cy, const nsr_frame *frames,
+                                 float *rays_o, float *rays_d, float *out_depth, float *out_color,
+                                 const double *bound_lo, const double *bound_hi, uint8_t *keep, float *header,
+                                 float *zero, int64_t zero_floats, void *stream) {
+    if (!state || !header) return fail("nsr_get_samples_window_fused: null pointer");
+    if (!indices && !indices_out) return fail("nsr_get_samples_window_fused: indices or indices_out is required");
+    if (K == 0 || n == 0) return fail("nsr_get_samples_window_fused: empty window (the header and the zero span would stay unwritten)");
+    return window_launch(indices, indices ? nullptr : indices_out, state, K, n, H0, H1, W0, W1, W_full, fx, fy, cx, cy, frames, rays_o, rays_d,
+                         out_depth, out_color, bound_lo, bound_hi, keep, nullptr, stream, header, zero, zero_floats);
 }
 
 int nsr_pose_grad(const int64_t *indices, int32_t K, int64_t n, int32_t H0, int32_t H1, int32_t W0, int32_t W1,

@@ -591,7 +591,11 @@ struct DwXyzWave {
             f32x4 qx, qy, qz;
 #pragma unroll
             for (int q = 0; q < 4; ++q) { qx[q] = o.pos[q].x; qy[q] = o.pos[q].y; qz[q] = o.pos[q].z; }
+#if defined(NSR_X_DW_NOSIN)              // A/B build (tools/build_ts.sh): what the sines cost this kernel (wrong numbers, timing only)
+            e = vfma(qz, splat(bz), vfma(qy, splat(by), qx * splat(bx)));
+#else
             e = sin_acc4(vfma(qz, splat(bz), vfma(qy, splat(by), qx * splat(bx))));     // decoder.py:29-30
+#endif
             if (kB0) { vb0[0] += sum4(o.y[0]); vb0[1] += sum4(o.y[1]); }
         }
         if (WJ) vb += sum4(o.a1);

@@ -174,6 +174,15 @@ NSR_DEV void atomic_max_pos(float *p, float v) {
     __hip_atomic_fetch_max((nsr_guint *)reinterpret_cast<unsigned *>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// returning flavours (the launch-wide hand-off of the window kernel: the value is back before the wave goes on)
+NSR_DEV unsigned atomic_fetch_max_u32(unsigned *p, unsigned v) {
+    return __hip_atomic_fetch_max((nsr_guint *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+NSR_DEV unsigned atomic_exchange_u32(unsigned *p, unsigned v) {
+    return __hip_atomic_exchange((nsr_guint *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+NSR_DEV void keep_alive_u(unsigned v) { asm volatile("" ::"v"(v)); }
+
 // One byte at a WAVE-UNIFORM address through the scalar cache (s_load_dword of the aligned word): counted by lgkmcnt, not by the
 // in-order vector-memory counter -- a vector load issued behind a wave's scatter atomics could only be waited for together
 // with all of them.  The array must not be written by the launch that reads it this way.

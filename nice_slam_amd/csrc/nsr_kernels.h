@@ -1226,9 +1226,9 @@ NSR_DEV unsigned philox_word(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
 struct WindowParams {
     const long long *indices;          // [K][n]; NULL: the kernel draws them (rng) and writes them to indices_out
     long long *indices_out;
-    unsigned long long *rng;           // [seed, calls so far, blocks done (internal)]: one uniform draw in [0, crop_h * crop_w) per
-    unsigned crop_pixels;              //   ray from philox(counter = (ray, call), key = seed); the last block advances `calls`
-    long long n;
+    unsigned long long *rng;           // [seed, calls so far, blocks done (internal), kept-max bits (internal)]: one uniform draw in
+    unsigned crop_pixels;              //   [0, crop_h * crop_w) per ray from philox(counter = (ray, call), key = seed); the last block
+    long long n;                       //   advances `calls`.  Also the launch's last-block hand-off when `hdr` is set (below)
     int K, H0, W0, crop_w, W_full;
     float fx, fy, cx, cy;
     const float *depth[NSR_MAX_WINDOW], *color[NSR_MAX_WINDOW], *c2w[NSR_MAX_WINDOW];
@@ -1236,12 +1236,31 @@ struct WindowParams {
     float *rays_o, *rays_d, *out_depth, *out_color;      // [K*n] concatenated in frame order
     double lo[3], hi[3];
     unsigned char *keep;               // optional
-    float *kept_max;                   // optional, caller-zeroed
+    float *kept_max;                   // optional, caller-zeroed (ignored when hdr is set)
+    // The fused iteration's zero fill inside this launch (nsr_get_samples_window_fused): x-blocks >= sample_bx of every grid row
+    // store zeros over zero[0 .. zero_n) while the first sample_bx place the rays (the fill is bandwidth, the sampling a latency
+    // chain: side by side they cost the longer of the two instead of two launches); the iteration's header {loss (fp64) = 0,
+    // kept max, 0} is written by the LAST block to finish, from maxima the blocks accumulate in rng[3] -- nothing has to be
+    // zeroed before the launch.
+    float *hdr;                        // [4] or NULL
+    float *zero;                       // 16-byte aligned
+    long long zero_n;                  // floats
+    int sample_bx;                     // x-blocks that sample; the rest (if any) fill
 };
 
 NSR_KERNEL void get_samples_window_kernel(const WindowParams P) {
     const long long i = (long long)bid_x() * nthreads() + tid();
     const int k = bid_y();
+    float vmax = 0.f;                  // this thread's candidate for the kept rays' maximum depth
+    if (bid_x() >= P.sample_bx) {
+        // a fill block: its share of the span, then done (it takes no part in the hand-off below: a thousand blocks counting
+        // themselves on one word were 10 us of same-address atomics)
+        const long long fb = nblk_x() - P.sample_bx, chunk = (long long)k * fb + (bid_x() - P.sample_bx), nchunk = fb * P.K;
+        const long long n4 = P.zero_n >> 2;
+        for (long long q = chunk * nthreads() + tid(); q < n4; q += nchunk * nthreads()) st4(P.zero + q * 4, F4{0.f, 0.f, 0.f, 0.f});
+        if (chunk == 0 && tid() < (int)(P.zero_n & 3)) P.zero[n4 * 4 + tid()] = 0.f;
+        return;
+    }
     if (i < P.n) {
     const long long t = (long long)k * P.n + i;
     // the frame's pose is requested first, with the draw's state: behind the index store below the compiler may not move the loads
@@ -1283,14 +1302,29 @@ NSR_KERNEL void get_samples_window_kernel(const WindowParams P) {
     }
     const bool kp = tb >= (double)gd;
     if (P.keep) P.keep[t] = kp ? 1 : 0;
-    if (kp && P.kept_max && gd > 0.f) atomic_max_pos(P.kept_max, gd);
+    if (kp && gd > 0.f) vmax = gd;
     }
-    if (!P.indices) {
+    if (P.hdr) {
+        // one returning atomic per wave (it has returned before the barrier below, i.e. before this block counts itself done)
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) { const float o = shfl_xor(vmax, m); vmax = o > vmax ? o : vmax; }
+        if ((tid() & 63) == 0 && vmax > 0.f) keep_alive_u(atomic_fetch_max_u32(reinterpret_cast<unsigned *>(P.rng + 3), __builtin_bit_cast(unsigned, vmax)));
+    } else if (P.kept_max && vmax > 0.f) {
+        atomic_max_pos(P.kept_max, vmax);
+    }
+    if (!P.indices || P.hdr) {
         // the last block to get here (every thread of every block has read the call counter by then) advances it
         block_sync();
         if (tid() == 0) {
-            const unsigned long long total = (unsigned long long)nblk_x() * P.K;
-            if (atomic_fetch_add_global_u64(P.rng + 2, 1ull) == total - 1) { P.rng[2] = 0ull; P.rng[1] = P.rng[1] + 1ull; }
+            const unsigned long long total = (unsigned long long)P.sample_bx * P.K;          // the sampling blocks
+            if (atomic_fetch_add_global_u64(P.rng + 2, 1ull) == total - 1) {
+                P.rng[2] = 0ull;
+                if (!P.indices) P.rng[1] = P.rng[1] + 1ull;
+                if (P.hdr) {
+                    const unsigned mx = atomic_exchange_u32(reinterpret_cast<unsigned *>(P.rng + 3), 0u);
+                    st4(P.hdr, F4{0.f, 0.f, __builtin_bit_cast(float, mx), 0.f});
+                }
+            }
         }
     }
 }

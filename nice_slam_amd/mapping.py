@@ -59,6 +59,9 @@ def _bound_arrays(bound):
 # "torch" -- one `torch.randint` call for the window.  Same distribution either way; neither is the reference's stream (it
 # draws once per keyframe).  `get_samples` (the drop-in of common.py:91-106) always uses torch.randint like the reference.
 PIXEL_DRAW = os.environ.get("NSR_PIXEL_DRAW", "kernel")
+# The fused iterations' one zero fill (loss accumulator, kept max, every gradient buffer of the backward) inside the window
+# kernel's launch (nsr_get_samples_window_fused) instead of a `torch.zeros` launch in front of it; "0": the separate fill (A/B).
+FUSED_FILL = os.environ.get("NSR_FUSED_FILL", "1") != "0"
 _DRAW_STATE = {}
 
 
@@ -110,11 +113,26 @@ def seed_pixel_draws(seed: int, device=None):
         _set_state(st[1], seed)
 
 
-def _launch_window(indices, K, n, crop, intr, frames, bound6, sbuf, keep, kmax_ptr, dev):
+def _launch_window(indices, K, n, crop, intr, frames, bound6, sbuf, keep, kmax_ptr, dev, fused=None):
+    """``fused``: None, or (header tensor [4] fp32, zero span tensor) of a fused iteration -- the launch then also zero-fills the
+    span and writes the header {loss = 0 (fp64), kept max, 0} itself (nsr_get_samples_window_fused): no fill launch before it."""
     lib = _capi.get_lib()
     H0, H1, W0, W1, W_full = crop
     fx, fy, cx, cy = intr
     N = K * n
+    if fused is not None:
+        hdr, zero = fused
+        draw = getattr(indices, "_nsr_draw", False)
+        indices._nsr_draw = False
+        state = getattr(indices, "_nsr_state", None)
+        if state is None:
+            state = _draw_state(dev)
+        lib.check(lib.nsr_get_samples_window_fused(None if draw else indices.data_ptr(), indices.data_ptr() if draw else None, state.data_ptr(),
+                                                   K, n, H0, H1, W0, W1, W_full, fx, fy, cx, cy, frames, sbuf.data_ptr(),
+                                                   sbuf.data_ptr() + 12 * N, sbuf.data_ptr() + 24 * N, sbuf.data_ptr() + 28 * N, bound6[0],
+                                                   bound6[1], keep.data_ptr(), hdr.data_ptr(), zero.data_ptr() if zero.numel() else None,
+                                                   zero.numel(), _stream(dev)), "nsr_get_samples_window_fused")
+        return
     if getattr(indices, "_nsr_draw", False):               # drawn by the kernel, written to `indices` for the backward / the caller
         indices._nsr_draw = False
         state = getattr(indices, "_nsr_state", None)
@@ -182,7 +200,8 @@ def _window_meta(H0, H1, W0, W1, n, W, fx, fy, cx, cy, c2ws, depths, colors, bou
     elif indices is None:
         indices = torch.randint((H1 - H0) * (W1 - W0), (K * n,), device=dev)      # one draw for the window (common.py:99 per frame)
     else:
-        indices = indices.to(dev).reshape(-1).contiguous()
+        indices = indices.to(dev).reshape(-1).contiguous().view(-1)             # (a tensor object of our own: it carries the state below)
+        indices._nsr_state = draw_state
     c2ws = [c if isinstance(c, torch.Tensor) else torch.as_tensor(c) for c in c2ws]
     crop = (int(H0), int(H1), int(W0), int(W1), int(W))
     intr = (float(fx), float(fy), float(cx), float(cy))
@@ -237,7 +256,9 @@ class _MappingLossFn(torch.autograd.Function):
             n_grad = sum(grids[s].numel() for s, nd in zip(slots, need_grid) if nd) + (6 * N if need_pose else 0) + \
                 sum(param_count(s) for s, nd in zip(slots, need_par) if nd)
         n_pose = 16 * K if need_pose else 0                     # d c2w of the window (pose_grads), behind the gradients
-        Z = torch.zeros((4 + n_grad + n_pose,), dtype=torch.float32, device=dev)
+        # (round 5: not a fill launch -- the window kernel zero-fills it beside its sampling blocks and writes the header)
+        fuse_fill = FUSED_FILL and N > 0
+        Z = (torch.empty if fuse_fill else torch.zeros)((4 + n_grad + n_pose,), dtype=torch.float32, device=dev)
         loss = Z[:2].view(torch.float64)
         kmax = Z[2:3]
         frames, hold = _frames_block(c2ws, depths, colors, dev)
@@ -250,7 +271,8 @@ class _MappingLossFn(torch.autograd.Function):
         F = FS[:n64 + (nf32 + 1) // 2]
         sbuf = FS[n64 + (nf32 + 1) // 2:].view(torch.float32)[:n_s]
         keep = sbuf[10 * N:].view(torch.uint8)[:N]
-        _launch_window(indices, K, n, crop, intr, frames, _bound_arrays(bound), sbuf, keep, kmax.data_ptr(), dev)
+        _launch_window(indices, K, n, crop, intr, frames, _bound_arrays(bound), sbuf, keep, kmax.data_ptr(), dev,
+                       fused=(Z[:4], Z[4:]) if fuse_fill else None)
         if sharder is not None:                                # the depth cap is a scalar of the WHOLE batch (Renderer.py:109,144)
             sharder.reduce_max(kmax)
         rays_o, rays_d = sbuf[:3 * N].view(N, 3), sbuf[3 * N:6 * N].view(N, 3)

@@ -209,6 +209,14 @@ NSR_DEV void atomic_max_pos(float *p, float v) {
     while (old < nw && !__atomic_compare_exchange_n(u, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
 }
 
+NSR_DEV unsigned atomic_fetch_max_u32(unsigned *p, unsigned v) {
+    unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED)) {}
+    return old;
+}
+NSR_DEV unsigned atomic_exchange_u32(unsigned *p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_ACQ_REL); }
+NSR_DEV void keep_alive_u(unsigned) {}
+
 NSR_DEV unsigned uniform_load_u8(const unsigned char *p) { return *p; }
 NSR_DEV char *lds_base() { return emu::B->lds; }
 

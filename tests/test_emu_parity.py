@@ -490,6 +490,59 @@ def test_window_kernel_draws_its_own_pixels(emu):
     assert (draws[0] != draws[1]).mean() > 0.9
 
 
+def test_window_kernel_as_first_launch_of_a_fused_iteration(emu):
+    """nsr_get_samples_window_fused (ABI 7): the same rays / mask as the plain entry points (explicit indices and drawn ones), the
+    span zero-filled to the float (lengths that are not multiples of four, lengths spread over many fill blocks, an empty span),
+    the header {loss = 0, kept max, 0} written by the launch itself over whatever was there, the hand-off words of the state zero
+    again afterwards and the call counter advanced only when the kernel drew."""
+    import ctypes as C
+    from emu_harness import ptr
+    from nice_slam_amd import _capi
+    sc, frames, idx, (H0, H1, W0, W1) = _window_case()
+    H, W, fx, fy, cx, cy = sc["intr"]
+    K, n = len(frames), 300
+    N = K * n
+    fr = (_capi.NsrFrame * K)()
+    hold = []
+    for k, (c2w, d, col) in enumerate(frames):
+        arrs = [np.ascontiguousarray(d.numpy(), dtype=np.float32), np.ascontiguousarray(col.numpy(), dtype=np.float32), np.ascontiguousarray(c2w.numpy(), dtype=np.float32)]
+        hold += arrs
+        fr[k].depth, fr[k].color, fr[k].c2w, fr[k].c2w_stride = arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, 4
+    b = sc["bound"]
+    lo, hi = (C.c_double * 3)(*b[:, 0].tolist()), (C.c_double * 3)(*b[:, 1].tolist())
+    seed = 0x0BADC0DE12345678
+    state = np.array([seed, 3, 0, 0], dtype=np.uint64)
+    g = np.random.default_rng(0)
+    given = g.integers(0, (H1 - H0) * (W1 - W0), size=N).astype(np.int64)
+    for zero_n, draw in ((0, False), (5, True), (4 * 8192 * 3 + 2, False), (70001, True)):
+        calls = int(state[1])
+        ind = np.full((N,), -1, np.int64) if draw else given.copy()
+        ro, rd = np.full((N, 3), np.nan, np.float32), np.full((N, 3), np.nan, np.float32)
+        gd, gc = np.full((N,), np.nan, np.float32), np.full((N, 3), np.nan, np.float32)
+        keep = np.full((N,), 9, np.uint8)
+        Z = np.full((4 + zero_n + 4,), np.nan, np.float32)              # header | span | guard
+        Z[-4:] = 7.0
+        emu.check(emu.nsr_get_samples_window_fused(None if draw else ptr(ind), ptr(ind) if draw else None, ptr(state), K, n, H0, H1, W0, W1, W,
+                                                   fx, fy, cx, cy, fr, ptr(ro), ptr(rd), ptr(gd), ptr(gc), lo, hi, ptr(keep),
+                                                   ptr(Z), ptr(Z[4:]) if zero_n else None, zero_n, None))
+        assert state.tolist() == [seed, calls + (1 if draw else 0), 0, 0]
+        ro2, rd2 = np.full((N, 3), np.nan, np.float32), np.full((N, 3), np.nan, np.float32)
+        gd2, gc2 = np.full((N,), np.nan, np.float32), np.full((N, 3), np.nan, np.float32)
+        keep2, kmax2 = np.full((N,), 9, np.uint8), np.zeros((1,), np.float32)
+        emu.check(emu.nsr_get_samples_window(ptr(ind), K, n, H0, H1, W0, W1, W, fx, fy, cx, cy, fr, ptr(ro2), ptr(rd2), ptr(gd2), ptr(gc2),
+                                             lo, hi, ptr(keep2), ptr(kmax2), None))
+        for a_, b_ in ((ro, ro2), (rd, rd2), (gd, gd2), (gc, gc2), (keep, keep2)):
+            assert np.array_equal(a_, b_)
+        assert Z[0] == 0 and Z[1] == 0 and Z[3] == 0 and Z[2] == kmax2[0] and kmax2[0] > 0
+        assert np.all(Z[4:4 + zero_n] == 0) and np.all(Z[-4:] == 7.0)
+        if draw:
+            assert ind.min() >= 0 and not np.array_equal(ind, given)
+    # a span that is not 16-byte aligned is refused
+    Z = np.zeros((64,), np.float32)
+    assert emu.nsr_get_samples_window_fused(ptr(given), None, ptr(state), K, n, H0, H1, W0, W1, W, fx, fy, cx, cy, fr, ptr(ro), ptr(rd), ptr(gd),
+                                            ptr(gc), lo, hi, ptr(keep), ptr(Z), ptr(Z[5:]), 8, None) != 0
+
+
 def test_fused_mapping_loss_in_the_forward(emu):
     """render forward with the mapping loss (Mapper.py:487-493): the loss value and d loss / d outputs it writes equal torch's
     on the forward's own outputs (masked by the bounding-box mask, depth term on gt > 0 only, colour term in the colour stage)"""
