@@ -493,6 +493,9 @@ NSR_DEV void scatter_walk(const GridDev &G, int lane, const float *Tx, const flo
                     if (tg == -1) { const int old = atomic_cas_lds_i(hot_tag(hot) + slot, -1, vox); tg = old == -1 ? vox : old; }
                     if (tg == vox) { atomic_add_lds(hot_val(hot) + slot * kC + ch, s[p]); done = true; }
                 }
+#if defined(NSR_X_SCATTER_LDS)           // A/B build: every update as an LDS atomic on some table row (wrong numbers; what a block-level write-back table could reach)
+                if (!done && hot.off >= 0) { atomic_add_lds(hot_val(hot) + (int)(((unsigned)vox * 2654435761u) >> 26) * kC + ch, s[p]); done = true; }
+#endif
                 if (!done) {
 #if defined(NSR_X_SCATTER_HASH)          // A/B builds (tools/build_ts.sh ... -DNSR_X_...): same request count, voxels spread over the grid
                     const int vx = (int)(((unsigned)vox * 2654435761u) % (unsigned)(G.X * G.Y * G.Z));
