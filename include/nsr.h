@@ -98,7 +98,9 @@ typedef struct nsr_render_args {
      * nsr_render_bwd takes as d_depth / d_rgb (d_var = NULL), so the caller's loss and its backward cost no launch. */
     const float *gt_color;    /* [N][3] */
     const uint8_t *keep;      /* [N] ray mask of the callers' bounding-box pre-filter (nsr_aabb_keep / nsr_get_samples_window);
-                                 NULL = every ray counts */
+                                 NULL = every ray counts.  With skip_masked the kernels read it through the scalar cache one
+                                 aligned 32-bit word at a time: the buffer must be readable up to the next 4-byte boundary
+                                 behind its last byte (any allocator's padding; do not hand in the tail of a page-exact mapping) */
     double *loss;             /* device scalar, caller-zeroed */
     double *dl_depth;         /* [N]    out, optional */
     float *dl_rgb;            /* [N][3] out, optional */
@@ -253,8 +255,9 @@ typedef struct nsr_adam_grid {
     float lr;
     int32_t pad_;
 } nsr_adam_grid;
-int nsr_masked_adam_multi(const nsr_adam_grid *grids, int32_t n_grids, float beta1, float beta2, float eps,
-                          int32_t zero_grad, float *scratch, void *stream);
+int nsr_masked_adam_multi(const nsr_adam_grid *grids, int32_t n_grids, double beta1, double beta2, double eps,
+                          int32_t zero_grad, float *scratch, void *stream);   /* (betas as doubles since ABI 7: the bias corrections
+                          1 - beta^t are formed from them in fp64, like torch's python scalars) */
 
 /* The dense rest of the callers' optimiser -- torch.optim.Adam over the decoder parameters and the camera tensors
  * (src/Mapper.py:368-387,504; src/Tracker.py:214-222,127) -- for up to 4 flat fp32 spans (a decoder's parameter blob, an [n,7] pose

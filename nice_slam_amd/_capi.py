@@ -108,7 +108,7 @@ SYMBOLS = (
                                                C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     ("nsr_pose_grad", C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
-    ("nsr_masked_adam_multi", C.c_int, [C.POINTER(NsrAdamGrid), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32,
+    ("nsr_masked_adam_multi", C.c_int, [C.POINTER(NsrAdamGrid), C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32,
                                         C.c_void_p, C.c_void_p]),
     ("nsr_flat_adam", C.c_int, [C.POINTER(NsrAdamSpan), C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_void_p]),
     ("nsr_pack_rows", C.c_int, [C.POINTER(NsrRows), C.c_int32, C.POINTER(NsrSpan), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -361,6 +361,13 @@ int nsr_render_fwd(const nsr_render_args *a, void *stream) {
     if (!a->depth || !a->var || !a->rgb) return fail("nsr_render_fwd: null output pointer");
     if (P.n_rays == 0) return 0;
     static const int fwd_split = env_int("NSR_FWD_SPLIT", 1);      // 0: always the one-launch kernel (measurement)
+    if (a->acts && a->zvals && a->raw) {
+        // a call that hands over an activation buffer (with zvals and raw: without them nsr_render_bwd refuses) will be differentiated: only the three-launch path saves into it, and the
+        // tile / keep arithmetic of the kernels that read it is 32-bit (tile_live, dw_live_mask, split_layout)
+        if (!fwd_split) return fail("nsr_render_fwd: NSR_FWD_SPLIT=0 (the one-launch kernel saves no activations) with an activation buffer: "
+                                    "nsr_render_bwd would read an unwritten buffer");
+        if (P.n_points_total > (1ll << 25) - 16) return fail("nsr_render_fwd: more than 2^25 sample points in one differentiated call (split the ray batch)");
+    }
     if (fwd_split && P.acts && P.zvals && P.raw && P.draw) {
         // a differentiated call with an activation buffer: sample placement -> decoder passes -> compositor (nsr_fwd2.h)
         const int passes = bwd_passes(P.stage), rpb = 4;
@@ -623,7 +630,7 @@ int nsr_pose_grad(const int64_t *indices, int32_t K, int64_t n, int32_t H0, int3
     return finish("nsr_pose_grad");
 }
 
-int nsr_masked_adam_multi(const nsr_adam_grid *grids, int32_t n_grids, float beta1, float beta2, float eps,
+int nsr_masked_adam_multi(const nsr_adam_grid *grids, int32_t n_grids, double beta1, double beta2, double eps,
                           int32_t zero_grad, float *scratch, void *stream) {
     if (n_grids < 0 || n_grids > 4) return fail("nsr_masked_adam_multi: 0..4 grids");
     if (n_grids == 0) return 0;
@@ -638,7 +645,8 @@ int nsr_masked_adam_multi(const nsr_adam_grid *grids, int32_t n_grids, float bet
         A.step[i] = g.step; A.lr[i] = g.lr;
         nmax = g.n_voxels > nmax ? g.n_voxels : nmax;
     }
-    A.n = n_grids; A.b1 = beta1; A.b2 = beta2; A.eps = eps; A.zero_grad = zero_grad; A.scal = scratch;
+    A.n = n_grids; A.b1 = (float)beta1; A.b2 = (float)beta2; A.eps = (float)eps; A.zero_grad = zero_grad; A.scal = scratch;
+    A.b1d = beta1; A.b2d = beta2;
     NSR_LAUNCH(nsr::adam_tick_kernel, dim3(1), dim3(64), 0, stream, A);
     if (nmax > 0) {
         const int tb = 256;
@@ -663,6 +671,7 @@ int nsr_flat_adam(const nsr_adam_span *spans, int32_t n_spans, double beta1, dou
     }
     A.n = n_spans; A.b1 = (float)beta1; A.b2 = (float)beta2; A.eps = (float)eps; A.zero_grad = zero_grad; A.scal = scratch;
     A.omb1 = (float)(1.0 - beta1); A.omb2 = (float)(1.0 - beta2);
+    A.b1d = beta1; A.b2d = beta2;
     NSR_LAUNCH(nsr::adam_tick_kernel, dim3(1), dim3(64), 0, stream, A);
     if (nmax > 0) {
         const int tb = 256;

@@ -1085,6 +1085,8 @@ struct AdamMulti {
     int n;
     float b1, b2, eps;
     float omb1, omb2;         // 1 - beta (flat_adam_kernel: formed in fp64 by the host, like torch's python scalars)
+    double b1d, b2d;          // the betas as the caller's doubles: the bias corrections 1 - beta^t are formed from THESE (with
+                              // 0.999f instead of 0.999 the first hundreds of steps are 6e-6 off torch's step size)
     int zero_grad;
     float *scal;              // [4][2]: step_size, bias2_sqrt
 };
@@ -1093,8 +1095,8 @@ NSR_KERNEL void adam_tick_kernel(const AdamMulti A) {
     if (i >= A.n) return;
     const int t = A.step[i][0] + 1;
     A.step[i][0] = t;
-    A.scal[2 * i + 0] = (float)((double)A.lr[i] / (1.0 - pow((double)A.b1, (double)t)));
-    A.scal[2 * i + 1] = (float)sqrt(1.0 - pow((double)A.b2, (double)t));
+    A.scal[2 * i + 0] = (float)((double)A.lr[i] / (1.0 - pow(A.b1d, (double)t)));
+    A.scal[2 * i + 1] = (float)sqrt(1.0 - pow(A.b2d, (double)t));
 }
 NSR_KERNEL void masked_adam_multi_kernel(const AdamMulti A) {
     const int i = bid_y();

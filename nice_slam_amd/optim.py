@@ -187,6 +187,10 @@ class FlatAdam:
         gs = [p.grad for p in e.parameters()]        # foreign gradient tensors: one concatenation (not capturable-stable)
         if any(g is None for g in gs):
             return None
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise _capi.NsrError("FlatAdam: a decoder whose .grad tensors are not the views of its gradient blob cannot be stepped under "
+                                 "graph capture (the concatenated copy gets a new address every step)")
+        self._foreign = gs
         return torch.cat([g.reshape(-1) for g in gs])
 
     def step(self, lr=None, zero_grad: bool = False):
@@ -195,10 +199,21 @@ class FlatAdam:
         arr = (_capi.NsrAdamSpan * len(self.entries))()
         hold, n = [], 0
         dev = self._steps.device
+        foreign = []
         for i, e in enumerate(self.entries):
+            if self._is_dec[i]:
+                # the backward writes -- and this step consumes -- the gradient of the WHOLE blob: torch would skip a frozen
+                # parameter (its .grad stays None), a blob cannot
+                rg = {p.requires_grad for p in e.parameters()}
+                if len(rg) > 1:
+                    raise _capi.NsrError("FlatAdam: entry %d mixes parameters with and without requires_grad; a decoder is stepped as "
+                                         "one blob (freeze it as a whole, or leave it out of the optimiser)" % i)
+            self._foreign = None
             g = self._grad(i)
             if g is None:
                 continue
+            if self._foreign is not None:
+                foreign += self._foreign
             p = e.flat_params() if self._is_dec[i] else e
             if g.device != p.device or g.numel() != p.numel():
                 raise _capi.NsrError("FlatAdam: gradient of entry %d does not match its parameter (device / size)" % i)
@@ -217,6 +232,8 @@ class FlatAdam:
             with _capi.on_device(dev):
                 lib.check(lib.nsr_flat_adam(arr, n, self.betas[0], self.betas[1], self.eps, 1 if zero_grad else 0,
                                             self._scratch.data_ptr(), _stream(dev)), "nsr_flat_adam")
+            if zero_grad and foreign:                # the kernel cleared the concatenated COPY: clear what the caller holds
+                torch._foreach_zero_(foreign)
 
     def zero_grad(self, set_to_none: bool = True):
         for e, d in zip(self.entries, self._is_dec):
