@@ -418,7 +418,7 @@ NSR_KERNEL NSR_BOUNDS(64 * kDxMaxWaves) void render_bwd_dx_kernel(const RenderPa
 // q = 0..3, i.e. X[point 4 q + g][channel i] -- the "lane = channel" operand form of a contraction over points, conflict-free
 // in LDS, no transposition anywhere.  Block = 8 compute waves, which own disjoint output tiles (roles below), + 2 loader
 // waves, which copy the 16-point tiles of the block with global -> LDS DMA into a ring of kDwRing slots (22 / 24 pieces of
-// 1 KB per tile, tiles alternating between the loaders, two tiles in flight each).  There is NO block barrier: a loader
+// 1 KB per tile, tiles alternating between the loaders, one tile in flight each: a landed tile is published at once).  There is NO block barrier: a loader
 // publishes "my m-th tile has landed" in an LDS word, every compute wave publishes "I am done with tile k", the loaders
 // reuse a slot when the slowest compute wave has left it.  Compute waves therefore drift apart, and on every SIMD the LDS
 // reads / sines of one wave run under the MFMAs of the other.
@@ -428,6 +428,7 @@ NSR_KERNEL NSR_BOUNDS(64 * kDxMaxWaves) void render_bwd_dx_kernel(const RenderPa
 // of the DMA cadence (35 us), the LDS read phases and the MFMAs: lock-step phases behind the barriers, the youngest waves
 // of a SIMD starving at issue.  Operands straight from global memory into registers, no LDS: 159 us, 240-256 VGPRs.)
 constexpr int kDwCompute = 8, kDwLoaders = 2, kDwWaves = kDwCompute + kDwLoaders, kDwRing = 6;
+constexpr long long kDwDbgOff = 768ll * kDxMaxWaves * 64;      // this kernel's stamp slots sit behind the dX kernel's (tests/perf/ts_d*.py)
 template <int KIND>
 struct DwLay {
     static constexpr int NC = KIND == NSR_FINE ? 4 : 2;          // feature operand tiles ([c_fine | c_mid] for the fine decoder)
@@ -884,22 +885,32 @@ NSR_DEV void dw_compute(const RenderParams &P, W &Wv, float *ring, int *ctl, flo
     typename W::Ops ops;
     int k = 0;
     unsigned long long lm = ~0ull;
+    const Dbg dbg{P.dbg ? P.dbg + kDwDbgOff + ((long long)bid_x() * kDxMaxWaves + wave) * 64 : nullptr};   // (-DNSR_TS builds: tests/perf/ts_dw.py)
+    dbg.stamp(0);
     for (long long t = bi; t < ntl; t += step, ++k) {
         loop_fence();
+        dbg.stamp(1);
         if ((k & 63) == 0) lm = dw_live_mask(P, bi, step, k >> 6, ntiles, lane);
-        while (flag_load(ctl + (k & 1)) <= (k >> 1)) spin_pause();          // the loader of this tile has landed it
+        while (flag_load(ctl + (k % kDwLoaders)) <= (k / kDwLoaders)) spin_pause();   // the loader of this tile has landed it
+        dbg.stamp(2);
         if ((lm >> (k & 63)) & 1ull) {                                       // (else: the loader left the slot empty)
             Wv.fetch(dw_src<KIND>(ring + (k % kDwRing) * Y::kSlot), lane, ops);
             Wv.consume(ops, lane, (t == last && ragged) ? ragged : kTile);
         }
+        dbg.stamp(3);
         flag_store(ctl + kDwLoaders + wave, k + 1);                          // (release: the slot's reads have returned)
+        dbg.stamp(4);
     }
+    dbg.stamp(5);
     // flush: every wave of the block is done with the ring (barrier), the row-tile pairs exchange their W^T products through it
     // (barrier), the images are written.  The loader waves take part in both barriers (dw_loader).
     block_sync();
+    dbg.stamp(6);
     Wv.flush_products(P.dec[KIND].params, ring, lane);
     block_sync();
+    dbg.stamp(7);
     Wv.flush(img, P.dec[KIND].params, ring, lane);
+    dbg.stamp(8);
 }
 
 template <int KIND>
@@ -910,10 +921,18 @@ NSR_DEV void dw_loader(const RenderParams &P, float *ring, int *ctl, int j, int 
     int m = 0;                                                               // this loader's m-th tile is the block's tile 2 m + j
     unsigned long long lm = ~0ull;
     int chunk = -1;
+    const Dbg dbg{P.dbg ? P.dbg + kDwDbgOff + ((long long)bid_x() * kDxMaxWaves + kDwCompute + j) * 64 : nullptr};
+    dbg.stamp(0);
     for (long long t = bi + j * step; t < ntl; t += kDwLoaders * step, ++m) {
         loop_fence();
+        dbg.stamp(1);
         const int k = kDwLoaders * m + j;
         if ((k >> 6) != chunk) { chunk = k >> 6; lm = dw_live_mask(P, bi, step, chunk, ntiles, lane); }
+        // The previous tile is waited for and published FIRST (it was requested a whole iteration ago: it has landed), then the ring slot
+        // of this one.  (Until round 5 the order was "slot, issue, then wait for the previous tile and publish it" -- two tiles in
+        // flight per loader, but a tile that had landed stayed unpublished for as long as its loader waited for the slot of the NEXT
+        // one, i.e. for the slowest compute wave: the faster waves stalled on tiles that sat in LDS; tests/perf/ts_dw.py.)
+        if (m >= 1) { dma_wait<0>(); flag_store(ctl + j, m); }
         if (k >= kDwRing) {                                                  // the slot still holds tile k - kDwRing
             for (;;) {
                 int lo = flag_load(ctl + kDwLoaders);
@@ -923,16 +942,16 @@ NSR_DEV void dw_loader(const RenderParams &P, float *ring, int *ctl, int j, int 
                 spin_pause();
             }
         }
+        dbg.stamp(2);
         if ((lm >> (k & 63)) & 1ull) {
             dw_issue<KIND>(P, t, ring + (k % kDwRing) * Y::kSlot, lane);
-            if (m >= 1) { dma_wait<Y::NOPS>(); flag_store(ctl + j, m); }      // all but the newest tile's pieces have landed
-        } else if (m >= 1) {                                                 // a tile without a ray of the batch: nothing to load
-            dma_wait<0>();
-            flag_store(ctl + j, m);
+            dbg.stamp(3);
         }
+        dbg.stamp(4);
     }
     dma_wait<0>();
     flag_store(ctl + j, m);
+    dbg.stamp(5);
     block_sync();                                                            // the compute waves' flush (dw_compute)
     block_sync();
 }
