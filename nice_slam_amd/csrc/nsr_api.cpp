@@ -230,11 +230,19 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
         int lds = 0;
         const int first = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE, last = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : P.stage;
         for (int kind = first; kind <= last; ++kind) {
-            const int need = (nsr::AUX_FLOATS + nsr::packedT_total(kind) + G.waves * nsr::kDxStg + (kind == NSR_COARSE ? 0 : nsr::kHotFloats) + 4) * 4;   // + the tile counter
+            const int need = (nsr::AUX_FLOATS + nsr::packedT_total(kind) + G.waves * nsr::kDxStg + 4) * 4;   // + the tile counter
             lds = need > lds ? need : lds;
         }
-        // hot-voxel table of a dX block: samples within `hot_cells` cells of their ray's origin (NSR_DX_HOT_CELLS, 0: off)
-        static const int hot_cells = env_int("NSR_DX_HOT_CELLS", 2);
+        // hot-voxel table of a dX block: samples within `hot_cells` cells of their ray's origin (NSR_DX_HOT_CELLS, 0: off), as many
+        // slots as the block's LDS has left (NSR_DX_HOT_SLOTS caps it; round 5: 64 slots / 2 cells -> what fits / 6 cells, measured)
+        static const int hot_cells = env_int("NSR_DX_HOT_CELLS", 6), hot_cap = env_int("NSR_DX_HOT_SLOTS", 512);
+        P.hot_slots = 0;
+        if (P.stage != NSR_STAGE_COARSE) {
+            int slots = (kLdsLimit - lds) / (nsr::kHotRow * 4);
+            slots = slots > hot_cap ? hot_cap : slots;
+            P.hot_slots = slots < 16 ? 16 : slots;
+            lds += P.hot_slots * nsr::kHotRow * 4;
+        }
         for (int s = 0; s < 4; ++s) {
             P.hot_z[s] = 0.f;
             if (s == NSR_COARSE || hot_cells <= 0 || !P.grid[s].dfeat) continue;

@@ -143,12 +143,12 @@ NSR_DEV void dx_pass(const RenderParams &P) {
     const int gl_off = (KIND == NSR_COARSE && P.lds_grid_floats > 0) ? tail_off : -1;
     float *gl = gl_off >= 0 ? reinterpret_cast<float *>(lds) + gl_off : nullptr;
     const bool use_hot = KIND != NSR_COARSE && P.hot_z[KIND] > 0.f && P.grid[KIND].dfeat != nullptr;
-    const HotTab hot{use_hot ? tail_off : -1};
+    const HotTab hot{use_hot ? tail_off : -1, P.hot_slots};
     // Tiles: block i of the n of a pass owns the contiguous range [T i / n, T (i + 1) / n) and its waves draw from it through
     // an LDS counter (a wave whose tile was cheap takes the next one: no rounds); NSR_X bit 7: the static deal tile = block *
     // waves + wave, + blocks * waves, ... of the first version (measurement).
     const bool dyn = !(P.xflags & 128);
-    int *tcnt = reinterpret_cast<int *>(stg + nw * kDxStg + (KIND == NSR_COARSE ? P.lds_grid_floats : kHotFloats));
+    int *tcnt = reinterpret_cast<int *>(stg + nw * kDxStg + (KIND == NSR_COARSE ? P.lds_grid_floats : P.hot_slots * kHotRow));
     const GridDev &G = P.grid[KIND];
     const DecDev &D = P.dec[KIND];
     const bool do_grid = G.dfeat != nullptr;
@@ -895,6 +895,10 @@ NSR_DEV void dw_compute(const RenderParams &P, W &Wv, float *ring, int *ctl, flo
         dbg.stamp(2);
         if ((lm >> (k & 63)) & 1ull) {                                       // (else: the loader left the slot empty)
             Wv.fetch(dw_src<KIND>(ring + (k % kDwRing) * Y::kSlot), lane, ops);
+#ifdef NSR_TS
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (stamped builds: the operand reads on their own)
+            dbg.stamp(9);
+#endif
             Wv.consume(ops, lane, (t == last && ragged) ? ragged : kTile);
         }
         dbg.stamp(3);

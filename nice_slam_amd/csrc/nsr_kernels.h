@@ -99,6 +99,7 @@ struct RenderParams {
     int skip_masked;          // 1 (with keep): rays with keep == 0 are not part of the batch (nsr_render_args.skip_masked)
     int lds_grid_floats;      // > 0 (coarse stage): the gradient grid (this many floats) is accumulated in the dX block's LDS
     float hot_z[4];           // dX kernel, per grid: samples with z below it use the block's hot-voxel table (0: no table)
+    int hot_slots;            // dX kernel: slots of that table (the launch sizes it to the LDS the block has left)
     int pass_beg[4];          // pass kernels (nsr_fwd2.h): blocks [pass_beg[p], pass_beg[p + 1]) of the launch work on decoder pass p
     // eval_points only
     const double *points;
@@ -422,20 +423,23 @@ NSR_DEV void coord_grad(const GridDev &G, const Lvl &L, int g, const Act<2> &dc,
 // keeps a small direct-mapped table of voxel rows in LDS: updates of samples closer to their ray's origin than `hot_z` (two
 // cells) go there when their voxel owns or can claim its slot, everything else straight to memory, and the block adds its
 // table to memory once at the end.
-constexpr int kHotSlots = 64, kHotBit = 1 << 30, kHotFloats = kHotSlots * (kC + 1);     // tags [64] | rows [64][32]
+constexpr int kHotBit = 1 << 30, kHotRow = kC + 1;        // a slot: one tag + one 32-channel row; the slot count is the launch's (RenderParams.hot_slots)
 // The table is addressed by its OFFSET from the block's LDS base (floats), a wave-uniform integer (-1: no table): a struct of
 // generic pointers handed down to the walk was spilled to scratch by the register allocator and re-loaded inside the hot
 // branch -- scratch loads count on vmcnt, so every probe waited for ALL of the wave's outstanding grid atomics.
-struct HotTab { int off; };
+struct HotTab { int off, slots; };                                // tags [slots] | rows [slots][32]
 NSR_DEV int *hot_tag(const HotTab &H) { return reinterpret_cast<int *>(lds_base()) + H.off; }
-NSR_DEV float *hot_val(const HotTab &H) { return reinterpret_cast<float *>(lds_base()) + H.off + kHotSlots; }
+NSR_DEV float *hot_val(const HotTab &H) { return reinterpret_cast<float *>(lds_base()) + H.off + H.slots; }
+NSR_DEV int hot_slot(const HotTab &H, int vox) {                  // multiplicative hash, scaled to [0, slots) by the high half of a product
+    return (int)(((unsigned long long)((unsigned)vox * 2654435761u) * (unsigned)H.slots) >> 32);
+}
 NSR_DEV void hot_init(const HotTab &H) {
-    for (int i = tid(); i < kHotSlots * kC; i += nthreads()) hot_val(H)[i] = 0.f;
-    for (int i = tid(); i < kHotSlots; i += nthreads()) hot_tag(H)[i] = -1;
+    for (int i = tid(); i < H.slots * kC; i += nthreads()) hot_val(H)[i] = 0.f;
+    for (int i = tid(); i < H.slots; i += nthreads()) hot_tag(H)[i] = -1;
 }
 NSR_DEV void hot_flush(const HotTab &H, const GridDev &G) {       // after a block barrier: one half wave per occupied slot
     const int ch = tid() & 31;
-    for (int s = tid() >> 5; s < kHotSlots; s += nthreads() >> 5) {
+    for (int s = tid() >> 5; s < H.slots; s += nthreads() >> 5) {
         const int v = hot_tag(H)[s];
         if (v >= 0) atomic_add_global(G.dfeat + (long long)v * kC + ch, hot_val(H)[s * kC + ch]);
     }
@@ -460,7 +464,7 @@ NSR_DEV void scatter_stage(const Lvl &L, int lane, const Act<2> &dc, bool active
 // per point (~25 instructions and three branches, ~380 cycles per atomic: the walk, not the atomic unit, set the pace).
 NSR_DEV void scatter_walk(const GridDev &G, int lane, const float *Tx, const float *tab,
                           int lds_grid = -1,           // >= 0: the whole gradient grid sits in LDS at this offset (floats; small grids, nsr_bwd2.h)
-                          HotTab hot = HotTab{-1}) {
+                          HotTab hot = HotTab{-1, 0}) {
     const int *vt = reinterpret_cast<const int *>(tab);
     const float *wt = tab + 128;
     const int h = lane >> 5, ch = lane & 31;
@@ -488,13 +492,13 @@ NSR_DEV void scatter_walk(const GridDev &G, int lane, const float *Tx, const flo
                 bool done = false;
                 if (lds_grid >= 0) { atomic_add_lds(reinterpret_cast<float *>(lds_base()) + lds_grid + vox * kC + ch, s[p]); done = true; }
                 else if (hot.off >= 0 && (v[p] & kHotBit)) {
-                    const int slot = (int)(((unsigned)vox * 2654435761u) >> 26);       // kHotSlots = 64
+                    const int slot = hot_slot(hot, vox);
                     int tg = lds_load_i(hot_tag(hot) + slot);
                     if (tg == -1) { const int old = atomic_cas_lds_i(hot_tag(hot) + slot, -1, vox); tg = old == -1 ? vox : old; }
                     if (tg == vox) { atomic_add_lds(hot_val(hot) + slot * kC + ch, s[p]); done = true; }
                 }
 #if defined(NSR_X_SCATTER_LDS)           // A/B build: every update as an LDS atomic on some table row (wrong numbers; what a block-level write-back table could reach)
-                if (!done && hot.off >= 0) { atomic_add_lds(hot_val(hot) + (int)(((unsigned)vox * 2654435761u) >> 26) * kC + ch, s[p]); done = true; }
+                if (!done && hot.off >= 0) { atomic_add_lds(hot_val(hot) + hot_slot(hot, vox) * kC + ch, s[p]); done = true; }
 #endif
                 if (!done) {
 #if defined(NSR_X_SCATTER_HASH)          // A/B builds (tools/build_ts.sh ... -DNSR_X_...): same request count, voxels spread over the grid
@@ -515,7 +519,7 @@ NSR_DEV void scatter_walk(const GridDev &G, int lane, const float *Tx, const flo
     }
 }
 NSR_DEV void scatter_merged(const GridDev &G, const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab,
-                            int lds_grid = -1, HotTab hot = HotTab{-1}, bool hot_pt = false) {
+                            int lds_grid = -1, HotTab hot = HotTab{-1, 0}, bool hot_pt = false) {
     scatter_stage(L, lane, dc, active, Tx, tab, hot.off >= 0 && hot_pt);
     wave_fence();
     scatter_walk(G, lane, Tx, tab, lds_grid, hot);

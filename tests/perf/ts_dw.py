@@ -40,6 +40,9 @@ for s in range(1, 5):
     cnt = raw[:, :8, 32 + s][okc].astype(np.float64)
     if cnt.sum() > 0:
         print("      %-40s %8.2f %8.3f %6.1f" % (cn[s], tot.mean(), tot.sum() / cnt.sum(), cnt.mean()))
+tot9, cnt9 = comp[:, :, 16 + 9][okc], raw[:, :8, 32 + 9][okc].astype(np.float64)
+if cnt9.sum() > 0:
+    print("      %-40s %8.2f %8.3f %6.1f   (of the line above; slot 3 then holds sines + MFMAs only)" % ("   operand reads (LDS) until they have landed", tot9.mean(), tot9.sum() / cnt9.sum(), cnt9.mean()))
 for a, b, nm in ((0, 1, "entry -> first loop top"), (5, 6, "loop exit -> every wave done (barrier)"), (6, 7, "W^T products + barrier"), (7, 8, "image stores")):
     d = (comp[:, :, b] - comp[:, :, a])[okc]
     print("      %-40s %8.2f   (p10 %.2f p90 %.2f)" % (nm, d.mean(), np.percentile(d, 10), np.percentile(d, 90)))
