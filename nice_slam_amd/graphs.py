@@ -1,8 +1,8 @@
 """hipGraph capture of a mapping / tracking iteration (convenience around torch.cuda.CUDAGraph, no kernel of its own).
 
-A fused mapping iteration (``mapping_loss`` + ``nice_slam_amd.backward``) is eight launches of 5-100 us (zero fill, window kernel,
-sample placement, decoder passes, compositor, dX, dW, finalize), a tracking iteration ten of 5-30 us (+ tracking loss, compositor
-backward, pose gradient; no dW / finalize): launched eagerly from Python the host sets the pace
+A fused mapping iteration (``mapping_loss`` + ``nice_slam_amd.backward``) is seven launches of 5-100 us (window kernel -- which also
+zero-fills the iteration's gradient buffer --, sample placement, decoder passes, compositor, dX, dW, finalize), a tracking iteration
+nine of 5-30 us (+ tracking loss, compositor backward, pose gradient; no dW / finalize): launched eagerly from Python the host sets the pace
 (~10 us per launch), replayed from a graph the GPU runs them back to back.  Everything this package launches is capturable: no
 host synchronisation, no data-dependent shapes, workspaces / packed decoder buffers / gradient blobs / the in-kernel pixel
 draw's state at stable addresses.  ``CapturedStep`` wraps the usual torch recipe (warm-up on a side stream, capture, replay):

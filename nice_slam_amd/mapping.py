@@ -11,8 +11,8 @@ about forty small ATen launches around two big kernels.  Here:
   render-backward launch (+ the partial-sum kernel) writing dense grid gradients, the decoder-gradient blob and -- with BA --
   the pose gradients.
 
-Same numbers as the unfused path (tests/test_hip_mapping.py); per iteration: the index draw, one zero-fill, the window kernel,
-render forward, render backward, the partial sum.
+Same numbers as the unfused path (tests/test_hip_mapping.py); per iteration: the window kernel (which draws the pixels and
+zero-fills the iteration's gradient buffer beside its sampling blocks), render forward, render backward, the partial sum.
 """
 from __future__ import annotations
 
@@ -390,9 +390,9 @@ def tracking_loss(renderer, c, decoders, c2w: torch.Tensor, depth: torch.Tensor,
     ``n_pixels`` samples from the frame's ``[ignore_edge_H, H - ignore_edge_H) x [ignore_edge_W, W - ignore_edge_W)`` crop
     under the pose ``c2w`` (3x4 or 4x4; gets its gradient), the bounding-box pre-filter as a mask, the colour-stage render with
     depth-guided samples, and ``sum_mask |gt - depth| / sqrt(var + 1e-10) (+ w_color * sum_mask |gt_rgb - rgb|)`` with
-    ``mask = kept & (gt > 0) (& tmp < 10 * median(tmp))`` -- five launches (index draw, one zero-fill, window kernel, render
-    forward, ``nsr_tracking_loss``) and three in the backward (render backward, pose gradient, + the partial sum only if a
-    decoder wants parameter gradients) instead of ~80.  Returns an fp64 scalar (an ordinary autograd node: an incoming gradient other than 1 scales the pose gradient)."""
+    ``mask = kept & (gt > 0) (& tmp < 10 * median(tmp))`` -- five launches forward (the window kernel, which draws the pixels and
+    zero-fills the gradient buffer; the render forward's three; ``nsr_tracking_loss``) and three in the backward (compositor backward,
+    dX, pose gradient; + dW / the partial sum only if a decoder wants parameter gradients) instead of ~80.  Returns an fp64 scalar (an ordinary autograd node: an incoming gradient other than 1 scales the pose gradient)."""
     dev = torch.device(device) if device is not None else depth.device
     H0, H1, W0, W1 = int(ignore_edge_H), renderer.H - int(ignore_edge_H), int(ignore_edge_W), renderer.W - int(ignore_edge_W)
     wmeta, c2ws = _window_meta(H0, H1, W0, W1, n_pixels, renderer.W, renderer.fx, renderer.fy, renderer.cx, renderer.cy,
