@@ -466,12 +466,21 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
                     step(st_i, False)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # With a process group alive its watchdog THREAD polls the events of the eager collectives enqueued so far (warm-up, the
+        # shard check of an earlier record).  Under the default "global" capture mode such a query from another thread is an error
+        # while this thread captures -- the watchdog throws, the process aborts (seen with one rank over RCCL when the `strong`
+        # record's capture followed the first record's shard check).  So: let the watchdog reap what has completed, and capture in
+        # "thread_local" mode (only THIS thread's calls are checked; the captured collectives themselves are not watched).
+        cap_mode = "global"
+        if sharded:
+            time.sleep(0.5)
+            cap_mode = "thread_local"
         try:
             for st_i in reps:
                 gph = torch.cuda.CUDAGraph()
                 if shard is not None:                            # the ranks' own pixel generator takes part in the capture
                     gph.register_generator_state(shard.generator(dev))
-                with torch.cuda.graph(gph):
+                with torch.cuda.graph(gph, capture_error_mode=cap_mode):
                     st_name = step(st_i, False)
                 graphs[st_name] = gph
             torch.cuda.synchronize()

@@ -41,7 +41,15 @@ class CapturedStep:
         self.graph = torch.cuda.CUDAGraph()
         for g in generators:
             self.graph.register_generator_state(g)
-        with torch.cuda.graph(self.graph):
+        # With a torch.distributed process group alive (ShardedMapping), its watchdog thread polls the events of earlier eager
+        # collectives: under the default "global" capture mode that query is an error while this thread captures and the watchdog
+        # aborts the process.  "thread_local" checks this thread's calls only; the short sleep lets the watchdog reap what is done.
+        mode = "global"
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            import time
+            time.sleep(0.5)
+            mode = "thread_local"
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.result = fn()                              # static output tensors of the captured iteration
 
     def __call__(self):

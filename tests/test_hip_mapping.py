@@ -55,6 +55,55 @@ def test_window_sampling_is_the_per_frame_loop():
         assert rel_err(got[k], frames[k][0].grad) < 1e-5, k
 
 
+def test_window_kernel_zero_fills_the_iterations_buffer():
+    """nsr_get_samples_window_fused (ABI 7) on the GPU: the rays / mask / kept maximum of the plain window entry point, the span
+    zero-filled to the last float whatever was there (48 MB-sized and tiny, lengths that are not multiples of four), the header
+    {loss = 0, kept max, 0} written by the launch itself, the hand-off words of the state zero again after every call, the call
+    counter advanced only when the kernel drew -- and the same under back-to-back launches on one stream."""
+    import ctypes as C
+    import nice_slam_amd as nsa
+    from nice_slam_amd import _capi, mapping
+    from nice_slam_amd.common import _stream
+    lib = _capi.get_lib()
+    sc = make_scene(seed=83, n_rays=8, small=True)
+    H, W, fx, fy, cx, cy = sc["intr"]
+    K, n = 3, 1500
+    N = K * n
+    frames = _frames(sc, K, DEV)
+    dev = torch.device(DEV)
+    fr, hold = mapping._frames_block([f[0] for f in frames], [f[1] for f in frames], [f[2] for f in frames], dev)
+    lo, hi = mapping._bound_arrays(sc["bound"])
+    crop = (4, H - 4, 5, W - 5)
+    given = torch.randint((H - 8) * (W - 10), (N,), generator=torch.Generator().manual_seed(5)).to(DEV)
+    ref = nsa.get_samples_window(*crop, n, H, W, fx, fy, cx, cy, [f[0] for f in frames], [f[1] for f in frames], [f[2] for f in frames],
+                                 sc["bound"], DEV, indices=given)
+    state = torch.tensor([99, 4, 0, 0], dtype=torch.int64, device=DEV)
+    for zero_n, draw in ((0, False), (7, False), (12 * 1024 * 1024 + 3, False), (70001, True), (12 * 1024 * 1024 + 3, True)):
+        calls = int(state[1])
+        Z = torch.full((4 + zero_n + 8,), float("nan"), dtype=torch.float32, device=DEV)
+        Z[-8:] = 7.0
+        sbuf = torch.full((10 * N + (N + 3) // 4,), float("nan"), dtype=torch.float32, device=DEV)
+        keep = sbuf[10 * N:].view(torch.uint8)[:N]
+        ind = torch.full((N,), -1, dtype=torch.int64, device=DEV) if draw else given.clone()
+        for rep in range(2 if not draw else 1):                # twice in a row: the second launch finds the state as the first left it
+            lib.check(lib.nsr_get_samples_window_fused(None if draw else ind.data_ptr(), ind.data_ptr() if draw else None, state.data_ptr(), K, n,
+                                                       crop[0], crop[1], crop[2], crop[3], W, fx, fy, cx, cy, fr, sbuf.data_ptr(), sbuf.data_ptr() + 12 * N,
+                                                       sbuf.data_ptr() + 24 * N, sbuf.data_ptr() + 28 * N, lo, hi, keep.data_ptr(), Z.data_ptr(),
+                                                       Z.data_ptr() + 16 if zero_n else None, zero_n, _stream(dev)), "fused")
+        torch.cuda.synchronize()
+        assert state.tolist() == [99, calls + (1 if draw else 0), 0, 0]
+        assert torch.all(Z[4:4 + zero_n] == 0) and torch.all(Z[-8:] == 7.0) and Z[0] == 0 and Z[1] == 0 and Z[3] == 0
+        if draw:
+            assert int(ind.min()) >= 0 and int(ind.max()) < (H - 8) * (W - 10)
+            chk = nsa.get_samples_window(*crop, n, H, W, fx, fy, cx, cy, [f[0] for f in frames], [f[1] for f in frames],
+                                         [f[2] for f in frames], sc["bound"], DEV, indices=ind)
+        else:
+            chk = ref
+        assert torch.equal(sbuf[:3 * N].view(N, 3), chk.rays_o) and torch.equal(sbuf[3 * N:6 * N].view(N, 3), chk.rays_d)
+        assert torch.equal(sbuf[6 * N:7 * N], chk.gt_depth) and torch.equal(sbuf[7 * N:10 * N].view(N, 3), chk.gt_color)
+        assert torch.equal(keep.bool(), chk.keep) and float(Z[2]) == float(chk.kept_max) and float(Z[2]) > 0
+
+
 def test_window_kernel_draws_its_own_pixels():
     """Default pixel draw of the fused entry points (mapping.PIXEL_DRAW = "kernel"): indices in range and close to uniform, the
     window's rays are those of the explicit-index path on the drawn indices, every call (and every replay of a captured graph)
