@@ -454,6 +454,7 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
     use_graph = not args.eager and ((not sharded) or os.environ.get("NSR_DIST_GRAPH", "1") == "1") \
         and os.environ.get("NSR_DIST_BACKEND", "nccl") == "nccl"
     graphs = {}
+    window_graph = None
     if use_graph:
         # The iteration is a handful of launches; one hipGraph per stage (identical kernel sequence, fresh torch.randint
         # draws on every replay) removes the host from the loop.
@@ -488,6 +489,29 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
                 for _ in range(3):                      # part of the warm-up, not of the timed region
                     gph.replay()
             torch.cuda.synchronize()
+            # The K timed steps as ONE graph (what tools/slam_synthetic.py does with the iterations of a frame): a replay per step
+            # leaves ~4 us between two graphs and a window of per-step replays pays its first launch and its last wait once per
+            # step sequence anyway -- measured on one box, 20 steps: 3.9995 ms as twenty replays, 3.8648 ms as one (tools/
+            # _window_probe of the round).  NSR_BENCH_WINDOW_GRAPH=0: one replay per step as before.
+            if os.environ.get("NSR_BENCH_WINDOW_GRAPH", "1") == "1" and args.steps <= 512:
+                try:
+                    wg = torch.cuda.CUDAGraph()
+                    if shard is not None:
+                        wg.register_generator_state(shard.generator(dev))
+                    stages_in_window = []
+                    with torch.cuda.graph(wg, capture_error_mode=cap_mode):
+                        for i in range(args.steps):
+                            stages_in_window.append(step(i, False))
+                    torch.cuda.synchronize()
+                    for _ in range(2):
+                        wg.replay()
+                    torch.cuda.synchronize()
+                    window_graph = (wg, stages_in_window)
+                except Exception as e:
+                    if rank == 0:
+                        print(f"[bench] capture of the whole window failed ({type(e).__name__}: {e}); one replay per step", file=sys.stderr)
+                    window_graph = None
+                    torch.cuda.synchronize()
         except Exception as e:                      # e.g. a collective that cannot be captured: run eagerly instead
             if rank == 0:
                 print(f"[bench] graph capture failed ({type(e).__name__}: {e}); falling back to eager", file=sys.stderr)
@@ -508,7 +532,11 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        stages = [timed_step(i) for i in range(args.steps)]
+        if use_graph and window_graph is not None:
+            window_graph[0].replay()
+            stages = list(window_graph[1])
+        else:
+            stages = [timed_step(i) for i in range(args.steps)]
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -574,7 +602,8 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
                                          "window sampling kernel (pixel draw: philox inside the kernel) + render forward (with the mapping loss) + render backward") +
                                         " (all grid + all decoder grads, like the reference autograd), no optimiser"),
                        "decoder_grads": "none (tracking)" if tracking else ("colour decoder only (what Mapper's optimiser steps)" if args.stepped_grads_only else "all decoders (reference autograd semantics)"),
-                       "launch": "hipGraph replay (one captured graph per stage)" if use_graph else "eager",
+                       "launch": ("hipGraph replay (the K timed steps captured as ONE graph, like the iterations of a frame in tools/slam_synthetic.py)" if window_graph is not None
+                                  else "hipGraph replay (one captured graph per stage, one replay per step)") if use_graph else "eager",
                        "activations": "saved by the forward (832 B per point and decoder + 640 B of dY scratch) and consumed by the split "
                                       "backward (dX + dW kernels)",
                        "timed_windows_ms": [round(w_ * 1e3, 3) for w_ in windows], "reported": "median window",
