@@ -732,16 +732,19 @@ def test_full_size_forward_blocks_in_a_subprocess():
     assert " passed" in r.stdout
 
 
-@pytest.mark.parametrize("cells", ["0", "64"])
-def test_hot_voxel_table_extremes_in_a_subprocess(cells):
+@pytest.mark.parametrize("cells,slots", [("0", None), ("64", None), ("64", "16")])
+def test_hot_voxel_table_extremes_in_a_subprocess(cells, slots):
     """The dX kernel's hot-voxel table (LDS rows for the samples next to their ray's origin, claimed with a compare-and-swap,
-    flushed once per block): NSR_DX_HOT_CELLS=0 switches it off, 64 sends EVERY sample of these small scenes through it (slot
-    collisions -> the fall-back to memory atomics is exercised too).  Both extremes against the oracle, like the default of
-    two cells in the rest of this file (the switch is read once per process)."""
+    flushed once per block; since round 5 as many slots as the block's LDS has left): NSR_DX_HOT_CELLS=0 switches it off, 64 sends
+    EVERY sample of these small scenes through it, and with NSR_DX_HOT_SLOTS=16 most of them find their slot taken by another voxel
+    (the fall-back to memory atomics).  All against the oracle, like the default of six cells in the rest of this file (the
+    switches are read once per process)."""
     import subprocess, sys
     if os.environ.get("NSR_DX_HOT_CELLS") is not None:
         pytest.skip("already the inner run")
     env = dict(os.environ, NSR_DX_HOT_CELLS=cells)
+    if slots is not None:
+        env["NSR_DX_HOT_SLOTS"] = slots
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k",
                         "golden_forward or random_scene or saved_activations_equal"],
                        env=env, capture_output=True, text=True, timeout=900)
