@@ -17,6 +17,8 @@
  *   nsr_flat_adam        <- src/Mapper.py:368-387,504, src/Tracker.py:214-222,127  torch.optim.Adam on the dense rest of the
  *                           callers' optimiser (decoder parameter blobs, camera tensors), one launch pair, capturable
  *   nsr_get_samples_window <- src/Mapper.py:437-481  sampling loop over the mapping window + bounding-box pre-filter
+ *   nsr_get_samples_window_fused <- the same as the first launch of a fused iteration: + the pixel draw of src/common.py:99 and the
+ *                           zero fill that `loss.backward()` (src/Mapper.py:503) relies on, inside the one launch (ABI 7)
  *   nsr_pose_grad        <- autograd of src/common.py:74-88 for that window (local BA, src/Mapper.py:417-419)
  *   nsr_pack_rows        <- (none) gather / scatter of the voxel rows + blobs that travel in the multi-GPU all-reduce
  *
