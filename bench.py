@@ -344,7 +344,8 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
         p.requires_grad_(not tracking)                              # (the tracker works on a detached copy, Tracker.py:138)
     if tracking:
         grids = {k: v.detach() for k, v in grids.items()}
-    if args.stepped_grads_only:
+    consumed = args.consumed_grads_only or role == "consumed"
+    if args.stepped_grads_only or consumed:
         renderer.decoder_grads = ("color",)
     if args.render_masked:
         renderer.skip_masked_rays = False
@@ -352,6 +353,15 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
     frames = [(c.to(dev), d.to(dev), col.to(dev)) for c, d, col in sc["frames"]]
     K = len(frames)
     params = list(dec.parameters())
+    consumed_frac = None
+    if consumed and not tracking:
+        # frustum feature selection (Mapper.py:315-333): the optimiser holds val[mask] of the CURRENT frame's mask only; the backward
+        # is told so (Renderer.grad_voxel_masks -> nsr_render_args.grad_voxel_mask) and skips the scatter into every other voxel
+        sel = nsa.FrustumSelector(sc["bound"], H, W, fx, fy, cx, cy)
+        pose = torch.eye(4)
+        pose[:3] = sc["frames"][-1][0][:3].detach().cpu().float()
+        renderer.grad_voxel_masks = {k: sel.voxel_mask(pose, k, v.shape[2:], frames[-1][1]) for k, v in grids.items() if k != "grid_coarse"}
+        consumed_frac = {k[5:]: round(float(m.float().mean()), 3) for k, m in renderer.grad_voxel_masks.items()}
     ev = HipEvents(4)                       # backward, kernel by kernel: start, stop, behind dX, behind dW
     ev_tot = HipEvents(2)                   # backward as a whole: start, stop only (every event record between two kernels costs
                                             # 3-5 us of its own: with four events the sum read 196 us where rocprofv3 had 179)
@@ -601,7 +611,10 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
                                         ("get_samples x window + cat + render_batch_ray + torch loss + backward" if args.unfused else
                                          "window sampling kernel (pixel draw: philox inside the kernel) + render forward (with the mapping loss) + render backward") +
                                         " (all grid + all decoder grads, like the reference autograd), no optimiser"),
-                       "decoder_grads": "none (tracking)" if tracking else ("colour decoder only (what Mapper's optimiser steps)" if args.stepped_grads_only else "all decoders (reference autograd semantics)"),
+                       "decoder_grads": "none (tracking)" if tracking else ("colour decoder only (what Mapper's optimiser steps)" if (args.stepped_grads_only or consumed) else "all decoders (reference autograd semantics)"),
+                       "grid_grads": ("only the voxels of the current frame's frustum mask (what the optimiser holds with frustum_feature_selection, "
+                                      "Mapper.py:315-333,394-401), selected share per grid %s" % consumed_frac) if consumed_frac else
+                                     "dense (reference autograd semantics)",
                        "launch": ("hipGraph replay (the K timed steps captured as ONE graph, like the iterations of a frame in tools/slam_synthetic.py)" if window_graph is not None
                                   else "hipGraph replay (one captured graph per stage, one replay per step)") if use_graph else "eager",
                        "activations": "saved by the forward (832 B per point and decoder + 640 B of dY scratch) and consumed by the split "
@@ -636,7 +649,7 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
                                             (rays_rank * rendered_frac, rays_rank, rendered_frac, 32 if dom == "coarse" else 48),
                                "executed_frac": (pts * (EXEC_BWD_MAC[dom] - FWD_MAC[dom]) * 2
                                                  / (ms * 1e-3)) / FP32_PEAK
-                               if not (args.stepped_grads_only or tracking) else None,
+                               if not (args.stepped_grads_only or consumed or tracking) else None,
                                "executed_note": "MFMA work the backward actually issues (dX + dW for every decoder -- the reference "
                                                 "autograd's semantics) over the same peak; `frac` counts only the necessary part"}
         if dom is not None and "roofline" in res:
@@ -654,7 +667,7 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
                              "executed_frac": pts * 3 * 15360 * 2 / (sp["dx"] * 1e-3) / FP32_PEAK}
                 ker["dw"] = {"kernel": "render_bwd_dw_kernel<color>", "ms": round(sp["dw"], 4),
                              "frac": pts * dw_nec * 2 / (sp["dw"] * 1e-3) / FP32_PEAK,
-                             "executed_frac": pts * ((14336 if args.stepped_grads_only else 47104)) * 2 / (sp["dw"] * 1e-3) / FP32_PEAK}
+                             "executed_frac": pts * ((14336 if (args.stepped_grads_only or consumed) else 47104)) * 2 / (sp["dw"] * 1e-3) / FP32_PEAK}
                 ker["finalize"] = {"kernel": "bwd_finalize_kernel", "ms": round(sp["finalize"], 4)}
             elif sp:
                 ker["dx"] = {"ms": round(sp["dx"], 4)}
@@ -682,12 +695,13 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
         res["kernel_ms"] = {f"render_bwd<{s}>": round(v[0], 4) for s, v in ksum.items()}
         if headline and not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(sc, rays_rank, stages_cfg, mix, crop if tracking else None)
-        if not headline:                                          # the short record that rides in the headline's line
+        if role != "headline":                                    # the short record that rides in the headline's line
             keep_keys = ("value", "unit", "rendered_rays_per_s", "sampled_rays_per_s", "n_gpus", "steps", "ms_per_step", "scaling", "shard_check",
                          "graph_capture", "rccl_ranks", "kernel_ms")
             short = {k: res[k] for k in keep_keys if k in res}
             short["config"] = {k: res["config"][k] for k in ("workload", "rays_per_gpu", "rays_per_iteration", "rays_rendered_per_iteration",
-                                                              "rays_kept_by_prefilter", "stage_mix", "launch", "timed_windows_ms", "parallelism")
+                                                              "rays_kept_by_prefilter", "stage_mix", "launch", "timed_windows_ms", "parallelism",
+                                                              "decoder_grads", "grid_grads")
                                if k in res["config"]}
             if "roofline" in res:
                 short["roofline"] = {k: res["roofline"][k] for k in ("frac", "avg_kernel_ms", "kernel") if k in res["roofline"]}
@@ -717,6 +731,14 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="the drop-in call sequence (get_samples per frame, render_batch_ray, torch loss) instead of mapping_loss")
     ap.add_argument("--stepped-grads-only", action="store_true",
                     help="parameter gradients only for the decoder the reference's optimiser steps (colour); default: all, like the reference autograd")
+    ap.add_argument("--consumed-grads-only", action="store_true",
+                    help="--stepped-grads-only + grid gradients only for the voxels inside the current frame's frustum mask -- what the "
+                         "mapper's optimiser consumes with frustum_feature_selection (Mapper.py:315-333,394-401); default: the reference's "
+                         "dense grid gradient")
+    ap.add_argument("--consumed-record", dest="consumed_record", action="store_true", default=None,
+                    help="after the timed configuration also time it with --consumed-grads-only and report that as `consumed_grads_only` "
+                         "in the same line (default: on for the default single-GPU command)")
+    ap.add_argument("--no-consumed-record", dest="consumed_record", action="store_false")
     ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
                     help="multi-GPU: weak = the configuration's rays per GPU, strong = in total (default: strong for config 3 / 4, else weak)")
     ap.add_argument("--render-masked", action="store_true",
@@ -773,6 +795,15 @@ def main():
         st = measure(args, "3", "strong", world, rank, dev, sharded, "strong")
         if res is not None:
             res["strong"] = st
+    # The same configuration with the gradients restricted to what the mapper's optimiser consumes (colour decoder, frustum-selected
+    # voxels): a SECOND record beside the headline (which stays the reference's dense autograd semantics), never instead of it.
+    want_consumed = args.consumed_record if args.consumed_record is not None else \
+        (args.config == "1" and world == 1 and not sharded and not args.stage and not args.rays and not args.unfused
+         and not args.consumed_grads_only and not args.stepped_grads_only)
+    if want_consumed:
+        cr = measure(args, args.config, scaling, world, rank, dev, sharded, "consumed", rays_override=args.rays, stage_override=args.stage)
+        if res is not None:
+            res["consumed_grads_only"] = cr
     if res is not None:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(res) + "\n").encode())

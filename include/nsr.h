@@ -19,6 +19,8 @@
  *   nsr_get_samples_window <- src/Mapper.py:437-481  sampling loop over the mapping window + bounding-box pre-filter
  *   nsr_get_samples_window_fused <- the same as the first launch of a fused iteration: + the pixel draw of src/common.py:99 and the
  *                           zero fill that `loss.backward()` (src/Mapper.py:503) relies on, inside the one launch (ABI 7)
+ *   nsr_get_samples_window_sharded <- the same for one rank of a ray-sharded iteration: + the batch-global max(gt_depth) of
+ *                           src/utils/Renderer.py:109,144 over ALL ranks' draws, without a collective (ABI 8)
  *   nsr_pose_grad        <- autograd of src/common.py:74-88 for that window (local BA, src/Mapper.py:417-419)
  *   nsr_pack_rows        <- (none) gather / scatter of the voxel rows + blobs that travel in the multi-GPU all-reduce
  *
@@ -43,7 +45,7 @@
 extern "C" {
 #endif
 
-#define NSR_VERSION 7
+#define NSR_VERSION 8
 
 /* stages of NICE.forward (decoder.py:312-342) */
 enum { NSR_STAGE_COARSE = 0, NSR_STAGE_MIDDLE = 1, NSR_STAGE_FINE = 2, NSR_STAGE_COLOR = 3 };
@@ -125,6 +127,14 @@ typedef struct nsr_render_args {
                                  Honoured by calls that will be differentiated (acts + zvals + raw given); a forward-only call
                                  renders every ray.  0 (default): keep only masks the fused loss; every ray is rendered. */
     int32_t pad2_;
+    const uint8_t *grad_voxel_mask[4]; /* ABI 8, opt-in, read by nsr_render_bwd only: per grid slot a [Z][Y][X] byte mask (the layout
+                                 nsr_frustum_mask writes and nsr_masked_adam takes) of the voxels whose gradient the caller will
+                                 CONSUME.  With `frustum_feature_selection` the mapper's optimiser holds only `val[mask]`
+                                 (src/Mapper.py:315-333,394-401): the reference's autograd scatters into the whole grid and
+                                 `val.grad[~mask]` is never read.  Given a mask, the backward's scatter skips voxels whose byte is 0:
+                                 dfeat of voxels inside the mask equals the dense run's (up to the order of the atomic adds),
+                                 dfeat of voxels outside stays as the caller left it (zero).  Ray / pose and decoder gradients are
+                                 unaffected (they never depended on dfeat).  NULL (default) = the reference's dense gradient. */
 } nsr_render_args;
 
 typedef struct nsr_bwd_args {
@@ -216,12 +226,25 @@ int nsr_get_samples_window_draw(int64_t *indices_out, uint64_t *rng_state, int32
  * before the launch.  indices: [K * n] or NULL (then drawn as in nsr_get_samples_window_draw and written to indices_out).
  * state: four uint64 on the device -- {seed, calls so far, 0, 0} -- owned by the caller; words 2 and 3 are the launch's hand-off
  * (blocks done, bit pattern of the running maximum) and are zero again when it ends; two launches that share a state must not
- * overlap.  K, n >= 1. */
+ * overlap.  header must be 16-byte aligned (one 16-byte store), state 8-byte aligned.  K, n >= 1. */
 int nsr_get_samples_window_fused(const int64_t *indices, int64_t *indices_out, uint64_t *state, int32_t K, int64_t n, int32_t H0, int32_t H1,
                                  int32_t W0, int32_t W1, int32_t W_full, float fx, float fy, float cx, float cy, const nsr_frame *frames,
                                  float *rays_o, float *rays_d, float *out_depth, float *out_color,
                                  const double *bound_lo, const double *bound_hi, uint8_t *keep, float *header,
                                  float *zero, int64_t zero_floats, void *stream);
+/* The fused window launch of ONE RANK of a ray-sharded mapping iteration (ABI 8; one process per GPU): the in-kernel
+ * pixel draw of nsr_get_samples_window_fused for this rank's state, and -- instead of an all-reduce of the kept rays' maximum depth,
+ * the one scalar of the WHOLE batch the render needs (src/utils/Renderer.py:109,144) -- the same draw REPEATED for the other ranks:
+ * peer_seeds (HOST array, n_peers <= 15 entries) are the seeds of their states, every rank has made the same number of calls (the
+ * call counter of `state` is used for all of them), keyframes and poses are replicated: extra blocks re-draw peer p's pixels, gather
+ * their depths and apply the bounding-box pre-filter (src/Mapper.py:471-481) without writing any ray, and the header's kept maximum
+ * becomes the maximum over the union batch -- bit-identical on every rank, no collective between the sampling and the render.
+ * header: 16-byte aligned; state: 8-byte aligned (also required by nsr_get_samples_window_fused). */
+int nsr_get_samples_window_sharded(int64_t *indices_out, uint64_t *state, const uint64_t *peer_seeds, int32_t n_peers, int32_t K, int64_t n,
+                                   int32_t H0, int32_t H1, int32_t W0, int32_t W1, int32_t W_full, float fx, float fy, float cx, float cy,
+                                   const nsr_frame *frames, float *rays_o, float *rays_d, float *out_depth, float *out_color,
+                                   const double *bound_lo, const double *bound_hi, uint8_t *keep, float *header,
+                                   float *zero, int64_t zero_floats, void *stream);
 /* gradient of the K poses from the ray gradients of such a window (autograd of src/common.py:74-88; local BA,
  * src/Mapper.py:417-419,441-453): d_c2w + k * out_stride holds rows 0..2 of pose k's gradient, row-major (12 floats;
  * out_stride = 12 for 3x4 poses, 16 for 4x4 ones whose last row the caller zero-fills). */

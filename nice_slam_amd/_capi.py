@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401  -- must be loaded first: libnsr.so binds to the HIP runtime (libamdhip64.so.7) torch already mapped
 
 MAX_SAMPLES = 64
-ABI_VERSION = 7
+ABI_VERSION = 8
 STAGE_ID = {"coarse": 0, "middle": 1, "fine": 2, "color": 3}
 SLOT_NAMES = ("coarse", "middle", "fine", "color")
 
@@ -42,7 +42,8 @@ class NsrRenderArgs(C.Structure):
                 ("gt_color", C.c_void_p), ("keep", C.c_void_p), ("loss", C.c_void_p), ("dl_depth", C.c_void_p), ("dl_rgb", C.c_void_p),
                 ("w_color", C.c_float), ("acts_masks_only", C.c_int32), ("acts", C.c_void_p),
                 ("ev_pass_start", C.c_void_p), ("ev_pass_stop", C.c_void_p),
-                ("skip_masked", C.c_int32), ("pad2_", C.c_int32)]
+                ("skip_masked", C.c_int32), ("pad2_", C.c_int32),
+                ("grad_voxel_mask", C.c_void_p * 4)]
 
 
 class NsrBwdArgs(C.Structure):
@@ -106,6 +107,10 @@ SYMBOLS = (
                                                C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(NsrFrame),
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    ("nsr_get_samples_window_sharded", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                                                 C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(NsrFrame),
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     ("nsr_pose_grad", C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     ("nsr_masked_adam_multi", C.c_int, [C.POINTER(NsrAdamGrid), C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32,

@@ -24,17 +24,35 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found: cannot build libnsr.so")
 
 
+STAMP = os.path.join(HERE, "libnsr.srchash")
+
+
+def source_hash() -> str:
+    """sha256 over the flags and every source / header the library is compiled from"""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def is_fresh() -> bool:
-    if not os.path.exists(OUT):
+    """The library is reused only if it was built from exactly these sources (a content hash written beside it by build_lib:
+    modification times do not say so -- an edit during a compile leaves a NEWER library of OLDER sources)."""
+    if not os.path.exists(OUT) or not os.path.exists(STAMP):
         return False
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    return all(os.path.getmtime(d) <= t for d in deps)
+    try:
+        with open(STAMP) as f:
+            return f.read().strip() == source_hash()
+    except OSError:
+        return False
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and is_fresh():
         return OUT
+    stamp = source_hash()                     # of what the compiler is about to read
     cmd = [hipcc_path(), *FLAGS, "-Rpass-analysis=kernel-resource-usage", *[os.path.join(CSRC, s) for s in SOURCES], "-o", OUT]
     if verbose:
         print(" ".join(cmd))
@@ -42,6 +60,8 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
     _write_resources(res.stderr)
+    with open(STAMP, "w") as f:
+        f.write(stamp + "\n")
     return OUT
 
 

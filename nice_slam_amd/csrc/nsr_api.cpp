@@ -148,7 +148,7 @@ int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays,
         if (g.Z < 1 || g.Y < 1 || g.X < 1) return fail("nsr: bad grid shape");
         if ((long long)g.Z * g.Y * g.X >= (1ll << 26)) return fail("nsr: grid too large for 32-bit voxel indexing");
         nsr::GridDev &G = P.grid[s];
-        G.feat = g.feat; G.dfeat = g.dfeat; G.Z = g.Z; G.Y = g.Y; G.X = g.X;
+        G.feat = g.feat; G.dfeat = g.dfeat; G.gmask = a->grad_voxel_mask[s]; G.Z = g.Z; G.Y = g.Y; G.X = g.X;
         for (int i = 0; i < 3; ++i) {
             if (!(g.hi[i] > g.lo[i])) return fail("nsr: empty normalisation box");
             G.lo[i] = g.lo[i];
@@ -553,7 +553,7 @@ int window_launch(const int64_t *indices, int64_t *indices_out, uint64_t *rng, i
                   int32_t W_full, float fx, float fy, float cx, float cy, const nsr_frame *frames,
                   float *rays_o, float *rays_d, float *out_depth, float *out_color,
                   const double *bound_lo, const double *bound_hi, uint8_t *keep, float *kept_max, void *stream,
-                  float *hdr = nullptr, float *zero = nullptr, int64_t zero_floats = 0) {
+                  float *hdr = nullptr, float *zero = nullptr, int64_t zero_floats = 0, const uint64_t *peer_seeds = nullptr, int32_t n_peers = 0) {
     if (K < 0 || K > NSR_MAX_WINDOW) return fail("nsr_get_samples_window: K must be in [0, 32]");
     if (n < 0 || H1 <= H0 || W1 <= W0 || W_full < W1) return fail("nsr_get_samples_window: bad crop");
     if (K == 0 || n == 0) return 0;
@@ -587,7 +587,13 @@ int window_launch(const int64_t *indices, int64_t *indices_out, uint64_t *rng, i
         if (want > 2048) want = 2048;
         fbx = (want + K - 1) / K;
     }
-    NSR_LAUNCH(nsr::get_samples_window_kernel, dim3((unsigned)(sbx + fbx), K), dim3(tb), 0, stream, P);
+    if (n_peers) {
+        if (n_peers < 0 || n_peers > NSR_MAX_PEERS || !peer_seeds) return fail("nsr_get_samples_window_sharded: 0..15 peers");
+        if (indices || !hdr) return fail("nsr_get_samples_window_sharded: peers need the in-kernel pixel draw (indices == NULL) and the fused header");
+        P.n_peers = n_peers;
+        for (int p = 0; p < n_peers; ++p) P.peer_seed[p] = peer_seeds[p];
+    }
+    NSR_LAUNCH(nsr::get_samples_window_kernel, dim3((unsigned)(sbx * (1 + n_peers) + fbx), K), dim3(tb), 0, stream, P);
     return finish("nsr_get_samples_window");
 }
 }  // namespace
@@ -616,10 +622,24 @@ int nsr_get_samples_window_fused(const int64_t *indices, int64_t *indices_out, u
                                  const double *bound_lo, const double *bound_hi, uint8_t *keep, float *header,
                                  float *zero, int64_t zero_floats, void *stream) {
     if (!state || !header) return fail("nsr_get_samples_window_fused: null pointer");
+    if ((reinterpret_cast<uintptr_t>(header) & 15) || (reinterpret_cast<uintptr_t>(state) & 7))
+        return fail("nsr_get_samples_window_fused: header must be 16-byte aligned (it is written with one 16-byte store), state 8-byte aligned");
     if (!indices && !indices_out) return fail("nsr_get_samples_window_fused: indices or indices_out is required");
     if (K == 0 || n == 0) return fail("nsr_get_samples_window_fused: empty window (the header and the zero span would stay unwritten)");
     return window_launch(indices, indices ? nullptr : indices_out, state, K, n, H0, H1, W0, W1, W_full, fx, fy, cx, cy, frames, rays_o, rays_d,
                          out_depth, out_color, bound_lo, bound_hi, keep, nullptr, stream, header, zero, zero_floats);
+}
+
+int nsr_get_samples_window_sharded(int64_t *indices_out, uint64_t *state, const uint64_t *peer_seeds, int32_t n_peers, int32_t K, int64_t n,
+                                   int32_t H0, int32_t H1, int32_t W0, int32_t W1, int32_t W_full, float fx, float fy, float cx, float cy,
+                                   const nsr_frame *frames, float *rays_o, float *rays_d, float *out_depth, float *out_color,
+                                   const double *bound_lo, const double *bound_hi, uint8_t *keep, float *header,
+                                   float *zero, int64_t zero_floats, void *stream) {
+    if (!state || !header || !indices_out) return fail("nsr_get_samples_window_sharded: null pointer");
+    if ((reinterpret_cast<uintptr_t>(header) & 15) || (reinterpret_cast<uintptr_t>(state) & 7)) return fail("nsr_get_samples_window_sharded: header must be 16-byte, state 8-byte aligned");
+    if (K == 0 || n == 0) return fail("nsr_get_samples_window_sharded: empty window (the header and the zero span would stay unwritten)");
+    return window_launch(nullptr, indices_out, state, K, n, H0, H1, W0, W1, W_full, fx, fy, cx, cy, frames, rays_o, rays_d,
+                         out_depth, out_color, bound_lo, bound_hi, keep, nullptr, stream, header, zero, zero_floats, peer_seeds, n_peers);
 }
 
 int nsr_pose_grad(const int64_t *indices, int32_t K, int64_t n, int32_t H0, int32_t H1, int32_t W0, int32_t W1,

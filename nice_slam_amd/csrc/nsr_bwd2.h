@@ -274,7 +274,7 @@ NSR_DEV void dx_pass(const RenderParams &P) {
                 }
                 sched_fence_emb();
                 const F4 b = load_b1(aux, 16 * Tk + pt);
-                const f32x4 darg = (e0 + e3) * cos_acc4(vfma(qz, splat(b.z), vfma(qy, splat(b.y), qx * splat(b.x))));
+                const f32x4 darg = (e0 + e3) * cos_dx4(vfma(qz, splat(b.z), vfma(qy, splat(b.y), qx * splat(b.x))));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     aB[Tk][0] = fmaf(darg[r], qx[r], aB[Tk][0]); aB[Tk][1] = fmaf(darg[r], qy[r], aB[Tk][1]);
@@ -303,7 +303,7 @@ NSR_DEV void dx_pass(const RenderParams &P) {
 #pragma unroll
             for (int Tk = 0; Tk < kET; ++Tk) {
                 const B4 b = load_b4(aux, 4 * Tk + g);
-                const f32x4 darg = dE[Tk] * cos_acc4(vfma(splat(pz), b.z, vfma(splat(py), b.y, splat(px) * b.x)));
+                const f32x4 darg = dE[Tk] * cos_dx4(vfma(splat(pz), b.z, vfma(splat(py), b.y, splat(px) * b.x)));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { ax = fmaf(darg[r], b.x[r], ax); ay = fmaf(darg[r], b.y[r], ay); az = fmaf(darg[r], b.z[r], az); }
                 sched_fence_emb();
@@ -314,6 +314,9 @@ NSR_DEV void dx_pass(const RenderParams &P) {
         dbg.stamp(4);
         Lvl L;
         if (need_dc) L = make_level(G, cpx, cpy, cpz);
+        // consumed-gradient mask (opt-in, nsr_render_args.grad_voxel_mask): two byte loads per lane, requested here, first used by the
+        // scatter's staging -- like every load of the iteration BEFORE this tile's atomics
+        const unsigned live = (do_grid && G.gmask) ? gmask_bits(G, L, g) : 3u;
         float dux = 0.f, duy = 0.f, duz = 0.f;
         if (RAYS) coord_grad(G, L, g, dc, dux, duy, duz);
         dx_keep(nx);
@@ -322,7 +325,7 @@ NSR_DEV void dx_pass(const RenderParams &P) {
         keep_alive_d(cpx); keep_alive_d(cpy); keep_alive_d(cpz); keep_alive_d(cz);
         dbg.stamp(5);
         if (do_grid && !(P.xflags & 1))
-            scatter_merged(G, L, lane, dc, active, Sw + kDxTx, Sw + kDxTab, gl_off, hot, (float)cz < P.hot_z[KIND]);
+            scatter_merged(G, L, lane, dc, active, Sw + kDxTx, Sw + kDxTab, gl_off, hot, (float)cz < P.hot_z[KIND], live);
         dbg.stamp(6);
         if (RAYS) {
             // d p = d u * (n-1)/2 * 2/(hi-lo) (+ embedding part), fp64 like autograd through Renderer.py:172;
@@ -498,8 +501,8 @@ NSR_DEV float red_g4(float v) { v += shfl_xor(v, 16); v += shfl_xor(v, 32); retu
 // ("G(j, row)": c_dim / 16 tiles).  Waves w and w + 4 share a SIMD, so the units are dealt such that every SIMD carries the
 // same number of MFMAs (14 tiles per 16 points, 18 for the fine decoder):
 //   w = 0..3:  We_w + Wh(j, row) + G(j, row)   with j = 1 (w < 2) or 2, row = w & 1
-//   w = 4, 5:  We_w + G(3, w - 4)              w = 4 also the bias sums of layer 0, w = 5 the output layer
-//   w = 6, 7:  Wh(4, row) + G(4, row) + Wh(3, row),  row = w - 6
+//   w = 4, 5:  We_w + G(3, w - 4)              w = 4 also the bias sums of layer 0
+//   w = 6, 7:  Wh(4, row) + G(4, row) + Wh(3, row),  row = w - 6;  w = 6 also the output layer (VALU sums)
 // The bias sums of layer j go with its Wh unit.  Within a tile the k-steps of ALL the wave's output tiles are issued
 // round-robin (a 16x16x4 fp32 MFMA has a 40-cycle dependent latency against a 32-cycle issue interval).
 template <int KIND, int WAVE>
@@ -511,7 +514,8 @@ struct DwXyzWave {
     static constexpr int GJ = WAVE < 2 ? 1 : (WAVE < 4 ? 2 : (WAVE < 6 ? 3 : 4));        // layer of the G unit
     static constexpr int W2J = WAVE >= 6 ? 3 : 0;                                         // layer of the second Wh unit
     static constexpr int ROW = WAVE < 4 ? (WAVE & 1) : (WAVE < 6 ? WAVE - 4 : WAVE - 6);
-    static constexpr bool kOut = WAVE == 5, kB0 = WAVE == 4;
+    static constexpr bool kOut = WAVE == 6, kB0 = WAVE == 4;    // (round 6: the output layer's VALU sums moved from wave 5 -- an embedding k-tile, i.e. sines,
+                                                                // + a feature block: the block's slowest role, tests/perf/ts_dw.py -- to wave 6, which evaluates no sine)
     f32x4 we[4];               // [W0 To 0, W0 To 1, W3e To 0, W3e To 1] x embedding k-tile WAVE
     f32x4 wh[2], w2[2], gg[4]; // row ROW of layers WJ / W2J (hidden-state k-tiles), of layer GJ (feature k-tiles)
     float vb, vb2, vb0[2];     // bias sums: layer WJ, layer W2J (row ROW); layer 0 (kB0)
@@ -595,7 +599,7 @@ struct DwXyzWave {
 #if defined(NSR_X_DW_NOSIN)              // A/B build (tools/build_ts.sh): what the sines cost this kernel (wrong numbers, timing only)
             e = vfma(qz, splat(bz), vfma(qy, splat(by), qx * splat(bx)));
 #else
-            e = sin_acc4(vfma(qz, splat(bz), vfma(qy, splat(by), qx * splat(bx))));     // decoder.py:29-30
+            e = sin_dw4(vfma(qz, splat(bz), vfma(qy, splat(by), qx * splat(bx))));     // decoder.py:29-30
 #endif
             if (kB0) { vb0[0] += sum4(o.y[0]); vb0[1] += sum4(o.y[1]); }
         }

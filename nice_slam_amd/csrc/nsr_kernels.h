@@ -41,6 +41,7 @@ NSR_DEV double tmin(double a, double b) { return (a < b || a != a) ? a : b; }
 struct GridDev {
     const float *feat;
     float *dfeat;
+    const unsigned char *gmask;   // backward, optional: [Z][Y][X] bytes, 0 = nobody consumes this voxel's gradient (nsr_render_args.grad_voxel_mask)
     int Z, Y, X;
     double lo[3];
     double ext[3];      // hi - lo (the divisor of normalize_3d_coordinate, common.py:281-283)
@@ -446,7 +447,8 @@ NSR_DEV void hot_flush(const HotTab &H, const GridDev &G) {       // after a blo
 }
 
 // part 1 (the wave that owns the tile): dc point-major into Tx, the class table into tab
-NSR_DEV void scatter_stage(const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab, bool hot = false) {
+// `live`: bit c = the lane's corner 2 g + c takes part (consumed-gradient mask, GridDev.gmask; 3 = both)
+NSR_DEV void scatter_stage(const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab, bool hot = false, unsigned live = 3u) {
     const int pt = lane & 15, g = lane >> 4;
     int *vt = reinterpret_cast<int *>(tab);
     float *wt = tab + 128;
@@ -454,7 +456,7 @@ NSR_DEV void scatter_stage(const Lvl &L, int lane, const Act<2> &dc, bool active
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int k = 2 * g + c, cls = k ^ L.par;
-        vt[pt * 8 + cls] = active ? (corner_vox(L, k) | (hot ? kHotBit : 0)) : -1;
+        vt[pt * 8 + cls] = (active && ((live >> c) & 1u)) ? (corner_vox(L, k) | (hot ? kHotBit : 0)) : -1;
         wt[pt * 8 + cls] = corner_w(L, k);
     }
 }
@@ -518,9 +520,15 @@ NSR_DEV void scatter_walk(const GridDev &G, int lane, const float *Tx, const flo
         }
     }
 }
+// the consumed-gradient mask bytes of the lane's two corners (requested early, consumed by scatter_stage)
+NSR_DEV unsigned gmask_bits(const GridDev &G, const Lvl &L, int g) {
+    unsigned live = 3u;
+    if (G.gmask) live = (G.gmask[corner_vox(L, 2 * g)] != 0 ? 1u : 0u) | (G.gmask[corner_vox(L, 2 * g + 1)] != 0 ? 2u : 0u);
+    return live;
+}
 NSR_DEV void scatter_merged(const GridDev &G, const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab,
-                            int lds_grid = -1, HotTab hot = HotTab{-1, 0}, bool hot_pt = false) {
-    scatter_stage(L, lane, dc, active, Tx, tab, hot.off >= 0 && hot_pt);
+                            int lds_grid = -1, HotTab hot = HotTab{-1, 0}, bool hot_pt = false, unsigned live = 3u) {
+    scatter_stage(L, lane, dc, active, Tx, tab, hot.off >= 0 && hot_pt, live);
     wave_fence();
     scatter_walk(G, lane, Tx, tab, lds_grid, hot);
     wave_fence();
@@ -579,6 +587,15 @@ NSR_DEV f32x4 sin_poly4(f32x4 r, u32x4 sign) {
 }
 // quotient by the "1.5 * 2^23" trick: t = x/pi + 12582912 has round(x/pi) in its low mantissa bits (|x| < 1e7), so
 // its parity is bit 0 of the float and no float->int conversion / compare / select is needed for the sign
+#if defined(NSR_X_LIBM_SIN)
+// CPU emulator A/B only (tests/perf/parity_causes.py): correctly rounded sines -- how much of a parity miss is the kernels' own sine?
+// NSR_X_LIBM_SIN = 1: every sine / cosine; 2: the forward's embedding only; 3: the dW kernel's re-evaluation only; 4: the dX kernel's cosines only
+}  // namespace nsr
+#include <cmath>
+namespace nsr {
+NSR_DEV f32x4 sin_libm4(f32x4 x) { f32x4 r; for (int i = 0; i < 4; ++i) r[i] = (float)std::sin((double)x[i]); return r; }
+NSR_DEV f32x4 cos_libm4(f32x4 x) { f32x4 r; for (int i = 0; i < 4; ++i) r[i] = (float)std::cos((double)x[i]); return r; }
+#endif
 NSR_DEV f32x4 sin_acc4(f32x4 x) {
     const f32x4 t = vfma(x, splat(0.318309886183790672f), splat(12582912.f));
     const f32x4 k = t - splat(12582912.f);
@@ -595,6 +612,50 @@ NSR_DEV f32x4 cos_acc4(f32x4 x) {
     r = (r - splat(1.57079637050628662f)) + splat(4.37113882867379289e-08f);
     return sin_poly4(r, (__builtin_bit_cast(u32x4, t) << 31) ^ 0x80000000u);
 }
+// the three places a Fourier feature is evaluated: the forward's embedding, the dW kernel's re-evaluation of it, the dX kernel's cosines
+#if defined(NSR_X_LIBM_SIN)
+NSR_DEV f32x4 sin_fwd4(f32x4 x) { return (NSR_X_LIBM_SIN == 1 || NSR_X_LIBM_SIN == 2) ? sin_libm4(x) : sin_acc4(x); }
+NSR_DEV f32x4 sin_dw4(f32x4 x) { return (NSR_X_LIBM_SIN == 1 || NSR_X_LIBM_SIN == 3) ? sin_libm4(x) : sin_acc4(x); }
+NSR_DEV f32x4 cos_dx4(f32x4 x) { return (NSR_X_LIBM_SIN == 1 || NSR_X_LIBM_SIN == 4) ? cos_libm4(x) : cos_acc4(x); }
+#else
+// The FORWARD's embedding sine in fp64 (round 6).  At ScanNet-size bounds (|p.B| ~ 1e3 rad) every gradient tensor of the path is a
+// heavily cancelling sum: the fp32 reference itself sits 1e-2 from an fp64 evaluation, and matching IT to 1e-4 means matching the
+// rounding of its per-element values.  Measured with these sources under the CPU emulator (tests/perf/parity_causes.py ->
+// profiles/r06_parity_causes.json, scannet/fine, 5000 rays): with the packed fp32 sine above (abs err 1.5e-7, i.e. one ulp off a
+// correctly rounded sine for a good share of the arguments) 31 of 50 gradient tensors miss 1e-4 (max 1.82e-4 -- the GPU's numbers);
+// with a correctly rounded sine in the forward's embedding ALONE none does (max 7.9e-5), and the dW kernel's re-evaluation and the
+// dX kernel's cosines do not matter at all.  fp64 vector operations issue at the unpacked fp32 rate on gfx950: ~16 operations per
+// sine instead of ~6, in the forward's pass kernel only.  x -> k = round(x / pi) through the 1.5 * 2^52 trick (parity = sign),
+// r = x - k pi (one fma: |k| < 2^21, the product's error k * 1.2e-16 is far below fp32), odd Taylor polynomial of degree 13 on
+// [-pi/2, pi/2] (truncation 6.7e-10 abs = 0.01 ulp of the fp32 result), ONE rounding to fp32.
+NSR_DEV float sin_f64(float x) {
+    const double xd = (double)x;
+    const double t = fma(xd, 0.31830988618379067, 6755399441055744.0);
+    const double k = t - 6755399441055744.0;
+    const double r = fma(k, -3.141592653589793, xd);
+    const double r2 = r * r;
+    double p = fma(r2, 1.6059043836821613e-10, -2.505210838544172e-08);      // 1/13!, -1/11!
+    p = fma(p, r2, 2.7557319223985893e-06);                                  // 1/9!
+    p = fma(p, r2, -1.984126984126984e-04);                                  // -1/7!
+    p = fma(p, r2, 8.333333333333333e-03);                                   // 1/5!
+    p = fma(p, r2, -1.6666666666666666e-01);                                 // -1/3!
+    const float s = (float)fma(p * r2, r, r);
+    const unsigned sign = (unsigned)__builtin_bit_cast(unsigned long long, t) << 31;
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s) ^ sign);
+}
+NSR_DEV f32x4 sin_fwd4(f32x4 x) {
+#if defined(NSR_X_FWD_SIN_F32)               // A/B build (tools/build_ts.sh): the packed fp32 sine in the forward, as until round 5 -- what the fp64 one costs
+    return sin_acc4(x);
+#else
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = sin_f64(x[i]);
+    return r;
+#endif
+}
+NSR_DEV f32x4 sin_dw4(f32x4 x) { return sin_acc4(x); }
+NSR_DEV f32x4 cos_dx4(f32x4 x) { return cos_acc4(x); }
+#endif
 // Fourier matrix rows of four consecutive channels (group = channel / 4): Bx[4], By[4], Bz[4]
 struct B4 { f32x4 x, y, z; };
 NSR_DEV B4 load_b4(const float *aux, int group) {
@@ -638,7 +699,7 @@ NSR_DEV void embed(Act<kET> &e, const float *aux, float px, float py, float pz, 
     for (int T = 0; T < kET; ++T) {
         const B4 b = load_b4(aux, 4 * T + g);
         const f32x4 arg = vfma(splat(pz), b.z, vfma(splat(py), b.y, splat(px) * b.x));     // decoder.py:29
-        e.t[T] = sin_acc4(arg);                                                            // decoder.py:30
+        e.t[T] = sin_fwd4(arg);                                                            // decoder.py:30
         sched_fence_emb();                  // bound the ILP the scheduler extracts from 24 independent sines
     }
 }
@@ -1220,6 +1281,7 @@ NSR_KERNEL void get_samples_kernel(const SampleParams P) {
 // with its bounding-box pre-filter (:471-481) as a byte mask + the kept rays' maximum depth.  grid.y = frame.
 // ------------------------------------------------------------------------------------------------
 #define NSR_MAX_WINDOW 32
+#define NSR_MAX_PEERS 15
 // philox4x32-10 (Salmon et al., SC'11; the generator torch.randint runs on the device): 128-bit counter, 64-bit key
 NSR_DEV unsigned philox_word(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
 #pragma unroll
@@ -1255,16 +1317,26 @@ struct WindowParams {
     float *zero;                       // 16-byte aligned
     long long zero_n;                  // floats
     int sample_bx;                     // x-blocks that sample; the rest (if any) fill
+    // Multi-GPU without a collective for the batch-global depth cap (nsr_get_samples_window_sharded): every rank draws its pixels from
+    // philox(counter = (ray, call), key = ITS seed) and all ranks make the same calls, so a rank can re-draw every other rank's pixels:
+    // x-blocks [sample_bx, sample_bx * (1 + n_peers)) repeat the draw, the depth gather and the pre-filter test of peer p's rays with
+    // peer_seed[p] -- no output, only their kept maximum joins the hand-off word.  The header's maximum is then the maximum over the
+    // UNION batch, computed redundantly (and bit-identically) on every rank: Renderer.py:109,144 without an all-reduce.
+    int n_peers;
+    unsigned long long peer_seed[NSR_MAX_PEERS];
 };
 
 NSR_KERNEL void get_samples_window_kernel(const WindowParams P) {
-    const long long i = (long long)bid_x() * nthreads() + tid();
+    const int draw_bx = P.sample_bx * (1 + P.n_peers);       // x-blocks that draw rays: this rank's, then the peers' (maximum only)
+    const int peer = bid_x() < draw_bx ? bid_x() / P.sample_bx : 0;      // 0: this rank's own rays
+    const bool own = peer == 0;
+    const long long i = (long long)(bid_x() - peer * P.sample_bx) * nthreads() + tid();
     const int k = bid_y();
     float vmax = 0.f;                  // this thread's candidate for the kept rays' maximum depth
-    if (bid_x() >= P.sample_bx) {
+    if (bid_x() >= draw_bx) {
         // a fill block: its share of the span, then done (it takes no part in the hand-off below: a thousand blocks counting
         // themselves on one word were 10 us of same-address atomics)
-        const long long fb = nblk_x() - P.sample_bx, chunk = (long long)k * fb + (bid_x() - P.sample_bx), nchunk = fb * P.K;
+        const long long fb = nblk_x() - draw_bx, chunk = (long long)k * fb + (bid_x() - draw_bx), nchunk = fb * P.K;
         const long long n4 = P.zero_n >> 2;
         for (long long q = chunk * nthreads() + tid(); q < n4; q += nchunk * nthreads()) st4(P.zero + q * 4, F4{0.f, 0.f, 0.f, 0.f});
         if (chunk == 0 && tid() < (int)(P.zero_n & 3)) P.zero[n4 * 4 + tid()] = 0.f;
@@ -1283,19 +1355,21 @@ NSR_KERNEL void get_samples_window_kernel(const WindowParams P) {
     if (P.indices) {
         idx = P.indices[t];
     } else {
-        const unsigned long long seed = P.rng[0], call = P.rng[1];
+        const unsigned long long seed = own ? P.rng[0] : P.peer_seed[peer - 1], call = P.rng[1];
         const unsigned r = philox_word((unsigned)t, (unsigned)(t >> 32), (unsigned)call, (unsigned)(call >> 32), (unsigned)seed, (unsigned)(seed >> 32));
         idx = (long long)(((unsigned long long)r * P.crop_pixels) >> 32);                  // uniform up to 2^-32 * crop_pixels
-        P.indices_out[t] = idx;
+        if (own) P.indices_out[t] = idx;
     }
     const int row = (int)(idx / P.crop_w) + P.H0, col = (int)(idx % P.crop_w) + P.W0;
     const long long pix = (long long)row * P.W_full + col;
     const float gd = P.depth[k][pix];
-    const float c0 = P.color[k][pix * 3 + 0], c1 = P.color[k][pix * 3 + 1], c2 = P.color[k][pix * 3 + 2];    // (all four in flight together)
-    P.out_depth[t] = gd;
-    P.out_color[t * 3 + 0] = c0;
-    P.out_color[t * 3 + 1] = c1;
-    P.out_color[t * 3 + 2] = c2;
+    if (own) {
+        const float c0 = P.color[k][pix * 3 + 0], c1 = P.color[k][pix * 3 + 1], c2 = P.color[k][pix * 3 + 2];    // (all four in flight together)
+        P.out_depth[t] = gd;
+        P.out_color[t * 3 + 0] = c0;
+        P.out_color[t * 3 + 1] = c1;
+        P.out_color[t * 3 + 2] = c2;
+    }
     const float dx = ((float)col - P.cx) / P.fx, dy = -(((float)row - P.cy) / P.fy), dzv = -1.f;
     double tb = 0.0;
 #pragma unroll
@@ -1303,14 +1377,13 @@ NSR_KERNEL void get_samples_window_kernel(const WindowParams P) {
         const float *R = Rm[a];
         const float d = (dx * R[0] + dy * R[1]) + dzv * R[2];       // common.py:87: products, then left-to-right sum
         const float o = R[3];
-        P.rays_d[t * 3 + a] = d;
-        P.rays_o[t * 3 + a] = o;
+        if (own) { P.rays_d[t * 3 + a] = d; P.rays_o[t * 3 + a] = o; }
         const double t0 = (P.lo[a] - (double)o) / (double)d, t1 = (P.hi[a] - (double)o) / (double)d;
         const double m = tmax(t0, t1);
         tb = (a == 0) ? m : tmin(tb, m);
     }
     const bool kp = tb >= (double)gd;
-    if (P.keep) P.keep[t] = kp ? 1 : 0;
+    if (P.keep && own) P.keep[t] = kp ? 1 : 0;
     if (kp && gd > 0.f) vmax = gd;
     }
     if (P.hdr) {
@@ -1325,7 +1398,7 @@ NSR_KERNEL void get_samples_window_kernel(const WindowParams P) {
         // the last block to get here (every thread of every block has read the call counter by then) advances it
         block_sync();
         if (tid() == 0) {
-            const unsigned long long total = (unsigned long long)P.sample_bx * P.K;          // the sampling blocks
+            const unsigned long long total = (unsigned long long)draw_bx * P.K;              // the sampling blocks (peers' included)
             if (atomic_fetch_add_global_u64(P.rng + 2, 1ull) == total - 1) {
                 P.rng[2] = 0ull;
                 if (!P.indices) P.rng[1] = P.rng[1] + 1ull;

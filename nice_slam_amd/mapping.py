@@ -127,6 +127,16 @@ def _launch_window(indices, K, n, crop, intr, frames, bound6, sbuf, keep, kmax_p
         state = getattr(indices, "_nsr_state", None)
         if state is None:
             state = _draw_state(dev)
+        peers = getattr(indices, "_nsr_peers", None)
+        if peers and draw:
+            # one rank of a ray-sharded iteration: the other ranks' draws are repeated for the batch-global depth cap (no collective)
+            seeds = (C.c_uint64 * len(peers))(*[int(v) for v in peers])
+            lib.check(lib.nsr_get_samples_window_sharded(indices.data_ptr(), state.data_ptr(), seeds, len(peers), K, n, H0, H1, W0, W1, W_full,
+                                                         fx, fy, cx, cy, frames, sbuf.data_ptr(), sbuf.data_ptr() + 12 * N, sbuf.data_ptr() + 24 * N,
+                                                         sbuf.data_ptr() + 28 * N, bound6[0], bound6[1], keep.data_ptr(), hdr.data_ptr(),
+                                                         zero.data_ptr() if zero.numel() else None, zero.numel(), _stream(dev)),
+                      "nsr_get_samples_window_sharded")
+            return
         lib.check(lib.nsr_get_samples_window_fused(None if draw else indices.data_ptr(), indices.data_ptr() if draw else None, state.data_ptr(),
                                                    K, n, H0, H1, W0, W1, W_full, fx, fy, cx, cy, frames, sbuf.data_ptr(),
                                                    sbuf.data_ptr() + 12 * N, sbuf.data_ptr() + 24 * N, sbuf.data_ptr() + 28 * N, bound6[0],
@@ -190,13 +200,14 @@ def pose_grads(indices, K, n, crop, intr, g_o, g_d, shapes, out=None) -> List[to
     return [out[k, :shp[0], :] for k, shp in enumerate(shapes)], out
 
 
-def _window_meta(H0, H1, W0, W1, n, W, fx, fy, cx, cy, c2ws, depths, colors, bound, device, indices, draw_state=None):
+def _window_meta(H0, H1, W0, W1, n, W, fx, fy, cx, cy, c2ws, depths, colors, bound, device, indices, draw_state=None, peer_seeds=None):
     K = len(depths)
     dev = torch.device(device)
     if indices is None and (PIXEL_DRAW == "kernel" or draw_state is not None) and dev.type == "cuda":
         indices = torch.empty((K * n,), dtype=torch.int64, device=dev)            # filled by the window kernel (see PIXEL_DRAW)
         indices._nsr_draw = True
         indices._nsr_state = draw_state                                           # None: the device's default state
+        indices._nsr_peers = list(peer_seeds) if (peer_seeds and FUSED_FILL) else None   # (ShardedMapping: the other ranks' seeds)
     elif indices is None:
         indices = torch.randint((H1 - H0) * (W1 - W0), (K * n,), device=dev)      # one draw for the window (common.py:99 per frame)
     else:
@@ -273,7 +284,9 @@ class _MappingLossFn(torch.autograd.Function):
         keep = sbuf[10 * N:].view(torch.uint8)[:N]
         _launch_window(indices, K, n, crop, intr, frames, _bound_arrays(bound), sbuf, keep, kmax.data_ptr(), dev,
                        fused=(Z[:4], Z[4:]) if fuse_fill else None)
-        if sharder is not None:                                # the depth cap is a scalar of the WHOLE batch (Renderer.py:109,144)
+        if sharder is not None and not (fuse_fill and getattr(indices, "_nsr_peers", None)):
+            # the depth cap is a scalar of the WHOLE batch (Renderer.py:109,144): one 4-byte MAX all-reduce -- unless the window kernel
+            # has just re-drawn the other ranks' pixels itself and its header already holds the maximum over the union (peer seeds)
             sharder.reduce_max(kmax)
         rays_o, rays_d = sbuf[:3 * N].view(N, 3), sbuf[3 * N:6 * N].view(N, 3)
         gt_depth, gt_color = sbuf[6 * N:7 * N], sbuf[7 * N:10 * N].view(N, 3)
@@ -359,7 +372,7 @@ class _MappingLossFn(torch.autograd.Function):
 def mapping_loss(renderer, c, decoders, frames: Sequence[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], pixs_per_image: int,
                  stage: str, w_color: float = 0.2, device=None, indices: Optional[torch.Tensor] = None, coarse_mapper: bool = False,
                  crop: Optional[Tuple[int, int, int, int]] = None, out: Optional[dict] = None, sharder=None,
-                 draw_state: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 draw_state: Optional[torch.Tensor] = None, peer_seeds=None) -> torch.Tensor:
     """One mapping iteration's loss (src/Mapper.py:437-493) as a single autograd node.
 
     ``frames``: ``(c2w, depth [H,W], color [H,W,3])`` per frame of the window, in the reference's order; a pose that requires
@@ -374,7 +387,7 @@ def mapping_loss(renderer, c, decoders, frames: Sequence[Tuple[torch.Tensor, tor
     H0, H1, W0, W1 = crop if crop is not None else (0, renderer.H, 0, renderer.W)
     wmeta, c2ws = _window_meta(H0, H1, W0, W1, pixs_per_image, renderer.W, renderer.fx, renderer.fy, renderer.cx, renderer.cy,
                                [f[0] for f in frames], [f[1] for f in frames], [f[2] for f in frames], renderer.bound, dev, indices,
-                               draw_state=draw_state)
+                               draw_state=draw_state, peer_seeds=peer_seeds)
     slots = stage_slots(stage)
     grids = _prep_grids(c, stage, dev)
     gates = [_gate(dev, torch.is_grad_enabled() and decoders.sub(s).wants_grad() and

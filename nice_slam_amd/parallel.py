@@ -237,8 +237,10 @@ class ShardedMapping:
     * every rank draws ITS OWN ``pixs_per_image`` pixels per keyframe from a generator seeded per rank (independent draws even
       when every process seeds torch identically, as the reference does: the union over ranks is the iteration's batch),
       renders them and forms its partial loss -- nothing is gathered, the loss is a sum over rays;
-    * one MAX all-reduce of a single float between the sampling kernel and the render: the bounding-box pre-filter's kept
-      rays' maximum depth is a scalar of the WHOLE batch (Renderer.py:109,144) and must agree on every rank;
+    * the bounding-box pre-filter's kept rays' maximum depth is a scalar of the WHOLE batch (Renderer.py:109,144) and must agree
+      on every rank: with the in-kernel pixel draw (default) every rank's window kernel re-draws the other ranks' pixels and takes
+      the maximum over the union itself -- no collective (round 6); with explicit indices / torch draws / ``peer_draw=False`` it
+      is one MAX all-reduce of a single float between the sampling kernel and the render;
     * ONE packed SUM all-reduce per iteration carries everything the backward produced: the frustum-selected voxel rows of
       every grid gradient (``set_voxel_masks``; dense grid gradients without masks), the flat decoder-gradient blobs, the pose
       gradients (local BA) and the partial loss.  Gather and scatter around it are one kernel each (``nsr_pack_rows``).
@@ -246,8 +248,14 @@ class ShardedMapping:
     The grids, decoders and poses are replicated; after ``loss.backward()`` every rank holds the full-batch gradients (inside
     the voxel masks for the grids), so the replicated optimiser steps stay identical."""
 
-    def __init__(self, renderer, group=None, seed: int = 0):
+    def __init__(self, renderer, group=None, seed: int = 0, peer_draw: bool = True):
         self.renderer, self.group = renderer, group
+        # round 6: with the in-kernel pixel draw every rank can repeat every other rank's draw (philox keyed by the rank's seed, the
+        # call counter advances in lock step), so the batch-global depth cap needs NO collective: the window kernel re-draws the
+        # peers' pixels and takes the maximum over the union itself (nsr_get_samples_window_sharded).  False, explicit `indices`,
+        # or more than 16 ranks: the 4-byte MAX all-reduce between the sampling and the render, as before.
+        self.peer_draw = bool(peer_draw)
+        self.max_collectives = 0             # MAX all-reduces issued so far (diagnostics / tests)
         self._rows = {}
         self._pending = None
         self.last_exchange_floats = 0
@@ -279,9 +287,18 @@ class ShardedMapping:
             self._draw_state = {}                    # one state tensor per device, kept for the life of the object: a graph
         st = self._draw_state.get(dev)               # captured on a device has that tensor's address baked in
         if st is None:
-            s = (self.seed * 1000003 + 7919 * (dist.get_rank(self.group) + 1)) & ((1 << 63) - 1)
-            st = self._draw_state[dev] = torch.tensor([s, 0, 0, 0], dtype=torch.int64, device=dev)
+            st = self._draw_state[dev] = torch.tensor([self.rank_seed(dist.get_rank(self.group)), 0, 0, 0], dtype=torch.int64, device=dev)
         return st
+
+    def rank_seed(self, rank: int) -> int:
+        """seed of rank ``rank``'s in-kernel draw state (every rank can compute every other rank's)"""
+        return (self.seed * 1000003 + 7919 * (int(rank) + 1)) & ((1 << 63) - 1)
+
+    def peer_seeds(self):
+        world, me = dist.get_world_size(self.group), dist.get_rank(self.group)
+        if not self.peer_draw or world < 2 or world > 16:
+            return None
+        return [self.rank_seed(r) for r in range(world) if r != me]
 
     def set_voxel_masks(self, masks):
         """dict grid key -> bool/uint8 [Z,Y,X] voxel mask (``FrustumSelector.voxel_mask``), identical on every rank;
@@ -292,6 +309,7 @@ class ShardedMapping:
                 self._rows[k] = torch.as_tensor(m).reshape(-1).ne(0).nonzero().squeeze(1).contiguous()
 
     def reduce_max(self, kmax: torch.Tensor):
+        self.max_collectives += 1
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX, group=self.group)
 
     def collect(self, d_grids, gflat, publish) -> bool:          # renderer.render_backward hook: park, exchange() follows
@@ -347,12 +365,13 @@ class ShardedMapping:
         """This rank's share of one mapping iteration (``pixs_per_image`` pixels per frame HERE); returns the rank's partial
         loss -- ``backward()`` leaves the all-rank gradients on every rank (and the all-rank loss in ``last_total_loss``)."""
         from . import mapping
-        state = None
+        state, peers = None, None
         if indices is None:                  # this rank's own draw (see __init__): never the global generator / the device's state
             dev = frames[0][1].device
             if mapping.PIXEL_DRAW == "kernel" and dev.type == "cuda":
                 state = self.draw_state(dev)
+                peers = self.peer_seeds()
             else:
                 indices = self._draw(len(frames) * int(pixs_per_image), self.renderer.H * self.renderer.W, dev)
         return mapping.mapping_loss(self.renderer, c, decoders, frames, pixs_per_image, stage, w_color=w_color, indices=indices,
-                                    coarse_mapper=(stage == "coarse"), out=out, sharder=self, draw_state=state)
+                                    coarse_mapper=(stage == "coarse"), out=out, sharder=self, draw_state=state, peer_seeds=peers)

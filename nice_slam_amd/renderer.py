@@ -298,9 +298,11 @@ def render_backward(a, meta, kept, need, g_depth, g_var, g_rgb, zero_buf=None, g
             dg = buf[off:off + cnt].view(1, Z, Y, X, ch).permute(0, 4, 1, 2, 3)      # [1,C,Z,Y,X], channels-last strides
             off += cnt
             a.grid[i].dfeat = dg.data_ptr()
+            a.grad_voxel_mask[i] = renderer._grad_voxel_mask_ptr(s, grids[s])
             d_grids.append(dg)
         else:
             a.grid[i].dfeat = None
+            a.grad_voxel_mask[i] = None
             d_grids.append(None)
     d_o = d_d = None
     if need_ray:
@@ -403,6 +405,11 @@ class Renderer(object):
         # produces dW for every decoder in every stage although src/Mapper.py:335-341 only ever steps the colour
         # decoder (and the fine one when fix_fine is False); None = reference semantics (requires_grad decides).
         self.decoder_grads = None
+        # Optional, opt-in: {"grid_middle": uint8 [Z,Y,X] tensor, ...} (what FrustumSelector.voxel_mask returns, frustum.py) -- the
+        # voxels whose gradient the caller will consume.  With `frustum_feature_selection` the mapper's optimiser only holds
+        # `val[mask]` (src/Mapper.py:315-333,394-401); given the same masks, the backward's scatter skips every other voxel
+        # (their gradient stays zero instead of being computed and thrown away).  None = the reference's dense gradient.
+        self.grad_voxel_masks = None
         self.profile_events = None              # optional callable(stage) -> (hipEvent_t start, stop[, behind dX, behind dW]) for the backward
         self.profile_fwd_events = None          # optional callable(stage) -> (hipEvent_t start, stop) around the forward's decoder-pass kernel
         self._gt_max = None                     # set by the multi-GPU wrapper: batch-global max(gt_depth)
@@ -416,6 +423,15 @@ class Renderer(object):
         d["profile_events"] = None
         d["profile_fwd_events"] = None
         return d
+
+    def _grad_voxel_mask_ptr(self, slot: str, grid: torch.Tensor):
+        m = None if not self.grad_voxel_masks else (self.grad_voxel_masks.get("grid_" + slot, self.grad_voxel_masks.get(slot)))
+        if m is None:
+            return None
+        if m.dtype != torch.uint8 or tuple(m.shape) != tuple(grid.shape[2:]) or m.device != grid.device or not m.is_contiguous():
+            raise _capi.NsrError(f"grad_voxel_masks[{slot}]: expected a contiguous uint8 {tuple(grid.shape[2:])} tensor on {grid.device}, "
+                                 f"got {m.dtype} {tuple(m.shape)} on {m.device}")
+        return m.data_ptr()
 
     def _workspace(self, nfloats: int, dev) -> torch.Tensor:
         ws = self._ws.get(dev)

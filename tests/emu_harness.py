@@ -149,7 +149,8 @@ class HostScene:
         return out
 
     def backward(self, stage, fwd, d_depth, d_var, d_rgb, want_grid=True, want_params=True, want_rays=True, max_blocks=0,
-                 overwrite_dparams=False, grad_scale=None, from_forward=False, in_place=False):
+                 overwrite_dparams=False, grad_scale=None, from_forward=False, in_place=False, grad_voxel_masks=None):
+        """grad_voxel_masks: None or {slot: uint8 [Z][Y][X]} -- nsr_render_args.grad_voxel_mask (consumed-gradient masks)"""
         if "acts" not in fwd:                              # forward without an activation buffer: run the saving forward now
             assert not from_forward and not in_place
             was, self.save_acts = self.save_acts, True
@@ -167,6 +168,12 @@ class HostScene:
             i = _capi.SLOT_NAMES.index(s)
             a.grid[i].dfeat = None
             a.dec[i].dparams = None
+            gm = None if grad_voxel_masks is None else grad_voxel_masks.get(s)
+            if gm is not None:
+                gm = np.ascontiguousarray(gm, dtype=np.uint8)
+                assert gm.shape == self.grids[s].shape[:3], (gm.shape, self.grids[s].shape)
+                keep.append(gm)
+            a.grad_voxel_mask[i] = ptr(gm)
             if want_grid:
                 res["d_grid_" + s] = np.zeros_like(self.grids[s])
                 a.grid[i].dfeat = ptr(res["d_grid_" + s])

@@ -35,7 +35,7 @@ def test_header_symbols_are_bound_and_exported(lib):
 
 def test_sizes_and_error_reporting(lib):
     from nice_slam_amd.layout import param_count
-    assert lib.nsr_version() == 7
+    assert lib.nsr_version() == 8
     # [passes][13 + 10 slots][points padded to 16][16] + d raw [.][4] + fp32 positions [.][4] + positions [.][4] doubles
     assert lib.nsr_acts_floats(0, 1000, 32) == 23 * 32000 * 16 + 32000 * 16
     assert lib.nsr_acts_floats(3, 1000, 48) == 3 * 23 * 48000 * 16 + 48000 * 16

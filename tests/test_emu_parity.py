@@ -903,3 +903,48 @@ def test_flat_adam_is_torch_adam(emu):
         assert rel_err(M[i], opt.state[ref[i]]["exp_avg"].numpy()) < 2e-6 and rel_err(V[i], opt.state[ref[i]]["exp_avg_sq"].numpy()) < 2e-6
     assert np.array_equal(P[2], ref[2].detach().numpy())            # lr = 0: parameters untouched, moments moved
 
+
+
+@pytest.mark.parametrize("stage", ["coarse", "middle", "color"])
+def test_consumed_gradient_voxel_masks(emu, stage):
+    """nsr_render_args.grad_voxel_mask (ABI 8, opt-in): with `frustum_feature_selection` the mapper's optimiser holds only
+    `val[mask]` (src/Mapper.py:315-333,394-401).  Given the same byte masks the scatter skips every other voxel: gradients of voxels
+    inside a mask equal the dense run's (the emulator's adds happen in one order: exactly, whenever the run structure is the same;
+    1e-6 otherwise -- a masked-out voxel between two samples of a run splits the run sum), voxels outside stay exactly zero, every
+    other gradient is untouched."""
+    s = make_scene(seed=131, n_rays=21, small=True)
+    sc = _host_scene(emu, s["grids"], s["params"], s["bound"].numpy())
+    w = s["w"]
+    args = (w["depth"].numpy(), w["var"].numpy(), w["rgb"].numpy())
+    fwd = sc.forward(stage, s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy())
+    dense = sc.backward(stage, fwd, *args)
+    rng = np.random.default_rng(5)
+    masks = {k: (rng.random(g.shape[:3]) < 0.6).astype(np.uint8) for k, g in sc.grids.items()}
+    masks["middle"][...] = 1                                   # one grid fully selected, one partly, (colour stage) one without a mask
+    use = {k: v for k, v in masks.items() if k != "color"}
+    fwd = sc.forward(stage, s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy())
+    got = sc.backward(stage, fwd, *args, grad_voxel_masks=use)
+    from emu_harness import stage_slots
+    for slot in stage_slots(stage):
+        k = "d_grid_" + slot
+        a, b = got[k][0], dense[k][0]                          # [32, Z, Y, X]
+        m = use.get(slot)
+        if m is None:
+            assert rel_err(a, b) < 1e-6, k
+            continue
+        inside = m.astype(bool)[None]
+        assert np.all(a[:, ~inside[0]] == 0.0), k              # nothing was scattered outside the mask
+        assert m.all() or np.abs(b[:, ~inside[0]]).max() > 0, k    # (and the dense run does put gradient there: the test has teeth)
+        den = np.abs(b).max()
+        assert np.abs(np.where(inside, a - b, 0.0)).max() <= 1e-6 * den, k
+    for k in dense:
+        if not k.startswith("d_grid_"):
+            assert rel_err(got[k], dense[k]) < 1e-6, k
+    # an all-zero mask: no grid gradient at all, everything else unchanged
+    fwd = sc.forward(stage, s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy())
+    none = sc.backward(stage, fwd, *args, grad_voxel_masks={k: np.zeros_like(v) for k, v in masks.items()})
+    for k in dense:
+        if k.startswith("d_grid_"):
+            assert not none[k].any(), k
+        else:
+            assert rel_err(none[k], dense[k]) < 1e-6, k

@@ -518,3 +518,65 @@ def test_fused_losses_are_ordinary_autograd_nodes():
     c2w.grad = None
     nsa.tracking_loss(renderer, grids_dev, dec, c2w, sc["depth_img"].to(DEV), sc["color_img"].to(DEV), 150, 4, 4, indices=idx[:150] % ((H - 8) * (W - 8))).backward()
     assert rel_err(ga, 0.25 * c2w.grad) < 2e-5
+
+
+@pytest.mark.parametrize("stage,fused", [("middle", True), ("color", True), ("color", False)])
+def test_consumed_gradient_voxel_masks(stage, fused):
+    """Renderer.grad_voxel_masks (nsr_render_args.grad_voxel_mask, ABI 8; opt-in): with `frustum_feature_selection` the mapper's
+    optimiser holds only `val[mask]` (src/Mapper.py:315-333,394-401), the rest of the reference's dense grid gradient is thrown
+    away.  With the frustum masks handed to the renderer the backward's scatter skips those voxels: gradients inside a mask equal
+    the dense run's up to the order of the atomic adds, gradients outside are EXACTLY zero, decoder and pose gradients are the
+    dense run's.  Through the fused iteration and through render_batch_ray + autograd."""
+    import nice_slam_amd as nsa
+    sc = make_scene(seed=83, n_rays=8, small=True)
+    H, W, fx, fy, cx, cy = sc["intr"]
+    renderer, dec, grids_dev = build_product(sc, DEV)
+    K, n = 3, 200
+    idx = torch.randint(H * W, (K * n,), generator=torch.Generator().manual_seed(6))
+    sel = nsa.FrustumSelector(sc["bound"], H, W, fx, fy, cx, cy)
+    frames0 = _frames(sc, K, DEV)
+    pose = torch.eye(4)
+    pose[:3] = frames0[-1][0][:3].detach().cpu()
+    masks = {k: sel.voxel_mask(pose, k, v.shape[2:], frames0[-1][1]) for k, v in grids_dev.items() if k != "grid_coarse"}
+    assert all(0.02 < float(m.float().mean()) < 0.98 for m in masks.values()), {k: float(m.float().mean()) for k, m in masks.items()}
+
+    def run(use_masks):
+        renderer.grad_voxel_masks = masks if use_masks else None
+        frames = _frames(sc, K, DEV, grad=True)
+        c = {k: v.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) for k, v in grids_dev.items()}
+        for p in dec.parameters():
+            p.requires_grad_(True); p.grad = None
+        try:
+            if fused:
+                loss = nsa.mapping_loss(renderer, c, dec, frames, n, stage, w_color=0.2, indices=idx)
+            else:
+                w = nsa.get_samples_window(0, H, 0, W, n, H, W, fx, fy, cx, cy, [f[0] for f in frames], [f[1] for f in frames],
+                                           [f[2] for f in frames], sc["bound"], DEV, indices=idx)
+                depth, _, color = renderer.render_batch_ray(c, dec, w.rays_d, w.rays_o, DEV, stage, gt_max=w.kept_max, gt_depth=w.gt_depth)
+                loss = (torch.abs(w.gt_depth - depth) * (w.keep & (w.gt_depth > 0))).sum() + 0.2 * (torch.abs(w.gt_color - color) * w.keep[:, None]).sum()
+            loss.backward()
+        finally:
+            renderer.grad_voxel_masks = None
+        return ({k: v.grad.clone() for k, v in c.items() if v.grad is not None},
+                {k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None}, [f[0].grad.clone() for f in frames])
+
+    g0, p0, c0 = run(False)
+    g1, p1, c1 = run(True)
+    assert set(g0) == set(g1) and len(g0) == {"middle": 1, "color": 3}[stage]
+    for k in g0:
+        m = masks[k].bool()[None, None]                                     # [1, 1, Z, Y, X]
+        dense, got = g0[k], g1[k]
+        assert float(dense.masked_fill(m, 0).abs().max()) > 0, k           # the dense run does scatter outside the mask
+        assert float(got.masked_fill(m, 0).abs().max()) == 0.0, k          # the masked run does not: exact zeros
+        assert rel_err(got.masked_fill(~m, 0), dense.masked_fill(~m, 0)) < 1e-5, k
+    for k in p0:
+        assert rel_err(p1[k], p0[k]) < 2e-5, k
+    for k in range(K):
+        assert rel_err(c1[k], c0[k]) < 1e-5, k
+    with pytest.raises(Exception, match="grad_voxel_masks"):
+        renderer.grad_voxel_masks = {"grid_middle": masks["grid_middle"].float()}
+        try:
+            run_c = {k: v.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) for k, v in grids_dev.items()}
+            nsa.mapping_loss(renderer, run_c, dec, _frames(sc, K, DEV), n, stage, w_color=0.2, indices=idx).backward()
+        finally:
+            renderer.grad_voxel_masks = None

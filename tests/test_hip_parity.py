@@ -29,7 +29,7 @@ def _compare(got, ref, tag, sc=None, stage=None, **kw):
 def test_native_library_is_the_path():
     from nice_slam_amd import _capi
     lib = _capi.get_lib()
-    assert lib.path.endswith("libnsr.so") and lib.nsr_version() == _capi.ABI_VERSION == 7
+    assert lib.path.endswith("libnsr.so") and lib.nsr_version() == _capi.ABI_VERSION == 8
 
 
 def test_golden_fixture_through_hip(golden):
