@@ -261,6 +261,7 @@ def verify_shards(nsa, shard, renderer, grids, dec, frames, per_frame, stage, H,
         fr = [(f[0].detach().clone().requires_grad_(True), f[1], f[2]) for f in frames]
         loss = fn(fr, indices, n)
         loss.backward()
+        shard.finish_exchange()                                 # (split exchange: the collective + the scatter; else a no-op)
         torch.cuda.synchronize()
         out = {"grid/" + k: g.grad.detach().clone() for k, g in grids.items() if g.grad is not None}
         out.update({"param/" + k: p.grad.detach().clone() for k, p in dec.named_parameters() if p.grad is not None})
@@ -381,8 +382,10 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
     shard = None
     if sharded:
         shard = ShardedMapping(renderer)
-        exchange = f"rays sharded x{world}: each rank samples, renders and differentiates its share; one MAX all-reduce of 1 float " \
-                   f"(batch-global depth cap) + ONE packed SUM all-reduce per iteration (dense grid gradients + decoder blob)"
+        exchange = f"rays sharded x{world}: each rank samples, renders and differentiates its share; " + \
+                   ("the batch-global depth cap without a collective (every rank's window kernel re-draws the other ranks' pixels)"
+                    if (shard.peer_seeds() and not tracking) else "one MAX all-reduce of 1 float (batch-global depth cap)") + \
+                   " + ONE packed SUM all-reduce per iteration (dense grid gradients + decoder blob)"
         if not args.dense_exchange and not tracking:
             # The mapper optimises only the voxels inside the current frame's frustum mask (Mapper.py:315-333), identical
             # on every rank: exchange those voxel rows only
@@ -401,7 +404,7 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
     if tracking:
         cam = frames[0][0][:3].clone().requires_grad_(True)       # the pose under optimisation (gradient w.r.t. the 3x4 matrix)
 
-    def step(it, timed):
+    def step(it, timed, finish=True):
         stage = stage_of(it)
         for g in grids.values():
             g.grad = None
@@ -427,6 +430,8 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
         elif shard is not None:
             loss = shard.mapping_loss(grids, dec, frames, per_frame, stage)
             nsa.backward(loss)
+            if finish:                                            # (split exchange: the collective + the scatter; otherwise a no-op)
+                shard.finish_exchange()
         elif args.unfused:                                        # the reference's call sequence through the drop-in surface
             ro, rd, gd, gc = [], [], [], []
             for c2w, dimg, cimg in frames:
@@ -460,9 +465,19 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
             torch.cuda._sleep(2_000_000)
             step(st_i, "total" if j < 4 else "split")
     torch.cuda.synchronize()
-    # RCCL collectives are capturable too; NSR_DIST_GRAPH=0 forces the eager path for multi-rank runs
-    use_graph = not args.eager and ((not sharded) or os.environ.get("NSR_DIST_GRAPH", "1") == "1") \
-        and os.environ.get("NSR_DIST_BACKEND", "nccl") == "nccl"
+    # Multi-rank launch modes (NSR_DIST_GRAPH): "1" (default) everything captured, the RCCL collective included (one graph for the K
+    # timed steps); "segments": the kernels before and behind the iteration's ONE collective as two captured segments per stage with
+    # the collective eager between them (ShardedMapping.split_exchange) -- what a failed capture of a collective falls back to, and the
+    # only graph mode of a backend that cannot be captured (gloo); "0": eager.  Fallback chain: captured -> segments -> eager.
+    dist_env = os.environ.get("NSR_DIST_GRAPH", "1")
+    backend_capturable = os.environ.get("NSR_DIST_BACKEND", "nccl") == "nccl"
+    dist_mode = None
+    if sharded:
+        dist_mode = "eager" if (args.eager or dist_env == "0") else ("segments" if (dist_env == "segments" or not backend_capturable) else "captured")
+        if tracking and dist_mode == "segments":
+            dist_mode = "captured"                 # replicas only: the tracking iteration has no collective to keep out of a graph
+    use_graph = not args.eager and (not sharded or dist_mode == "captured")
+    segments = {}
     graphs = {}
     window_graph = None
     if use_graph:
@@ -477,15 +492,8 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
                     step(st_i, False)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        # With a process group alive its watchdog THREAD polls the events of the eager collectives enqueued so far (warm-up, the
-        # shard check of an earlier record).  Under the default "global" capture mode such a query from another thread is an error
-        # while this thread captures -- the watchdog throws, the process aborts (seen with one rank over RCCL when the `strong`
-        # record's capture followed the first record's shard check).  So: let the watchdog reap what has completed, and capture in
-        # "thread_local" mode (only THIS thread's calls are checked; the captured collectives themselves are not watched).
-        cap_mode = "global"
-        if sharded:
-            time.sleep(0.5)
-            cap_mode = "thread_local"
+        # (capture mode: "thread_local" while a process group is alive -- its watchdog thread polls events, nice_slam_amd/graphs.py)
+        cap_mode = nsa.graphs.default_capture_error_mode()
         try:
             for st_i in reps:
                 gph = torch.cuda.CUDAGraph()
@@ -522,17 +530,48 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
                         print(f"[bench] capture of the whole window failed ({type(e).__name__}: {e}); one replay per step", file=sys.stderr)
                     window_graph = None
                     torch.cuda.synchronize()
-        except Exception as e:                      # e.g. a collective that cannot be captured: run eagerly instead
+        except Exception as e:                      # e.g. a collective that cannot be captured: kernel segments instead (multi-rank), else eager
             if rank == 0:
-                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); falling back to eager", file=sys.stderr)
+                print(f"[bench] graph capture failed ({type(e).__name__}: {e}); falling back to {'kernel segments' if shard is not None and not tracking else 'eager'}", file=sys.stderr)
             graphs.clear()
             use_graph = False
+            if shard is not None and not tracking:
+                dist_mode = "segments (captured mode fell back)"
+            torch.cuda.synchronize()
+    if shard is not None and dist_mode is not None and dist_mode.startswith("segments"):
+        # two graphs per stage around the one eager collective: A = sampling + forward + backward + pack, B = scatter + publish
+        shard.split_exchange = True
+        try:
+            for st_i in reps:
+                def first(st_i=st_i):
+                    step(st_i, False, finish=False)
+                    rec = shard.deferred()
+                    if rec is None:
+                        raise RuntimeError("the iteration did not qualify for the split exchange")
+                    return rec
+                seg = nsa.graphs.SegmentedStep(first, shard.reduce_deferred, shard.scatter_deferred, warmup=2, device=dev,
+                                               generators=(shard.generator(dev),))
+                segments[stage_of(st_i)] = seg
+            torch.cuda.synchronize()
+            for seg in segments.values():
+                for _ in range(3):
+                    seg()
+            torch.cuda.synchronize()
+        except Exception as e:
+            if rank == 0:
+                print(f"[bench] segment capture failed ({type(e).__name__}: {e}); falling back to eager", file=sys.stderr)
+            segments.clear()
+            shard.split_exchange = False
+            dist_mode = "eager (segment capture fell back)"
             torch.cuda.synchronize()
 
     def timed_step(i):
+        stage = stage_of(i)
+        if segments:
+            segments[stage]()
+            return stage
         if not use_graph:
             return step(i, False)
-        stage = stage_of(i)
         graphs[stage].replay()
         return stage
 
@@ -616,7 +655,8 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
                                       "Mapper.py:315-333,394-401), selected share per grid %s" % consumed_frac) if consumed_frac else
                                      "dense (reference autograd semantics)",
                        "launch": ("hipGraph replay (the K timed steps captured as ONE graph, like the iterations of a frame in tools/slam_synthetic.py)" if window_graph is not None
-                                  else "hipGraph replay (one captured graph per stage, one replay per step)") if use_graph else "eager",
+                                  else "hipGraph replay (one captured graph per stage, one replay per step)") if use_graph else
+                                 ("hipGraph replay of two kernel segments per iteration, the one all-reduce eager between them" if segments else "eager"),
                        "activations": "saved by the forward (832 B per point and decoder + 640 B of dY scratch) and consumed by the split "
                                       "backward (dX + dW kernels)",
                        "timed_windows_ms": [round(w_ * 1e3, 3) for w_ in windows], "reported": "median window",
@@ -680,6 +720,19 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
                                                    "of its own event records (rocprofv3 of the same command reads 5-10 % less per kernel); "
                                                    "`avg_kernel_ms` / `frac` come from iterations with (start, stop) only")
                 res["roofline"]["furthest_from_peak"] = furthest
+            # every stage of the timed mix, not only the dominant one (12 of the 20 steps of the driver's command are middle / fine)
+            fsum, per_stage = ev_fwd.summary(), {}
+            for st_, (ms_b, _) in ksum.items():
+                pts_s = rays_rank * rendered_frac * (32 if st_ == "coarse" else 48)
+                rec_ = {"backward_ms": round(ms_b, 4), "backward_frac": pts_s * (NEC_MAC[st_] - FWD_MAC[st_]) * 2 / (ms_b * 1e-3) / FP32_PEAK,
+                        "backward_executed_frac": None if (args.stepped_grads_only or consumed or tracking) else
+                        pts_s * (EXEC_BWD_MAC[st_] - FWD_MAC[st_]) * 2 / (ms_b * 1e-3) / FP32_PEAK,
+                        "steps_in_timed_window": stages.count(st_)}
+                if st_ in fsum:
+                    rec_["forward_pass_ms"] = round(fsum[st_][0], 4)
+                    rec_["forward_pass_frac"] = pts_s * FWD_MAC[st_] * 2 / (fsum[st_][0] * 1e-3) / FP32_PEAK
+                per_stage[st_] = rec_
+            res["roofline"]["stages"] = per_stage
             nst = {st_: stages.count(st_) for st_ in set(stages)}
             flop_iter = sum(cnt * rays_rank * rendered_frac * (32 if st_ == "coarse" else 48) * NEC_MAC[st_] * 2 for st_, cnt in nst.items()) / max(1, len(stages))
             if not tracking:
@@ -689,7 +742,11 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
         if shard is not None:
             res["config"]["grad_exchange_MB_last_iter"] = round(shard.last_exchange_floats * 4 / 1e6, 2)
             res["rccl_ranks"] = world
-            res["graph_capture"] = "ok" if use_graph else ("off (--eager / NSR_DIST_GRAPH=0)" if args.eager or os.environ.get("NSR_DIST_GRAPH", "1") != "1" else "fell_back")
+            res["graph_capture"] = "ok" if use_graph else ("segments" if segments else ("off (--eager / NSR_DIST_GRAPH=0)" if args.eager or dist_env == "0" else "fell_back"))
+            res["dist_mode"] = {"mode": dist_mode if (use_graph or segments or dist_mode.startswith("eager")) else "eager (fell back)",
+                                "collectives_per_iteration": {"max": 0 if (shard.peer_seeds() and not tracking) else 1, "sum": 1},
+                                "modes": "captured: kernels + the RCCL collective in one graph for the K steps | segments: two kernel graphs per "
+                                         "iteration, the collective eager between them | eager: every launch from the host"}
         if shard_check is not None:
             res["shard_check"] = shard_check
         res["kernel_ms"] = {f"render_bwd<{s}>": round(v[0], 4) for s, v in ksum.items()}
@@ -697,7 +754,7 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
             res["cpu_baseline"] = cpu_baseline(sc, rays_rank, stages_cfg, mix, crop if tracking else None)
         if role != "headline":                                    # the short record that rides in the headline's line
             keep_keys = ("value", "unit", "rendered_rays_per_s", "sampled_rays_per_s", "n_gpus", "steps", "ms_per_step", "scaling", "shard_check",
-                         "graph_capture", "rccl_ranks", "kernel_ms")
+                         "graph_capture", "dist_mode", "rccl_ranks", "kernel_ms")
             short = {k: res[k] for k in keep_keys if k in res}
             short["config"] = {k: res["config"][k] for k in ("workload", "rays_per_gpu", "rays_per_iteration", "rays_rendered_per_iteration",
                                                               "rays_kept_by_prefilter", "stage_mix", "launch", "timed_windows_ms", "parallelism",

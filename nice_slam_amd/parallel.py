@@ -248,8 +248,11 @@ class ShardedMapping:
     The grids, decoders and poses are replicated; after ``loss.backward()`` every rank holds the full-batch gradients (inside
     the voxel masks for the grids), so the replicated optimiser steps stay identical."""
 
-    def __init__(self, renderer, group=None, seed: int = 0, peer_draw: bool = True):
+    def __init__(self, renderer, group=None, seed: int = 0, peer_draw: bool = True, split_exchange: bool = False):
         self.renderer, self.group = renderer, group
+        self.split_exchange = bool(split_exchange)   # see finish_exchange(): pack inside backward(), collective + scatter behind it
+        self._deferred, self._leafs = None, None
+        self.sum_collectives = 0             # packed SUM all-reduces issued so far
         # round 6: with the in-kernel pixel draw every rank can repeat every other rank's draw (philox keyed by the rank's seed, the
         # call counter advances in lock step), so the batch-global depth cap needs NO collective: the window kernel re-draws the
         # peers' pixels and takes the maximum over the union itself (nsr_get_samples_window_sharded).  False, explicit `indices`,
@@ -318,48 +321,116 @@ class ShardedMapping:
 
     def exchange(self, named_grads, pose_base, loss32):
         """``named_grads``: [(grid key, channels-last gradient)] of this backward; ``pose_base``: [K,4,4] pose gradients or
-        None; ``loss32``: 1-element fp32 tensor holding this rank's partial loss.  All are summed over the ranks in place."""
+        None; ``loss32``: 1-element fp32 tensor holding this rank's partial loss.  All are summed over the ranks in place --
+        unless ``split_exchange`` is set (and the iteration qualifies, see ``finish_exchange``): then this call only PACKS, and the
+        caller runs the collective and the scatter after ``backward()`` has returned."""
         from . import _capi
         from .common import _stream
         gflat, publish = self._pending if self._pending is not None else (None, None)
         self._pending = None
         lib = _capi.get_lib()
         dev = loss32.device
-        rows_arr = (_capi.NsrRows * max(1, len(named_grads)))()
-        n_rows_total, dense = 0, []
-        ng = 0
+        leafs, self._leafs = self._leafs, None
+        split = self.split_exchange and pose_base is None and leafs is not None and \
+            all(k in leafs and leafs[k].grad is None for k, _ in named_grads)
+        keys, rows_of, dense, n_rows_total = [], [], [], 0
         for k, g in named_grads:
             rows = self._rows.get(k)
             if rows is None:
-                dense.append(g)
+                dense.append((k, g))
                 continue
             if rows.device != dev:
                 rows = self._rows[k] = rows.to(dev)
             if not g.is_contiguous(memory_format=torch.channels_last_3d):
                 raise RuntimeError("ShardedMapping: grid gradients must be channels-last (what render backward produces)")
-            rows_arr[ng].grid, rows_arr[ng].rows, rows_arr[ng].n_rows = g.data_ptr(), rows.data_ptr(), rows.numel()
+            keys.append(k)
+            rows_of.append((g, rows))
             n_rows_total += rows.numel()
-            ng += 1
         spans = [t for t in (gflat, None if pose_base is None else pose_base.view(-1), loss32) if t is not None]
-        span_arr = (_capi.NsrSpan * len(spans))()
-        for i, t in enumerate(spans):
-            span_arr[i].ptr, span_arr[i].n = t.data_ptr(), t.numel()
         total = n_rows_total * 32 + sum(t.numel() for t in spans)
         buf = torch.empty((total,), dtype=torch.float32, device=dev)
+        rec = {"keys": keys, "rows": [r for _, r in rows_of], "spans": spans, "buf": buf, "dense": dense, "publish": publish,
+               "leafs": leafs if split else None, "loss32": loss32, "dev": dev}
         with _capi.on_device(dev):                               # two launches + a collective on the gradients' device
-            stream = _stream(dev)
-            lib.check(lib.nsr_pack_rows(rows_arr, ng, span_arr, len(spans), buf.data_ptr(), 0, stream), "nsr_pack_rows")
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-            lib.check(lib.nsr_pack_rows(rows_arr, ng, span_arr, len(spans), buf.data_ptr(), 1, stream), "nsr_pack_rows")
-        floats = total
-        for g in dense:                                          # grids without a mask: dense, in place (one more collective each)
+            self._pack_rows(lib, rec, [g for g, _ in rows_of], 0, _stream(dev))
+            if split:
+                # the kernels up to here and the scatter behind the collective can be two captured graph segments with the
+                # collective eager between them (bench.py NSR_DIST_GRAPH=segments): finish_exchange() = reduce_deferred() + scatter_deferred()
+                self._deferred = rec
+                return
+            self._reduce(rec, [g for _, g in dense])
+            self._pack_rows(lib, rec, [g for g, _ in rows_of], 1, _stream(dev))
+        self._finish(rec)
+
+    @staticmethod
+    def _pack_rows(lib, rec, grid_tensors, mode, stream):
+        from . import _capi
+        ng = len(grid_tensors)
+        rows_arr = (_capi.NsrRows * max(1, ng))()
+        for i, (g, rows) in enumerate(zip(grid_tensors, rec["rows"])):
+            rows_arr[i].grid, rows_arr[i].rows, rows_arr[i].n_rows = g.data_ptr(), rows.data_ptr(), rows.numel()
+        span_arr = (_capi.NsrSpan * len(rec["spans"]))()
+        for i, t in enumerate(rec["spans"]):
+            span_arr[i].ptr, span_arr[i].n = t.data_ptr(), t.numel()
+        lib.check(lib.nsr_pack_rows(rows_arr, ng, span_arr, len(rec["spans"]), rec["buf"].data_ptr(), mode, stream), "nsr_pack_rows")
+
+    def _reduce(self, rec, dense_tensors):
+        self.sum_collectives += 1
+        dist.all_reduce(rec["buf"], op=dist.ReduceOp.SUM, group=self.group)
+        floats = rec["buf"].numel()
+        for g in dense_tensors:                                  # grids without a mask: dense, in place (one more collective each)
             _, v, _ = _voxel_rows(g)
             dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
             floats += v.numel()
         self.last_exchange_floats = floats
-        self.last_total_loss = loss32
-        if publish is not None:
-            publish()
+
+    def _finish(self, rec):
+        self.last_total_loss = rec["loss32"]
+        if rec["publish"] is not None:
+            rec["publish"]()
+
+    # -- split exchange -------------------------------------------------------------------------------------------------------
+    # `split_exchange = True`: backward() returns with the iteration's gradients PACKED but not yet summed; the caller then runs
+    #     rec = sharder.deferred(); sharder.reduce_deferred(rec); sharder.scatter_deferred(rec)      (= finish_exchange())
+    # Everything before and everything behind the collective is kernels only, so both halves replay from hipGraphs while the
+    # collective itself stays an ordinary eager call -- the middle path between "collectives captured in the graph" and a
+    # fully eager iteration (a capture that fails with N > 1 RCCL ranks then costs one graph boundary, not the 4x of eager
+    # launches).  The scatter writes into the `.grad` tensors autograd has produced by then (it may have cloned the backward's
+    # buffers), so an iteration qualifies only if those were None before (no accumulation) and no pose is optimised (local BA:
+    # the blocking exchange runs instead, inside backward(), as without the flag).
+    def deferred(self):
+        return self._deferred
+
+    def _grad_targets(self, rec, keys):
+        out = []
+        for k in keys:
+            g = rec["leafs"][k].grad
+            if g is None or not g.is_contiguous(memory_format=torch.channels_last_3d):
+                raise RuntimeError(f"ShardedMapping.split_exchange: {k}.grad is missing or not channels-last after backward()")
+            out.append(g)
+        return out
+
+    def reduce_deferred(self, rec=None):
+        rec = rec if rec is not None else self._deferred
+        if rec is not None:
+            self._reduce(rec, self._grad_targets(rec, [k for k, _ in rec["dense"]]))
+
+    def scatter_deferred(self, rec=None):
+        from . import _capi
+        from .common import _stream
+        rec = rec if rec is not None else self._deferred
+        if rec is None:
+            return
+        with _capi.on_device(rec["dev"]):
+            self._pack_rows(_capi.get_lib(), rec, self._grad_targets(rec, rec["keys"]), 1, _stream(rec["dev"]))
+        self._finish(rec)
+
+    def finish_exchange(self):
+        """after ``backward()`` of a ``split_exchange`` iteration: the collective + the scatter (no-op if backward() ran the blocking exchange)"""
+        rec, self._deferred = self._deferred, None
+        if rec is not None:
+            self.reduce_deferred(rec)
+            self.scatter_deferred(rec)
 
     def mapping_loss(self, c, decoders, frames, pixs_per_image, stage, w_color: float = 0.2, indices=None, out=None):
         """This rank's share of one mapping iteration (``pixs_per_image`` pixels per frame HERE); returns the rank's partial
@@ -373,5 +444,6 @@ class ShardedMapping:
                 peers = self.peer_seeds()
             else:
                 indices = self._draw(len(frames) * int(pixs_per_image), self.renderer.H * self.renderer.W, dev)
+        self._leafs = {k: v for k, v in c.items() if torch.is_tensor(v)} if self.split_exchange else None
         return mapping.mapping_loss(self.renderer, c, decoders, frames, pixs_per_image, stage, w_color=w_color, indices=indices,
                                     coarse_mapper=(stage == "coarse"), out=out, sharder=self, draw_state=state, peer_seeds=peers)
