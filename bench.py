@@ -668,7 +668,7 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
             nec = pts * (NEC_MAC[dom] - FWD_MAC[dom]) * 2
             ach = nec / (ms * 1e-3)
             traffic, tsrc = None, None
-            tpath = next((p_ for p_ in (os.path.join(ROOT, "profiles", n_) for n_ in ("r05_traffic.json", "r04_traffic.json")) if os.path.exists(p_)), None)
+            tpath = next((p_ for p_ in (os.path.join(ROOT, "profiles", n_) for n_ in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json")) if os.path.exists(p_)), None)
             if tpath and cfg_id == "1" and rays_rank == 1000 and dom == "color":       # from a separate rocprofv3 --pmc run (tools/pmc_bench.sh)
                 tall = json.load(open(tpath))                 # one entry per kernel: the backward = the sum over its kernels
                 ks = [k for k in tall if any(n_ in k for n_ in ("render_bwd_dx_kernel<3", "render_bwd_dw_kernel<3", "bwd_finalize", "comp_bwd"))]
@@ -739,6 +739,11 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
                 res["roofline"]["iteration"] = {"necessary_flop_per_iteration": flop_iter, "ms": dt / args.steps * 1e3,
                                                 "frac": flop_iter / (dt / args.steps) / FP32_PEAK,
                                                 "note": "forward + backward necessary FLOP of the timed stage mix over the timed region's wall time per iteration"}
+        if os.environ.get("NSR_DEBUG_PTRS") == "1":                 # measurement: where the iteration's buffers landed (mode study of the dX kernel)
+            from nice_slam_amd import mapping as _mp
+            res["buffer_ptrs"] = {st_: {k_: (hex(v_) if isinstance(v_, int) and k_ not in ("Z_bytes", "acts_bytes") else
+                                              ({a_: hex(b_) for a_, b_ in v_.items()} if isinstance(v_, dict) else v_))
+                                         for k_, v_ in d_.items()} for st_, d_ in (_mp.DEBUG_PTRS or {}).items()}
         if shard is not None:
             res["config"]["grad_exchange_MB_last_iter"] = round(shard.last_exchange_floats * 4 / 1e6, 2)
             res["rccl_ranks"] = world

@@ -626,19 +626,19 @@ NSR_DEV f32x4 cos_dx4(f32x4 x) { return (NSR_X_LIBM_SIN == 1 || NSR_X_LIBM_SIN =
 // with a correctly rounded sine in the forward's embedding ALONE none does (max 7.9e-5), and the dW kernel's re-evaluation and the
 // dX kernel's cosines do not matter at all.  fp64 vector operations issue at the unpacked fp32 rate on gfx950: ~16 operations per
 // sine instead of ~6, in the forward's pass kernel only.  x -> k = round(x / pi) through the 1.5 * 2^52 trick (parity = sign),
-// r = x - k pi (one fma: |k| < 2^21, the product's error k * 1.2e-16 is far below fp32), odd Taylor polynomial of degree 13 on
-// [-pi/2, pi/2] (truncation 6.7e-10 abs = 0.01 ulp of the fp32 result), ONE rounding to fp32.
+// r = x - k pi (one fma: |k| < 2^21, the product's error k * 1.2e-16 is far below fp32), odd minimax polynomial of degree 11 on
+// [-pi/2, pi/2] (max error 1.7e-11 abs = 3e-4 ulp of the fp32 result: 0.02 % of random arguments round differently from
+// libm's double sine rounded once), ONE rounding to fp32.
 NSR_DEV float sin_f64(float x) {
     const double xd = (double)x;
     const double t = fma(xd, 0.31830988618379067, 6755399441055744.0);
     const double k = t - 6755399441055744.0;
     const double r = fma(k, -3.141592653589793, xd);
     const double r2 = r * r;
-    double p = fma(r2, 1.6059043836821613e-10, -2.505210838544172e-08);      // 1/13!, -1/11!
-    p = fma(p, r2, 2.7557319223985893e-06);                                  // 1/9!
-    p = fma(p, r2, -1.984126984126984e-04);                                  // -1/7!
-    p = fma(p, r2, 8.333333333333333e-03);                                   // 1/5!
-    p = fma(p, r2, -1.6666666666666666e-01);                                 // -1/3!
+    double p = fma(r2, -2.38466908183069e-08, 2.7522618644441596e-06);       // minimax on [0, (pi/2)^2] of (sin r - r) / r^3 in u = r^2
+    p = fma(p, r2, -0.00019840804034260232);                                 // (weighted by r^3: max |error| of the sine 1.7e-11,
+    p = fma(p, r2, 0.008333330495622904);                                    //  tests/test_oracle_modes.py pins it; one fma fewer and
+    p = fma(p, r2, -0.16666666606465366);                                    //  3x fewer misrounded results than the degree-13 Taylor form)
     const float s = (float)fma(p * r2, r, r);
     const unsigned sign = (unsigned)__builtin_bit_cast(unsigned long long, t) << 31;
     return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s) ^ sign);

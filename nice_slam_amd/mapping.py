@@ -17,9 +17,8 @@ zero-fills the iteration's gradient buffer beside its sampling blocks), render f
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Optional, Sequence, Tuple
-
 import os
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -111,6 +110,9 @@ def seed_pixel_draws(seed: int, device=None):
         if st is None:
             st = _DRAW_STATE[key] = [torch.initial_seed() & ((1 << 63) - 1), torch.zeros(4, dtype=torch.int64, device=torch.device(*key))]
         _set_state(st[1], seed)
+
+
+DEBUG_PTRS = {} if os.environ.get("NSR_DEBUG_PTRS") == "1" else None
 
 
 def _launch_window(indices, K, n, crop, intr, frames, bound6, sbuf, keep, kmax_ptr, dev, fused=None):
@@ -314,6 +316,9 @@ class _MappingLossFn(torch.autograd.Function):
         if need_bwd and renderer.profile_fwd_events is not None:
             a.ev_pass_start, a.ev_pass_stop = renderer.profile_fwd_events(stage)
         acts = renderer._attach_acts(a, stage, N, S, dev, masks_only=not any(need_par)) if need_bwd else None
+        if DEBUG_PTRS is not None:                              # measurement (bench.py NSR_DEBUG_PTRS=1): where the iteration's buffers landed
+            DEBUG_PTRS[stage] = {"Z": Z.data_ptr(), "Z_bytes": 4 * Z.numel(), "FS": FS.data_ptr(), "acts": None if acts is None else acts.data_ptr(),
+                                 "acts_bytes": None if acts is None else 4 * acts.numel(), "grids": {s: grids[s].data_ptr() for s in slots}}
         if need_bwd and acts is None:
             raise _capi.NsrError("nice_slam_amd: the activation buffer of a %d-ray fused iteration does not fit (Renderer."
                                  "max_saved_activation_bytes / free device memory); use smaller batches or render_batch_ray" % N)

@@ -328,6 +328,7 @@ class ShardedMapping:
         from .common import _stream
         gflat, publish = self._pending if self._pending is not None else (None, None)
         self._pending = None
+        self._deferred = None                 # (a record of an earlier split iteration -- e.g. one a graph segment keeps -- is not THIS backward's)
         lib = _capi.get_lib()
         dev = loss32.device
         leafs, self._leafs = self._leafs, None

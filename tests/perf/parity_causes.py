@@ -2,7 +2,8 @@
 """TEST INFRASTRUCTURE (CPU only, build container): what makes the ScanNet-bound fine stage miss 1e-4 against the fp32 oracle?
 
 The kernel sources run under the CPU emulator (tests/emu: same sources, MFMA modelled as the k = 0..3 fma chain) twice:
-  A  as shipped (packed-fp32 Cody-Waite sine, abs err ~1.5e-7)
+  A  as shipped until round 5 (packed-fp32 Cody-Waite sine everywhere, abs err ~1.5e-7; -DNSR_X_FWD_SIN_F32)
+  P  the product of round 6 (the forward's embedding sine in fp64, rounded once: nsr_kernels.h sin_f64; no define)
   B  -DNSR_X_LIBM_SIN: every sine / cosine correctly rounded (double libm, rounded once to fp32)
 and each result is compared, tensor by tensor, against
   O1 the fp32 oracle as the parity tests use it (ATen mm / MKL order inside the Linear layers),
@@ -69,7 +70,9 @@ def main():
     a = ap.parse_args()
     torch.set_num_threads(8)
     s = make_scene(seed=a.seed, n_rays=a.rays, scene=a.scene, fine_scale=1.0)
-    libs = {"A_shipped_sine": build_variant("a", ""), "B_correctly_rounded_sine": build_variant("b", "-DNSR_X_LIBM_SIN=1")}
+    libs = {"A_shipped_sine": build_variant("a", "-DNSR_X_FWD_SIN_F32"),      # rounds 1-5: the packed fp32 sine everywhere
+            "P_product_fp64_forward_sine": build_variant("p", ""),            # round 6: what libnsr.so is built from
+            "B_correctly_rounded_sine": build_variant("b", "-DNSR_X_LIBM_SIN=1")}
     for tag, v in (("B2_correctly_rounded_forward_embedding_only", 2), ("B3_correctly_rounded_dW_reevaluation_only", 3), ("B4_correctly_rounded_dX_cosines_only", 4)):
         if a.split:
             libs[tag] = build_variant("b%d" % v, "-DNSR_X_LIBM_SIN=%d" % v)

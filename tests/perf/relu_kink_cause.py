@@ -65,11 +65,13 @@ def main():
     ap.add_argument("--layer", type=int, default=1)
     ap.add_argument("--top", type=int, default=6)
     ap.add_argument("--rays", type=int, default=100_000)
+    ap.add_argument("--scene", default="synthetic")
+    ap.add_argument("--seed", type=int, default=26)
     ap.add_argument("--full", action="store_true", help="also evaluate the full-batch oracle (max|dW| of the layer: the test's denominator)")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_relu_kink_cause.json"))
     args = ap.parse_args()
     torch.set_num_threads(8)
-    sc = make_scene(seed=26, n_rays=args.rays, scene="synthetic", fine_scale=1.0)
+    sc = make_scene(seed=args.seed, n_rays=args.rays, scene=args.scene, fine_scale=1.0)
     n, S = args.rays, 48
     key_w, key_b = f"dparam/color_decoder.pts_linears.{args.layer}.weight", f"dparam/color_decoder.pts_linears.{args.layer}.bias"
     # 1. candidates
@@ -77,24 +79,27 @@ def main():
     with torch.no_grad():
         for lo_i in range(0, n, 10_000):
             sl = slice(lo_i, min(n, lo_i + 10_000))
-            z32 = layer_preact(sc, sl, args.layer, torch.float32)[:, args.row]
-            z64 = layer_preact(sc, sl, args.layer, torch.float64)[:, args.row]
-            a = z32.abs().double()
-            k = torch.topk(-a, args.top).indices
+            z32 = layer_preact(sc, sl, args.layer, torch.float32)
+            z64 = layer_preact(sc, sl, args.layer, torch.float64)
+            if args.row >= 0:
+                z32, z64 = z32[:, args.row:args.row + 1], z64[:, args.row:args.row + 1]
+            a = z32.abs().double().reshape(-1)
+            k = torch.topk(-a, min(args.top, a.numel())).indices
+            nu = z32.shape[1]
             for i in k.tolist():
-                best.append((float(a[i]), lo_i * S + i, float(z32[i]), float(z64[i])))
+                best.append((float(a[i]), lo_i * S + i // nu, float(z32.reshape(-1)[i]), float(z64.reshape(-1)[i]), (args.row if args.row >= 0 else i % nu)))
     best.sort()
     best = best[:args.top]
     print("candidates (|z| smallest):")
-    for a, gp, z32, z64 in best:
-        print(f"   point {gp} = ray {gp // S} sample {gp % S}:  z32 = {z32:+.3e}   z64 = {z64:+.3e}   sign flip between fp32 and fp64: {(z32 > 0) != (z64 > 0)}")
+    for a, gp, z32, z64, unit in best:
+        print(f"   unit {unit} point {gp} = ray {gp // S} sample {gp % S}:  z32 = {z32:+.3e}   z64 = {z64:+.3e}   sign flip between fp32 and fp64: {(z32 > 0) != (z64 > 0)}")
     # 2. emulator / oracle fp32 / oracle fp64 on each candidate's ray
     lib = _capi.Lib(os.path.join(TESTS, "emu", "libnsr_emu.so"))
     hs = emu_harness.HostScene(lib, sc["grids"], sc["params"], sc["bound"].numpy())
     hs.save_acts = True
     j = int(torch.argmax(sc["gt_depth"]))
     rows = []
-    for a, gp, z32, z64 in best:
+    for a, gp, z32, z64, unit in best:
         r = gp // S
         idx = torch.tensor([r, j])
         sub = {k: sc[k] for k in ("grids", "params", "bound", "intr")}
@@ -105,11 +110,11 @@ def main():
         o64 = oracle_render(sub, "color", backward=True, lo=torch.float64)
         fwd = hs.forward("color", sub["rays_o"].numpy(), sub["rays_d"].numpy(), sub["gt_depth"].numpy())
         emu = hs.backward("color", fwd, sub["w"]["depth"].numpy(), sub["w"]["var"].numpy(), sub["w"]["rgb"].numpy())
-        row = lambda d_, k_: np.asarray(d_[k_].detach().cpu() if torch.is_tensor(d_[k_]) else d_[k_], dtype=np.float64)[args.row]
+        row = lambda d_, k_: np.asarray(d_[k_].detach().cpu() if torch.is_tensor(d_[k_]) else d_[k_], dtype=np.float64)[unit]
         w_e, w_32, w_64 = row(emu, key_w), row(o32, key_w), row(o64, key_w)
         b_e, b_32, b_64 = float(row(emu, key_b)), float(row(o32, key_b)), float(row(o64, key_b))
         # the whole contribution of the point to the row: the oracle with unit `row` of that point's relu forced the other way
-        rec = {"point": gp, "ray": r, "sample": gp % S, "z_oracle_fp32": z32, "z_oracle_fp64": z64,
+        rec = {"unit": unit, "point": gp, "ray": r, "sample": gp % S, "z_oracle_fp32": z32, "z_oracle_fp64": z64,
                "db_row": {"kernel_sources_emulated": b_e, "oracle_fp32": b_32, "oracle_fp64": b_64},
                "max_abs_dW_row": {"kernel - oracle_fp32": float(np.abs(w_e - w_32).max()), "oracle_fp64 - oracle_fp32": float(np.abs(w_64 - w_32).max()),
                                   "kernel - oracle_fp64": float(np.abs(w_e - w_64).max()), "oracle_fp32 row": float(np.abs(w_32).max())},
@@ -120,7 +125,7 @@ def main():
                                                    and np.abs(w_e - w_32).max() > 1e-3 * np.abs(w_32).max())
         rows.append(rec)
         print(json.dumps(rec))
-    out = {"case": "stress100k (BASELINE configs[4])", "tensor": key_w, "row": args.row,
+    out = {"case": "%s seed %d, %d rays" % (args.scene, args.seed, args.rays), "tensor": key_w, "row": args.row,
            "method": __doc__.split("\n\n")[2].strip(), "candidates": rows}
     if args.full:
         ref = oracle_render_chunked(sc, "color")
