@@ -709,6 +709,12 @@ def measure(args, cfg_id, scaling, world, rank, dev, sharded, role="headline", r
                              "frac": pts * dw_nec * 2 / (sp["dw"] * 1e-3) / FP32_PEAK,
                              "executed_frac": pts * ((14336 if (args.stepped_grads_only or consumed) else 47104)) * 2 / (sp["dw"] * 1e-3) / FP32_PEAK}
                 ker["finalize"] = {"kernel": "bwd_finalize_kernel", "ms": round(sp["finalize"], 4)}
+                if cfg_id == "1" and rays_rank == 1000 and not (args.stepped_grads_only or consumed):
+                    # this kernel alone lands in one of two modes from process to process on the same box and binary (twelve fresh
+                    # processes: 93.5-98.0 us six times, 101.2-108.2 six times; profiles/r06_dx_modes_12_processes.txt -- not a function
+                    # of any virtual address: the physical placement a process gets): say which one this run drew
+                    ker["dx"]["mode"] = "fast" if sp["dx"] < 0.0995 else "slow"
+                    ker["dx"]["mode_note"] = "dX<colour> of this process between events: < 99.5 us = the fast mode (93.5-98.0 in the 12-process study), else the slow one (101.2-108.2); +-5 % on `value`"
             elif sp:
                 ker["dx"] = {"ms": round(sp["dx"], 4)}
                 ker["dw"] = {"ms": round(sp["dw"], 4)}
