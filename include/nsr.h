@@ -135,11 +135,6 @@ typedef struct nsr_render_args {
                                  dfeat of voxels inside the mask equals the dense run's (up to the order of the atomic adds),
                                  dfeat of voxels outside stays as the caller left it (zero).  Ray / pose and decoder gradients are
                                  unaffected (they never depended on dfeat).  NULL (default) = the reference's dense gradient. */
-    float *zero_span;         /* ABI 8, opt-in, nsr_render_fwd with acts + zvals + raw only (a call that will be differentiated): a span of   */
-    int64_t zero_floats;      /* device floats (16-byte aligned) the forward zero-fills -- the gradient buffers `loss.backward()` (src/Mapper.py:503)
-                                 accumulates into: the waves of the decoder-pass kernel store zeros when they run out of tiles, instead of a
-                                 fill launch or of fill blocks beside the window kernel's sampling (nsr_get_samples_window_fused with
-                                 zero_floats = 0 then only writes the header).  Complete when nsr_render_fwd's launches are. */
 } nsr_render_args;
 
 typedef struct nsr_bwd_args {

@@ -43,8 +43,7 @@ class NsrRenderArgs(C.Structure):
                 ("w_color", C.c_float), ("acts_masks_only", C.c_int32), ("acts", C.c_void_p),
                 ("ev_pass_start", C.c_void_p), ("ev_pass_stop", C.c_void_p),
                 ("skip_masked", C.c_int32), ("pad2_", C.c_int32),
-                ("grad_voxel_mask", C.c_void_p * 4),
-                ("zero_span", C.c_void_p), ("zero_floats", C.c_int64)]
+                ("grad_voxel_mask", C.c_void_p * 4)]
 
 
 class NsrBwdArgs(C.Structure):

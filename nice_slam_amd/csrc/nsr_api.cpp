@@ -376,11 +376,6 @@ int nsr_render_fwd(const nsr_render_args *a, void *stream) {
                                     "nsr_render_bwd would read an unwritten buffer");
         if (P.n_points_total > (1ll << 25) - 16) return fail("nsr_render_fwd: more than 2^25 sample points in one differentiated call (split the ray batch)");
     }
-    if (a->zero_span || a->zero_floats) {
-        if (!(fwd_split && P.acts && P.zvals && P.raw && P.draw)) return fail("nsr_render_fwd: zero_span is filled by the split forward's pass kernel: the call needs acts + zvals + raw");
-        if (!a->zero_span || a->zero_floats < 0 || (reinterpret_cast<uintptr_t>(a->zero_span) & 15)) return fail("nsr_render_fwd: zero_span must be a 16-byte aligned device span");
-        P.zero = a->zero_span; P.zero_n = a->zero_floats;
-    }
     if (fwd_split && P.acts && P.zvals && P.raw && P.draw) {
         // a differentiated call with an activation buffer: sample placement -> decoder passes -> compositor (nsr_fwd2.h)
         const int passes = bwd_passes(P.stage), rpb = 4;

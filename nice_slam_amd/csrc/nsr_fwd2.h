@@ -114,16 +114,6 @@ NSR_DEV void fwd_pass(const RenderParams &P, int bi, int nbp) {
     dbg.stamp(1);
     const long long ntiles = (P.n_points_total + kTile - 1) / kTile;
     const long long t0 = ntiles * bi / nbp, t1 = ntiles * (bi + 1) / nbp;
-    // The fused iteration's zero fill (nsr_render_args.zero_span, round 6): every gradient buffer of the backward that follows, 48 MB in
-    // the colour stage.  It is bandwidth, this kernel is matrix-core time with HBM mostly idle (124 MB in 72 us): every wave stores its
-    // share of the span -- 1 KB per instruction, fire and forget -- half of it behind each of its first two tiles (in front of a tile the
-    // in-order vector-memory counter would make the tile's loads wait for them; all of it behind the last tile would sit in the
-    // kernel's tail: +3 us, measured), the rest when it runs out of tiles.  Beside the window kernel's sampling blocks, where round 5 had
-    // put it, the fill was what that launch waited for (11.0 us against 5.9 without it: profiles/r06_experiments.txt).
-    const long long zwb = nthreads() >> 6, zgw = (long long)bid_x() * zwb + wave, znw = (long long)nblk_x() * zwb;
-    const long long zn4 = P.zero_n >> 2;
-    long long zq = zgw * 64 + lane0;
-    const long long zhalf = ((zn4 + znw * 64 - 1) / (znw * 64) + 1) / 2;     // store instructions per tile (half the wave's share)
     for (;;) {
         int take = 0;
         if (lane0 == 0) take = atomic_fetch_add_lds_i(cnt, 1);
@@ -175,14 +165,7 @@ NSR_DEV void fwd_pass(const RenderParams &P, int bi, int nbp) {
                 if (active && g == 0) { float *rw = P.raw + gp * 4; rw[0] = oc[0]; rw[1] = oc[1]; rw[2] = oc[2]; }
             }
         }
-        if (P.zero_n > 0) {
-            for (long long i = 0; i < zhalf && zq < zn4; ++i, zq += znw * 64) st4(P.zero + zq * 4, F4{0.f, 0.f, 0.f, 0.f});
-        }
         dbg.stamp(3);
-    }
-    if (P.zero_n > 0) {                                              // what is left of the wave's share (fewer than two tiles)
-        for (; zq < zn4; zq += znw * 64) st4(P.zero + zq * 4, F4{0.f, 0.f, 0.f, 0.f});
-        if (zgw == 0 && lane0 < (int)(P.zero_n & 3)) P.zero[zn4 * 4 + lane0] = 0.f;
     }
     dbg.stamp(9);
 }

@@ -67,8 +67,6 @@ struct RenderParams {
     DecDev dec[4];
     double *depth, *var;
     float *rgb, *raw;
-    float *zero;              // nsr_render_args.zero_span: zero-filled by the waves of the forward's pass kernel when they run out of tiles
-    long long zero_n;
     double *zvals;            // [N][S] saved sample depths (optional)
     float *acts;              // saved decoder activations (optional, see ActSink): the backward then loads h_i / relu masks
     int acts_masks_only;      // 1: only the relu masks are saved (no parameter gradients will be asked for)

@@ -61,10 +61,6 @@ PIXEL_DRAW = os.environ.get("NSR_PIXEL_DRAW", "kernel")
 # The fused iterations' one zero fill (loss accumulator, kept max, every gradient buffer of the backward) inside the window
 # kernel's launch (nsr_get_samples_window_fused) instead of a `torch.zeros` launch in front of it; "0": the separate fill (A/B).
 FUSED_FILL = os.environ.get("NSR_FUSED_FILL", "1") != "0"
-# round 6: the fill itself rides in the FORWARD's decoder-pass kernel (nsr_render_args.zero_span: its waves store zeros when they run
-# out of tiles -- bandwidth under matrix-core time); the window kernel then only writes the 16-byte header.  "0": fill blocks beside
-# the window kernel's sampling blocks as in round 5 (A/B).
-FILL_IN_FORWARD = os.environ.get("NSR_FILL_IN_FORWARD", "1") != "0"
 _DRAW_STATE = {}
 
 
@@ -288,9 +284,8 @@ class _MappingLossFn(torch.autograd.Function):
         F = FS[:n64 + (nf32 + 1) // 2]
         sbuf = FS[n64 + (nf32 + 1) // 2:].view(torch.float32)[:n_s]
         keep = sbuf[10 * N:].view(torch.uint8)[:N]
-        fill_fwd = fuse_fill and need_bwd and FILL_IN_FORWARD and Z.numel() > 4     # the forward's pass kernel zero-fills Z[4:] (below)
         _launch_window(indices, K, n, crop, intr, frames, _bound_arrays(bound), sbuf, keep, kmax.data_ptr(), dev,
-                       fused=(Z[:4], Z[4:4] if fill_fwd else Z[4:]) if fuse_fill else None)
+                       fused=(Z[:4], Z[4:]) if fuse_fill else None)
         if sharder is not None and not (fuse_fill and getattr(indices, "_nsr_peers", None)):
             # the depth cap is a scalar of the WHOLE batch (Renderer.py:109,144): one 4-byte MAX all-reduce -- unless the window kernel
             # has just re-drawn the other ranks' pixels itself and its header already holds the maximum over the union (peer seeds)
@@ -327,8 +322,6 @@ class _MappingLossFn(torch.autograd.Function):
         if need_bwd and acts is None:
             raise _capi.NsrError("nice_slam_amd: the activation buffer of a %d-ray fused iteration does not fit (Renderer."
                                  "max_saved_activation_bytes / free device memory); use smaller batches or render_batch_ray" % N)
-        if fill_fwd:
-            a.zero_span, a.zero_floats = Z[4:].data_ptr(), Z.numel() - 4
         lib.check(lib.nsr_render_fwd(C.byref(a), stream), "nsr_render_fwd")
         if track is not None:                                   # the tracker's loss needs the batch median of the rendered outputs
             lib.check(lib.nsr_tracking_loss(N, gt_depth.data_ptr(), gt_color.data_ptr(), keep.data_ptr(), depth.data_ptr(), var.data_ptr(),

@@ -948,54 +948,3 @@ def test_consumed_gradient_voxel_masks(emu, stage):
             assert not none[k].any(), k
         else:
             assert rel_err(none[k], dense[k]) < 1e-6, k
-
-
-@pytest.mark.parametrize("stage,zero_n", [("color", 4 * 8192 * 3 + 2), ("middle", 5), ("coarse", 70001)])
-def test_forward_zero_fills_the_gradient_span(emu, stage, zero_n):
-    """nsr_render_args.zero_span (ABI 8, round 6): the waves of the differentiated forward's decoder-pass kernel zero-fill the span --
-    the gradient buffers the backward accumulates into (Mapper.py:503) -- when they run out of tiles: to the float (lengths that are
-    not multiples of four, shorter than one wave's store), nothing beside it touched, the forward's results unchanged; a call without
-    an activation buffer (the one-launch forward) refuses the field, so does a span that is not 16-byte aligned."""
-    import ctypes as C
-    import scene_util as su
-    from emu_harness import HostScene, ptr
-    from nice_slam_amd import _capi
-    sc = su.make_scene(seed=31, n_rays=45, small=True)
-    hs = HostScene(emu, sc["grids"], sc["params"], sc["bound"])
-    ro, rd, gt = (np.ascontiguousarray(sc[k].numpy(), dtype=np.float32) for k in ("rays_o", "rays_d", "gt_depth"))
-    N = ro.shape[0]
-    S = hs.n_samples + (hs.n_surface if stage != "coarse" else 0)
-
-    def run(span):
-        kp = []
-        a = hs._args(stage, ro, rd, gt, kp)
-        out = {"depth": np.full(N, np.nan), "var": np.full(N, np.nan), "rgb": np.full((N, 3), np.nan, np.float32),
-               "raw": np.full((N, S, 4), np.nan, np.float32), "zvals": np.full((N, S), np.nan)}
-        out["acts"] = np.full((emu.nsr_acts_floats(_capi.STAGE_ID[stage], N, S),), np.nan, np.float32)
-        a.depth, a.var, a.rgb, a.raw, a.zvals, a.acts = (ptr(out[k_]) for k_ in ("depth", "var", "rgb", "raw", "zvals", "acts"))
-        if span is not None:
-            a.zero_span, a.zero_floats = ptr(span), span.size
-        emu.check(emu.nsr_render_fwd(C.byref(a), None))
-        return out
-
-    ref = run(None)
-    Z = np.full((4 + zero_n + 4,), 7.0, np.float32)
-    got = run(Z[4:4 + zero_n])
-    assert np.all(Z[:4] == 7.0) and np.all(Z[4:4 + zero_n] == 0.0) and np.all(Z[-4:] == 7.0)
-    for k_ in ("depth", "var", "rgb", "raw", "zvals"):
-        assert np.array_equal(got[k_], ref[k_]), k_
-    # refused: no activation buffer / misaligned span
-    kp = []
-    a = hs._args(stage, ro, rd, gt, kp)
-    d0, v0, r0 = np.zeros(N), np.zeros(N), np.zeros((N, 3), np.float32)
-    a.depth, a.var, a.rgb = ptr(d0), ptr(v0), ptr(r0)
-    a.zero_span, a.zero_floats = ptr(Z[4:]), 8
-    assert emu.nsr_render_fwd(C.byref(a), None) != 0
-    Z2 = np.zeros((64,), np.float32)
-    kp = []
-    a = hs._args(stage, ro, rd, gt, kp)
-    o2 = {"depth": np.zeros(N), "var": np.zeros(N), "rgb": np.zeros((N, 3), np.float32), "raw": np.zeros((N, S, 4), np.float32), "zvals": np.zeros((N, S)),
-          "acts": np.zeros((emu.nsr_acts_floats(_capi.STAGE_ID[stage], N, S),), np.float32)}
-    a.depth, a.var, a.rgb, a.raw, a.zvals, a.acts = (ptr(o2[k_]) for k_ in ("depth", "var", "rgb", "raw", "zvals", "acts"))
-    a.zero_span, a.zero_floats = ptr(Z2[1:]), 8
-    assert emu.nsr_render_fwd(C.byref(a), None) != 0

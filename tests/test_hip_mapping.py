@@ -580,47 +580,3 @@ def test_consumed_gradient_voxel_masks(stage, fused):
             nsa.mapping_loss(renderer, run_c, dec, _frames(sc, K, DEV), n, stage, w_color=0.2, indices=idx).backward()
         finally:
             renderer.grad_voxel_masks = None
-
-
-@pytest.mark.parametrize("stage", ["middle", "color"])
-def test_gradient_buffers_are_zero_filled_by_the_forward(stage, monkeypatch):
-    """mapping.FILL_IN_FORWARD (nsr_render_args.zero_span, ABI 8, round 6): the iteration's zero fill -- every gradient buffer the
-    backward accumulates into -- is done by the waves of the forward's decoder-pass kernel when they run out of tiles (the window kernel
-    only writes the 16-byte header) instead of by fill blocks beside the window kernel's sampling.  Two iterations in a row on the same
-    (recycled, hence dirty) allocator blocks: loss and every gradient equal those of the round-5 arrangement up to the order of the
-    atomic adds, and voxels no ray touched hold EXACT zeros."""
-    import nice_slam_amd as nsa
-    from nice_slam_amd import mapping
-    sc = make_scene(seed=85, n_rays=8, small=True)
-    H, W, fx, fy, cx, cy = sc["intr"]
-    renderer, dec, grids_dev = build_product(sc, DEV)
-    K, n = 3, 257
-    idx = torch.randint(H * W, (K * n,), generator=torch.Generator().manual_seed(9))
-
-    def run(in_fwd):
-        monkeypatch.setattr(mapping, "FILL_IN_FORWARD", in_fwd)
-        res = None
-        for _ in range(2):                                      # the second iteration re-uses the first one's (non-zero) buffers
-            frames = _frames(sc, K, DEV, grad=True)
-            c = {k: v.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) for k, v in grids_dev.items()}
-            for p in dec.parameters():
-                p.requires_grad_(True); p.grad = None
-            loss = nsa.mapping_loss(renderer, c, dec, frames, n, stage, w_color=0.2, indices=idx)
-            loss.backward()
-            torch.cuda.synchronize()
-            res = (loss.detach().clone(), {k: v.grad.clone() for k, v in c.items() if v.grad is not None},
-                   {k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None}, [f[0].grad.clone() for f in frames])
-            del c, frames, loss
-        return res
-
-    l0, g0, p0, c0 = run(False)
-    l1, g1, p1, c1 = run(True)
-    assert abs(float(l0) - float(l1)) <= 1e-12 * abs(float(l0))
-    for k in g0:
-        assert rel_err(g1[k], g0[k]) < 1e-5, k
-        assert torch.equal(g1[k] == 0, g0[k] == 0), k          # the same voxels untouched, and exactly zero in both
-        assert float((g1[k] == 0).float().mean()) > 0.05, k
-    for k in p0:
-        assert rel_err(p1[k], p0[k]) < 2e-5, k
-    for a, b in zip(c0, c1):
-        assert rel_err(b, a) < 1e-5
