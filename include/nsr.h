@@ -110,7 +110,9 @@ typedef struct nsr_render_args {
     float *dl_rgb;            /* [N][3] out, optional */
     float w_color;            /* cfg mapping.w_color_loss */
     int32_t acts_masks_only;  /* with `acts`: 1 = the backward will want no parameter gradients (tracking), the forward only
-                                 writes the relu masks (1 of the 13 KB per tile and decoder); 0 = everything */
+                                 writes the relu masks (1 of the 13 KB per tile and decoder); 0 = everything.  ABI 8: bits 1..3 say the
+                                 same for ONE decoder pass each (2: middle -- or the coarse stage's only pass --, 4: fine, 8: colour): a
+                                 decoder nobody will step (src/Mapper.py:335-341 steps the colour decoder only) saves its masks only */
     /* --- saved decoder activations + workspace of the split backward (ABI 3/4; required for a call that will be differentiated since
      * ABI 6).  nsr_acts_floats(stage, n_rays, n_samples + n_surface) floats, device, uninitialised: nsr_render_fwd (given acts, zvals
      * and raw) runs as sample placement -> decoder passes -> compositor and writes, per decoder pass and 16-point tile of the sample list,

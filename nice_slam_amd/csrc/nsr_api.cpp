@@ -124,7 +124,7 @@ int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays,
     P.rays_o = a->rays_o;
     P.rays_d = a->rays_d;
     P.acts = a->acts;
-    P.acts_masks_only = a->acts_masks_only ? 1 : 0;
+    P.acts_masks_only = a->acts_masks_only & 15;
     if (!bwd && a->acts && a->zvals) {
         // activation buffer: the forward leaves the sample positions (and, with the fused loss, d raw) for the split backward;
         // the three-launch forward (nsr_fwd2.h) keeps its per-sample scratch there
@@ -205,7 +205,12 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
     P.draw = P.acts + L.o_draw;
     P.pf = P.acts + L.o_pf;
     P.pd = reinterpret_cast<double *>(P.acts + L.o_pd);
-    if (any_params && P.acts_masks_only) return fail("nsr_render_bwd: the forward saved relu masks only (acts_masks_only); parameter gradients need the full activations");
+    for (int s = 0; s < 4; ++s)
+        if (P.dec[s].dparams && (P.acts_masks_only & (1 | (2 << (s == NSR_COARSE ? 0 : s - NSR_MIDDLE)))))
+            return fail("nsr_render_bwd: the forward saved relu masks only for a decoder whose parameter gradients are asked for (acts_masks_only); they need the full activations");
+    // (the fine decoder's input is [c_fine | c_mid], decoder.py:182-187: its dW reads the middle pass's saved features)
+    if (P.dec[NSR_FINE].dparams && (P.acts_masks_only & (1 | 2)))
+        return fail("nsr_render_bwd: the forward saved relu masks only for the middle decoder (acts_masks_only), whose features the fine decoder's parameter gradients read");
     static const int xflags = env_int("NSR_X", 0);
     P.xflags = xflags;
     if (any_params) {

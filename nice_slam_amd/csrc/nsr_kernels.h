@@ -69,7 +69,7 @@ struct RenderParams {
     float *rgb, *raw;
     double *zvals;            // [N][S] saved sample depths (optional)
     float *acts;              // saved decoder activations (optional, see ActSink): the backward then loads h_i / relu masks
-    int acts_masks_only;      // 1: only the relu masks are saved (no parameter gradients will be asked for)
+    int acts_masks_only;      // bit 0: only the relu masks are saved (no parameter gradients will be asked for); bit 1 + p: the same for decoder pass p alone
     long long n_points_total; // n_rays * S
     long long act_tiles;      // 16-point tiles of the sample-point list (n_points_total rounded up): tile stride of `acts` / `dy`
     // backward only
@@ -731,7 +731,7 @@ struct ActSink {
 };
 NSR_DEV ActSink act_sink(const RenderParams &P, int pass, long long gp, int g) {
     ActSink a;
-    a.full = !P.acts_masks_only;
+    a.full = !(P.acts_masks_only & (1 | (2 << pass)));
     a.p = (P.acts && gp >= 0) ? P.acts + (((long long)pass * P.act_tiles + (gp >> 4)) * kActSlots) * 256 + ((gp & 15) * 4 + g) * 4 : nullptr;
     return a;
 }

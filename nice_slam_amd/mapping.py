@@ -315,7 +315,7 @@ class _MappingLossFn(torch.autograd.Function):
         a.skip_masked = 1 if (renderer.skip_masked_rays and need_bwd) else 0
         if need_bwd and renderer.profile_fwd_events is not None:
             a.ev_pass_start, a.ev_pass_stop = renderer.profile_fwd_events(stage)
-        acts = renderer._attach_acts(a, stage, N, S, dev, masks_only=not any(need_par)) if need_bwd else None
+        acts = renderer._attach_acts(a, stage, N, S, dev, masks_only=[not g_ for g_ in need_par]) if need_bwd else None
         if DEBUG_PTRS is not None:                              # measurement (bench.py NSR_DEBUG_PTRS=1): where the iteration's buffers landed
             DEBUG_PTRS[stage] = {"Z": Z.data_ptr(), "Z_bytes": 4 * Z.numel(), "FS": FS.data_ptr(), "acts": None if acts is None else acts.data_ptr(),
                                  "acts_bytes": None if acts is None else 4 * acts.numel(), "grids": {s: grids[s].data_ptr() for s in slots}}

@@ -149,7 +149,7 @@ class _RenderFn(torch.autograd.Function):
         chunk = 0
         if need_bwd:
             n_sl = len(slots)
-            masks_only = not any(ctx.needs_input_grad[3 + n_sl:3 + 2 * n_sl])
+            masks_only = [not g_ for g_ in ctx.needs_input_grad[3 + n_sl:3 + 2 * n_sl]]     # per decoder: one nobody differentiates saves its relu masks only
             acts = renderer._attach_acts(a, stage, n, S, dev, masks_only=masks_only)
             keep.append(acts)
             if acts is None:
@@ -227,7 +227,7 @@ def _chunked_backward(a, meta, kept, need, g_depth, g_var, g_rgb, chunk):
         raw = torch.empty((m, S, 4), dtype=torch.float32, device=dev)
         zs = torch.empty((m, S), dtype=torch.float64, device=dev)
         ac.depth, ac.var, ac.rgb, ac.raw, ac.zvals = depth.data_ptr(), var.data_ptr(), rgb.data_ptr(), raw.data_ptr(), zs.data_ptr()
-        acts = renderer._attach_acts(ac, stage, m, S, dev, masks_only=not any(need_par))
+        acts = renderer._attach_acts(ac, stage, m, S, dev, masks_only=[not g_ for g_ in need_par])
         if acts is None:
             raise _capi.NsrError("nice_slam_amd: no room for the activation buffer of a %d-ray chunk" % m)
         lib.check(lib.nsr_render_fwd(C.byref(ac), stream), "nsr_render_fwd(chunk)")
@@ -516,7 +516,14 @@ class Renderer(object):
         except torch.cuda.OutOfMemoryError:
             return None
         a.acts = acts.data_ptr()
-        a.acts_masks_only = 1 if masks_only else 0
+        # masks_only: bool (every decoder) or one bool per decoder pass of the stage, in slot order (nsr_render_args.acts_masks_only)
+        if isinstance(masks_only, (list, tuple)):
+            masks_only = list(masks_only)
+            if len(masks_only) >= 2 and not masks_only[1]:
+                masks_only[0] = False               # the fine decoder's dW reads the middle pass's saved features ([c_fine | c_mid], decoder.py:182-187)
+            a.acts_masks_only = 1 if all(masks_only) else sum(2 << i for i, m in enumerate(masks_only) if m)
+        else:
+            a.acts_masks_only = 1 if masks_only else 0
         return acts
 
     def render_img(self, c, decoders, c2w, device, stage, gt_depth=None):

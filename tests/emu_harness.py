@@ -135,7 +135,8 @@ class HostScene:
             nfl = self.lib.nsr_acts_floats(_capi.STAGE_ID[stage], n, S)
             out["acts"] = np.full((max(1, nfl),), np.nan, dtype=np.float32)
             a.acts = ptr(out["acts"])
-            a.acts_masks_only = 1 if getattr(self, "acts_masks_only", False) else 0
+            m = getattr(self, "acts_masks_only", False)         # True / False, or the bit field of nsr_render_args.acts_masks_only
+            a.acts_masks_only = int(m) if not isinstance(m, bool) else (1 if m else 0)
         if fused_loss is not None:
             out["loss"], out["dl_depth"], out["dl_rgb"] = np.zeros(1), np.full(n, np.nan), np.full((n, 3), np.nan, dtype=np.float32)
             gcol = np.ascontiguousarray(fused_loss["gt_color"], dtype=np.float32)
@@ -177,7 +178,7 @@ class HostScene:
             if want_grid:
                 res["d_grid_" + s] = np.zeros_like(self.grids[s])
                 a.grid[i].dfeat = ptr(res["d_grid_" + s])
-            if want_params:
+            if want_params is True or (want_params and s in want_params):       # True / False, or the slots whose decoders want them
                 res["d_flat_" + s] = np.full_like(self.flat[s], np.nan) if overwrite_dparams else np.zeros_like(self.flat[s])
                 a.dec[i].dparams = ptr(res["d_flat_" + s])
         b = _capi.NsrBwdArgs()
@@ -206,6 +207,6 @@ class HostScene:
         for s in stage_slots(stage):       # back to reference layouts
             if want_grid:
                 res["d_grid_" + s] = res["d_grid_" + s].transpose(3, 0, 1, 2)[None]
-            if want_params:
+            if "d_flat_" + s in res:
                 res.update({"dparam/" + k: v for k, v in unflat_grads(res.pop("d_flat_" + s), s).items()})
         return res

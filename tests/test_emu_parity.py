@@ -792,6 +792,29 @@ def test_saved_activations_equal_the_forward_rerun(emu, stage):
         assert rel_err(v, res[False][1][k]) < 1e-5, k
     with pytest.raises(Exception, match="masks only"):
         sc.backward(stage, fwd, s["w"]["depth"].numpy(), s["w"]["var"].numpy(), s["w"]["rgb"].numpy(), want_params=True)
+    # per decoder (ABI 8: bits 1..3 of acts_masks_only): only the LAST decoder of the stage will be stepped (the mapper steps the colour
+    # decoder, Mapper.py:335-341) -- the others save their relu masks alone, the backward still yields every grid / ray gradient and
+    # that decoder's parameter gradients, and refuses parameter gradients of a decoder whose activations were not saved
+    from emu_harness import stage_slots
+    slots = stage_slots(stage)
+    if len(slots) > 1:
+        sc = _host_scene(emu, s["grids"], s["params"], s["bound"].numpy())
+        sc.acts_masks_only = sum(2 << i for i in range(len(slots) - 1))
+        fwd = sc.forward(stage, s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy())
+        npts = s["rays_o"].shape[0] * 48
+        npad = (npts + 15) // 16 * 16
+        sl = fwd["acts"][:len(slots) * 13 * npad * 16].reshape(len(slots), npad // 16, 13, 16, 16)
+        assert np.isnan(sl[:-1, :, :12]).all() and not np.isnan(sl[-1, :, :12].reshape(-1, 16)[:npts]).any()     # hidden states of the last decoder only
+        if stage == "fine":        # the fine decoder's dW reads the middle pass's features ([c_fine | c_mid]): refused, not silently wrong
+            with pytest.raises(Exception, match="masks only for the middle decoder"):
+                sc.backward(stage, fwd, s["w"]["depth"].numpy(), s["w"]["var"].numpy(), s["w"]["rgb"].numpy(), want_params=(slots[-1],))
+        else:
+            r4 = sc.backward(stage, fwd, s["w"]["depth"].numpy(), s["w"]["var"].numpy(), s["w"]["rgb"].numpy(), want_params=(slots[-1],))
+            assert any(k.startswith("dparam/" + slots[-1]) for k in r4) and not any(k.startswith("dparam/" + slots[0]) for k in r4)
+            for k, v in r4.items():
+                assert rel_err(v, res[False][1][k]) < 1e-5, k
+        with pytest.raises(Exception, match="masks only"):
+            sc.backward(stage, fwd, s["w"]["depth"].numpy(), s["w"]["var"].numpy(), s["w"]["rgb"].numpy(), want_params=(slots[0],))
 
 
 @pytest.mark.parametrize("stage,acts", [("color", True), ("fine", False), ("coarse", True)])

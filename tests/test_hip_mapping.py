@@ -580,3 +580,49 @@ def test_consumed_gradient_voxel_masks(stage, fused):
             nsa.mapping_loss(renderer, run_c, dec, _frames(sc, K, DEV), n, stage, w_color=0.2, indices=idx).backward()
         finally:
             renderer.grad_voxel_masks = None
+
+
+@pytest.mark.parametrize("stepped,fused", [(("color",), True), (("color",), False), (("fine", "color"), True)])
+def test_stepped_decoders_only(stepped, fused):
+    """Renderer.decoder_grads (opt-in): parameter gradients only for the decoders the optimiser steps (src/Mapper.py:335-341: the colour
+    decoder, + the fine one when fix_fine is off).  The other decoders of the stage get no `.grad`, the stepped ones' and every grid /
+    pose gradient equal the all-decoders run's (up to atomic order) -- and, since ABI 8, the forward saves only the relu masks of a
+    decoder nobody differentiates (nsr_render_args.acts_masks_only bits 1..3; the middle pass stays complete when the fine decoder is
+    stepped: its dW reads the middle features)."""
+    import nice_slam_amd as nsa
+    sc = make_scene(seed=86, n_rays=8, small=True)
+    H, W, fx, fy, cx, cy = sc["intr"]
+    renderer, dec, grids_dev = build_product(sc, DEV)
+    K, n = 3, 150
+    idx = torch.randint(H * W, (K * n,), generator=torch.Generator().manual_seed(12))
+
+    def run(which):
+        renderer.decoder_grads = which
+        frames = _frames(sc, K, DEV, grad=True)
+        c = {k: v.detach().clone(memory_format=torch.preserve_format).requires_grad_(True) for k, v in grids_dev.items()}
+        for p in dec.parameters():
+            p.requires_grad_(True); p.grad = None
+        try:
+            if fused:
+                loss = nsa.mapping_loss(renderer, c, dec, frames, n, "color", w_color=0.2, indices=idx)
+            else:
+                w = nsa.get_samples_window(0, H, 0, W, n, H, W, fx, fy, cx, cy, [f[0] for f in frames], [f[1] for f in frames],
+                                           [f[2] for f in frames], sc["bound"], DEV, indices=idx)
+                depth, _, color = renderer.render_batch_ray(c, dec, w.rays_d, w.rays_o, DEV, "color", gt_max=w.kept_max, gt_depth=w.gt_depth)
+                loss = (torch.abs(w.gt_depth - depth) * (w.keep & (w.gt_depth > 0))).sum() + 0.2 * (torch.abs(w.gt_color - color) * w.keep[:, None]).sum()
+            loss.backward()
+        finally:
+            renderer.decoder_grads = None
+        return ({k: v.grad.clone() for k, v in c.items() if v.grad is not None},
+                {k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None}, [f[0].grad.clone() for f in frames])
+
+    g0, p0, c0 = run(None)
+    g1, p1, c1 = run(stepped)
+    assert p1 and all(any(k.startswith(s + "_decoder.") for s in stepped) for k in p1), sorted(p1)[:4]
+    assert {k for k in p0 if any(k.startswith(s + "_decoder.") for s in stepped)} == set(p1)
+    for k in p1:
+        assert rel_err(p1[k], p0[k]) < 2e-5, k
+    for k in g0:
+        assert rel_err(g1[k], g0[k]) < 1e-5, k
+    for a, b in zip(c0, c1):
+        assert rel_err(b, a) < 1e-5
