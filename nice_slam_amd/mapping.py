@@ -271,6 +271,11 @@ class _MappingLossFn(torch.autograd.Function):
         n_pose = 16 * K if need_pose else 0                     # d c2w of the window (pose_grads), behind the gradients
         # (round 5: not a fill launch -- the window kernel zero-fills it beside its sampling blocks and writes the header)
         fuse_fill = FUSED_FILL and N > 0
+        if fuse_fill and not getattr(indices, "_nsr_draw", False) and getattr(indices, "_nsr_state", None) is None and _capturing() \
+                and (dev.type, dev.index if dev.index is not None else torch.cuda.current_device()) not in _DRAW_STATE:
+            # explicit indices, nothing is drawn -- but the fused launch borrows the device's draw state for its hand-off words, and that
+            # tensor cannot be created under graph capture (it must outlive every graph): the separate fill + plain window launch instead
+            fuse_fill = False
         Z = (torch.empty if fuse_fill else torch.zeros)((4 + n_grad + n_pose,), dtype=torch.float32, device=dev)
         loss = Z[:2].view(torch.float64)
         kmax = Z[2:3]
@@ -385,7 +390,10 @@ def mapping_loss(renderer, c, decoders, frames: Sequence[Tuple[torch.Tensor, tor
     mask, renders ``stage`` and returns ``sum_{kept, gt>0} |gt - depth| (+ w_color * sum_kept |gt_rgb - rgb|`` in the colour
     stage) as an fp64 scalar, an ordinary autograd node (an incoming gradient other than 1 scales every gradient, on the device).
     ``out`` (optional dict) receives the sampled rays, masks and rendered outputs.  ``sharder``: a
-    ``nice_slam_amd.parallel.ShardedMapping`` (multi-GPU; use its ``mapping_loss`` method)."""
+    ``nice_slam_amd.parallel.ShardedMapping`` (multi-GPU; use its ``mapping_loss`` method).
+    One stream per device draw state: the fused window launch uses hand-off words of the device's draw state (also with explicit
+    ``indices``), so two iterations of one process that run on DIFFERENT streams at the same time (a coarse mapper beside the mapper)
+    must each pass their own ``draw_state`` tensor (4 int64 on the device: ``[seed, 0, 0, 0]``); iterations on one stream need nothing."""
     if coarse_mapper and stage != "coarse":
         raise ValueError("the coarse mapper optimises in stage 'coarse' (Mapper.py:403-404)")
     dev = torch.device(device) if device is not None else frames[0][1].device
