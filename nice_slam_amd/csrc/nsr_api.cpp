@@ -146,7 +146,7 @@ int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays,
         const nsr_grid &g = a->grid[s];
         if (!g.feat) return fail("nsr: missing feature grid for this stage");
         if (g.Z < 1 || g.Y < 1 || g.X < 1) return fail("nsr: bad grid shape");
-        if ((long long)g.Z * g.Y * g.X >= (1ll << 26)) return fail("nsr: grid too large for 32-bit voxel indexing");
+        if ((long long)g.Z * g.Y * g.X >= (1ll << 25)) return fail("nsr: grid too large for 32-bit byte offsets (2^25 voxels = 4 GB)");
         nsr::GridDev &G = P.grid[s];
         G.feat = g.feat; G.dfeat = g.dfeat; G.gmask = a->grad_voxel_mask[s]; G.Z = g.Z; G.Y = g.Y; G.X = g.X;
         for (int i = 0; i < 3; ++i) {

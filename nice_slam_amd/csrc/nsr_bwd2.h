@@ -155,24 +155,31 @@ NSR_DEV void dx_pass(const RenderParams &P) {
     if (!do_grid && !PARAMS && !RAYS) return;
     const Dbg dbg{P.dbg ? P.dbg + (((long long)bid_y() * nblk_x() + bid_x()) * kDxMaxWaves + wave) * 64 : nullptr};
     dbg.stamp(0);
+    constexpr long long sstride = 256;                       // floats between two slots of a tile
+    const float *acts_pass = P.acts + (long long)act_pass(KIND) * P.act_tiles * kActSlots * 256;
+    const long long ntiles = (P.n_points_total + kTile - 1) / kTile;
+    const long long t0 = dyn ? ntiles * bid_x() / nblk_x() : 0, tend = dyn ? ntiles * (bid_x() + 1) / nblk_x() : ntiles;
+    // A wave's FIRST tile is dealt statically (range start + wave; the counter starts behind them) and its inputs are requested here,
+    // in front of the operand staging: they land under the 64 KB copy instead of being waited for behind the barrier (round 6: ~2 us
+    // of every launch).  A first tile without a ray of the batch (pre-filter) falls back to the counter.
+    long long tile = dyn ? t0 + wave : (long long)bid_x() * nw + wave;
+    const bool pre = tile < tend && (!dyn || tile_live(P, tile));
+    DxIn cur;
+    if (pre) cur = dx_load(P, acts_pass, tile, pt, g);
     copy_f4<AUX_FLOATS / 4>(aux, D.packed);
     copy_f4<packedT_total(KIND) / 4>(wt, D.packed + AUX_FLOATS + packed_total(KIND));
     if (gl) for (int i = tid(); i < P.lds_grid_floats; i += nthreads()) gl[i] = 0.f;
     if (use_hot) hot_init(hot);
-    if (tid() == 0) tcnt[0] = 0;
+    if (tid() == 0) tcnt[0] = nw;
     block_sync();
     dbg.stamp(1);
-    constexpr long long sstride = 256;                       // floats between two slots of a tile
-    const float *acts_pass = P.acts + (long long)act_pass(KIND) * P.act_tiles * kActSlots * 256;
     float *dys = P.dy + (long long)act_pass(KIND) * P.act_tiles * kDySlots * 256;
-    const long long ntiles = (P.n_points_total + kTile - 1) / kTile;
     const long long tstep = (long long)nblk_x() * nw;
     const bool need_dc = do_grid || RAYS;
     float aB[kET][3];                                        // d _B partial sums of lane (channel j, point group)
 #pragma unroll
     for (int k = 0; k < kET; ++k) { aB[k][0] = 0.f; aB[k][1] = 0.f; aB[k][2] = 0.f; }
 
-    const long long t0 = dyn ? ntiles * bid_x() / nblk_x() : 0, tend = dyn ? ntiles * (bid_x() + 1) / nblk_x() : ntiles;
     auto claim = [&]() -> long long {                        // the block's next unclaimed tile that holds a ray of the batch (wave-uniform)
         for (;;) {
             int k = 0;
@@ -183,9 +190,11 @@ NSR_DEV void dx_pass(const RenderParams &P) {
     };
     // d raw written by the forward's loss epilogue: the incoming gradient applies here (one uniform scalar, read once)
     const float dr_scale = (!P.draw_scaled && P.g_scale) ? (float)P.g_scale[0] : 1.f;
-    long long tile = dyn ? claim() : (long long)bid_x() * nw + wave;
-    DxIn cur;
-    if (tile < tend) { cur = dx_load(P, acts_pass, tile, pt, g); dx_keep(cur); }     // (waited for HERE: otherwise the loop header
+    if (!pre && dyn) {
+        tile = claim();
+        if (tile < tend) cur = dx_load(P, acts_pass, tile, pt, g);
+    }
+    if (tile < tend) dx_keep(cur);                                                     // (waited for HERE: otherwise the loop header
     while (tile < tend) {                                                              //  carries an `s_waitcnt vmcnt(0)` for them, which
                                                                                        //  every later iteration spends on its atomics)
         loop_fence();
@@ -363,34 +372,36 @@ NSR_DEV void dx_pass(const RenderParams &P) {
         dbg.stamp(7);
     }
     dbg.stamp(8);
-    if (use_hot) {
-        block_sync();
-        hot_flush(hot, G);
-    }
-    if (gl && do_grid) {
-        block_sync();
-        for (int i = tid(); i < P.lds_grid_floats; i += nthreads()) {
-            const float v = gl[i];
-            if (v != 0.f) atomic_add_global(G.dfeat + i, v);
-        }
-    }
+    // The block's end: ONE barrier.  A wave leaves its d _B sums (over its lane groups) in its OWN staging region as soon as it runs out
+    // of tiles -- no barrier in front of that, the region is the wave's --, and behind the barrier the partial image is summed and stored
+    // BEFORE the hot table's flush: its store does not queue behind the flush's atomics (round 6; before: barrier, flush, barrier, sums,
+    // barrier, store -- 8 us from the last wave's last tile to the end of the block in the stamps of tests/perf/ts_dx.py).
     if (XYZ && PARAMS) {
-        // d _B of this block: sum over the lane groups, then over the waves through LDS (the staging regions are free)
-        block_sync();
 #pragma unroll
         for (int k = 0; k < kET; ++k)
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 float v = aB[k][d];
                 v += shfl_xor(v, 16); v += shfl_xor(v, 32);
-                if (g == 0) stg[wave * kDbPart + d * 96 + 16 * k + pt] = v;
+                if (g == 0) Sw[d * 96 + 16 * k + pt] = v;
             }
-        block_sync();
+    }
+    if (use_hot || (gl && do_grid) || (XYZ && PARAMS)) block_sync();
+    dbg.stamp(10);
+    if (XYZ && PARAMS) {
         float *part = P.dbpart + ((long long)bid_y() * nblk_x() + bid_x()) * kDbPart;
         for (int t = tid(); t < kDbPart; t += nthreads()) {
             float s = 0.f;
-            for (int w = 0; w < nw; ++w) s += stg[w * kDbPart + t];
+            for (int w = 0; w < nw; ++w) s += stg[w * kDxStg + t];
             part[t] = s;
+        }
+    }
+    if (use_hot) hot_flush(hot, G);
+    dbg.stamp(11);
+    if (gl && do_grid) {
+        for (int i = tid(); i < P.lds_grid_floats; i += nthreads()) {
+            const float v = gl[i];
+            if (v != 0.f) atomic_add_global(G.dfeat + i, v);
         }
     }
     dbg.stamp(9);

@@ -147,6 +147,11 @@ typedef __attribute__((address_space(3))) float nsr_lfloat;
 NSR_DEV void atomic_add_global(float *p, float v) {
     __hip_atomic_fetch_add((nsr_gfloat *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// the same at a WAVE-UNIFORM base + a 32-bit per-lane byte offset: global_atomic_add_f32 voffset, vdata, s[base] -- the per-lane 64-bit
+// address (a 64-bit shift + a 64-bit add per atomic) becomes one v_lshl_add_u32.  The array must be smaller than 4 GB.
+NSR_DEV void atomic_add_global_off(float *base, unsigned byte_off, float v) {
+    __hip_atomic_fetch_add((nsr_gfloat *)(reinterpret_cast<char *>(base) + byte_off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 NSR_DEV void atomic_add_lds(float *p, float v) {
     __hip_atomic_fetch_add((nsr_lfloat *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }

@@ -467,18 +467,20 @@ NSR_DEV void scatter_stage(const Lvl &L, int lane, const Act<2> &dc, bool active
 NSR_DEV void scatter_walk(const GridDev &G, int lane, const float *Tx, const float *tab,
                           int lds_grid = -1,           // >= 0: the whole gradient grid sits in LDS at this offset (floats; small grids, nsr_bwd2.h)
                           HotTab hot = HotTab{-1, 0}) {
-    const int *vt = reinterpret_cast<const int *>(tab);
-    const float *wt = tab + 128;
     const int h = lane >> 5, ch = lane & 31;
+    // the table's LDS offset (floats) as ONE opaque per-lane register: the staging regions sit beyond the 64 KB an LDS instruction's
+    // immediate offset reaches, and with the region's constant folded into every read's literal the compiler formed each of the 32
+    // addresses of a round with a v_add of its own (128 per tile); off an opaque base the reads carry p * 32 bytes as their immediates
+    const int tab_off = (int)(tab - reinterpret_cast<const float *>(lds_base()));
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
-        const int k = 2 * q + h;
+        const int *vk = reinterpret_cast<const int *>(lds_base()) + opaque_i(tab_off + 2 * q + h);
         int v[16];
         float s[16];
 #pragma unroll
         for (int p = 0; p < 16; ++p) {        // all LDS reads of the round in flight at once
-            v[p] = vt[p * 8 + k];
-            s[p] = wt[p * 8 + k];
+            v[p] = vk[p * 8];
+            s[p] = __builtin_bit_cast(float, vk[p * 8 + 128]);
         }
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
@@ -513,7 +515,7 @@ NSR_DEV void scatter_walk(const GridDev &G, int lane, const float *Tx, const flo
 #elif defined(NSR_X_SCATTER_HALF)        // one of the two 64-byte lines of every voxel row
                     if (ch < 16) atomic_add_global(G.dfeat + (long long)vx * kC + ch, s[p]);
 #else
-                    atomic_add_global(G.dfeat + (long long)vx * kC + ch, s[p]);
+                    atomic_add_global_off(G.dfeat, ((unsigned)vx << 7) + ((unsigned)ch << 2), s[p]);      // (a grid is < 2^25 voxels = 4 GB: nsr_api.cpp)
 #endif
                 }
             }

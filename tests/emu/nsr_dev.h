@@ -201,6 +201,7 @@ NSR_DEV int atomic_cas_lds_i(int *p, int expect, int v) { const int o = *p; if (
 NSR_DEV int lds_load_i(const int *p) { return *p; }
 NSR_DEV float lds_load_f(const float *p) { return *p; }
 NSR_DEV void atomic_add_global_d(double *p, double v) { *p += v; }
+NSR_DEV void atomic_add_global_off(float *base, unsigned byte_off, float v) { atomic_add_global(reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off), v); }
 NSR_DEV unsigned long long atomic_fetch_add_global_u64(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
 NSR_DEV void atomic_max_pos(float *p, float v) {
     uint32_t *u = reinterpret_cast<uint32_t *>(p);

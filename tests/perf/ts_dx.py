@@ -39,6 +39,14 @@ for s in range(1, 10):
     d = (t[:, :, s] - t[:, :, s - 1])[ok & (t[:, :, s] > 0) & (t[:, :, s - 1] > 0)]
     if d.size:
         print("   %-48s %8.2f %8.2f %8.2f   (mean / p10 / p90 us)" % (names[s], d.mean(), np.percentile(d, 10), np.percentile(d, 90)))
+print("   absolute times after the first wave's entry (mean / p10 / p90 / max us):")
+for s, nm in ((0, "wave entry"), (1, "operands staged"), (2, "last tile: requests issued"), (3, "last tile: layers done"), (4, "last tile: embedding done"),
+              (5, "last tile: level done, next inputs landed"), (6, "last tile: scatter issued"), (7, "last tile: ray gradients"), (8, "loop exit (incl. deferred walk)"),
+              (10, "block barrier before the hot-table flush"), (11, "hot table flushed"), (9, "d _B partials written, exit")):
+    m = ok & (t[:, :, s] > 0)
+    if m.any():
+        d = t[:, :, s][m] - t0
+        print("      %-46s %8.2f %8.2f %8.2f %8.2f" % (nm, d.mean(), np.percentile(d, 10), np.percentile(d, 90), d.max()))
 npass = {"coarse": 1, "middle": 1, "fine": 2, "color": 3}[stage]
 per = int(ok.any(1).sum()) // npass
 for p_ in range(npass):                                      # blocks [p * per, (p + 1) * per): decoder pass p (grid.y)
