@@ -446,24 +446,57 @@ NSR_DEV void hot_flush(const HotTab &H, const GridDev &G) {       // after a blo
     }
 }
 
-// part 1 (the wave that owns the tile): dc point-major into Tx, the class table into tab
+// part 1 (the wave that owns the tile): dc point-major into Tx, the class table into tab.
+// Round 6: the table carries the walk's DECISIONS, made here once per (point, class) by the lane that owns the entry -- two entries per
+// lane, all 128 of a tile in parallel -- instead of being re-derived by every one of the walk's 64 sequential steps:
+//   vt[p][cls] >= 0  the run of this class ENDS at point p and is to be added: bits 0..24 = the voxel, or, with kHotBit, bits 0..23 =
+//                    the float offset of the voxel's row in the block's hot table (the slot is found or claimed HERE);
+//             <  0   nothing to emit at this point (inside a run, or the corner is inactive / masked);
+//   wt[p][cls]       the corner's weight; its SIGN BIT set = "same voxel as the previous point of the class": the run sum continues
+//                    (trilinear weights are >= 0; the walk uses |w|).
+// Before: per step a neighbour comparison for "same", one for "end", a sign test and their conjunction, per emission the hot-bit test,
+// a multiplicative hash, the tag read, a compare-and-swap on a free slot and two LDS round trips in the dependent chain -- ~11
+// instructions per step and 11 / 35 per plain / hot emission against 7 and 9 / 9 now (the kernel's length follows its instruction count).
 // `live`: bit c = the lane's corner 2 g + c takes part (consumed-gradient mask, GridDev.gmask; 3 = both)
-NSR_DEV void scatter_stage(const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab, bool hot = false, unsigned live = 3u) {
+NSR_DEV void scatter_stage(const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab, HotTab hot = HotTab{-1, 0},
+                           bool hot_pt = false, unsigned live = 3u) {
     const int pt = lane & 15, g = lane >> 4;
     int *vt = reinterpret_cast<int *>(tab);
-    float *wt = tab + 128;
+    int *wt = vt + 128;
     tx_store(Tx, dc, pt, g);
+    int raw[2], cls[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        const int k = 2 * g + c, cls = k ^ L.par;
-        vt[pt * 8 + cls] = (active && ((live >> c) & 1u)) ? (corner_vox(L, k) | (hot ? kHotBit : 0)) : -1;
-        wt[pt * 8 + cls] = corner_w(L, k);
+        const int k = 2 * g + c;
+        cls[c] = k ^ L.par;
+        raw[c] = (active && ((live >> c) & 1u)) ? corner_vox(L, k) : -1;
+        vt[pt * 8 + cls[c]] = raw[c];
+    }
+    wave_fence();
+    int prev[2], next[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        prev[c] = vt[(pt > 0 ? pt - 1 : pt) * 8 + cls[c]];
+        next[c] = vt[(pt < 15 ? pt + 1 : pt) * 8 + cls[c]];
+    }
+    wave_fence();                         // (every lane has its neighbours before any entry is rewritten)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const bool same = pt > 0 && raw[c] == prev[c];
+        const bool emit = raw[c] >= 0 && (pt == 15 || raw[c] != next[c]);
+        int word = emit ? raw[c] : -1;
+        if (emit && hot.off >= 0 && hot_pt) {
+            const int slot = hot_slot(hot, raw[c]);
+            int tg = lds_load_i(hot_tag(hot) + slot);
+            if (tg == -1) { const int old = atomic_cas_lds_i(hot_tag(hot) + slot, -1, raw[c]); tg = old == -1 ? raw[c] : old; }
+            if (tg == raw[c]) word = kHotBit | (slot * kC);
+        }
+        vt[pt * 8 + cls[c]] = word;
+        wt[pt * 8 + cls[c]] = __builtin_bit_cast(int, corner_w(L, 2 * g + c)) | (same ? (int)0x80000000 : 0);
     }
 }
-// part 2 (any wave, after a fence / flag hand-off): the walks and the atomics.  Branch-light: the run sums are a segmented
-// scan with selects (the same fma chain per run as a sequential walk: acc = x*w at a run's first point, fma afterwards), and
-// the only divergent code is one predicated atomic per point -- the first version walked with a data-dependent branch nest
-// per point (~25 instructions and three branches, ~380 cycles per atomic: the walk, not the atomic unit, set the pace).
+// part 2 (after a wave fence): the walks and the atomics.  Lane = (class of the pair 2 q + h, channel); per step one select, one fma
+// and the emission test; the only divergent code is the emission itself (an LDS atomic on a hot row or one memory atomic).
 NSR_DEV void scatter_walk(const GridDev &G, int lane, const float *Tx, const float *tab,
                           int lds_grid = -1,           // >= 0: the whole gradient grid sits in LDS at this offset (floats; small grids, nsr_bwd2.h)
                           HotTab hot = HotTab{-1, 0}) {
@@ -472,50 +505,34 @@ NSR_DEV void scatter_walk(const GridDev &G, int lane, const float *Tx, const flo
     // immediate offset reaches, and with the region's constant folded into every read's literal the compiler formed each of the 32
     // addresses of a round with a v_add of its own (128 per tile); off an opaque base the reads carry p * 32 bytes as their immediates
     const int tab_off = (int)(tab - reinterpret_cast<const float *>(lds_base()));
+    const int hv_off = hot.off + hot.slots + ch;              // this lane's channel of hot row 0 (floats from the LDS base)
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
         const int *vk = reinterpret_cast<const int *>(lds_base()) + opaque_i(tab_off + 2 * q + h);
-        int v[16];
-        float s[16];
+        int v[16], w[16];
+        float x[16];
 #pragma unroll
         for (int p = 0; p < 16; ++p) {        // all LDS reads of the round in flight at once
             v[p] = vk[p * 8];
-            s[p] = __builtin_bit_cast(float, vk[p * 8 + 128]);
+            w[p] = vk[p * 8 + 128];
+            x[p] = Tx[p * kTxS + ch];
         }
+        sched_fence();                        // (the scheduler would sink each dc read to its use: one LDS round trip per step)
+        float s = 0.f;
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
-            const float x = Tx[p * kTxS + ch];
-            const float first = x * s[p];
-            s[p] = (p > 0 && v[p] == v[p - 1]) ? fmaf(x, s[p], s[p - 1]) : first;
-        }
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const bool end = p == 15 || v[p] != v[p + 1];
-            if (end && v[p] >= 0) {
-                const int vox = v[p] & ~kHotBit;
-                bool done = false;
-                if (lds_grid >= 0) { atomic_add_lds(reinterpret_cast<float *>(lds_base()) + lds_grid + vox * kC + ch, s[p]); done = true; }
-                else if (hot.off >= 0 && (v[p] & kHotBit)) {
-                    const int slot = hot_slot(hot, vox);
-                    int tg = lds_load_i(hot_tag(hot) + slot);
-                    if (tg == -1) { const int old = atomic_cas_lds_i(hot_tag(hot) + slot, -1, vox); tg = old == -1 ? vox : old; }
-                    if (tg == vox) { atomic_add_lds(hot_val(hot) + slot * kC + ch, s[p]); done = true; }
-                }
-#if defined(NSR_X_SCATTER_LDS)           // A/B build: every update as an LDS atomic on some table row (wrong numbers; what a block-level write-back table could reach)
-                if (!done && hot.off >= 0) { atomic_add_lds(hot_val(hot) + hot_slot(hot, vox) * kC + ch, s[p]); done = true; }
-#endif
-                if (!done) {
-#if defined(NSR_X_SCATTER_HASH)          // A/B builds (tools/build_ts.sh ... -DNSR_X_...): same request count, voxels spread over the grid
-                    const int vx = (int)(((unsigned)vox * 2654435761u) % (unsigned)(G.X * G.Y * G.Z));
+            // (the same fma chain per run as a sequential walk; a run's first term is fma(x, w, 0) = x * w)
+            s = fmaf(x[p], fabsf(__builtin_bit_cast(float, w[p])), w[p] < 0 ? s : 0.f);
+            if (v[p] >= 0) {
+                if (lds_grid >= 0) atomic_add_lds(reinterpret_cast<float *>(lds_base()) + lds_grid + v[p] * kC + ch, s);
+                else if (v[p] & kHotBit) atomic_add_lds(reinterpret_cast<float *>(lds_base()) + hv_off + (v[p] & (kHotBit - 1)), s);
+                else {
+#if defined(NSR_X_SCATTER_STORE)         // A/B build: plain stores to the same addresses (what the vector-memory path costs without the atomic)
+                    G.dfeat[(long long)v[p] * kC + ch] = s;
+#elif defined(NSR_X_SCATTER_HALF)        // A/B build: one of the two 64-byte lines of every voxel row
+                    if (ch < 16) atomic_add_global_off(G.dfeat, ((unsigned)v[p] << 7) + ((unsigned)ch << 2), s);
 #else
-                    const int vx = vox;
-#endif
-#if defined(NSR_X_SCATTER_STORE)         // plain stores to the same addresses (what the vector-memory path costs without the atomic)
-                    G.dfeat[(long long)vx * kC + ch] = s[p];
-#elif defined(NSR_X_SCATTER_HALF)        // one of the two 64-byte lines of every voxel row
-                    if (ch < 16) atomic_add_global(G.dfeat + (long long)vx * kC + ch, s[p]);
-#else
-                    atomic_add_global_off(G.dfeat, ((unsigned)vx << 7) + ((unsigned)ch << 2), s[p]);      // (a grid is < 2^25 voxels = 4 GB: nsr_api.cpp)
+                    atomic_add_global_off(G.dfeat, ((unsigned)v[p] << 7) + ((unsigned)ch << 2), s);      // (a grid is < 2^25 voxels = 4 GB: nsr_api.cpp)
 #endif
                 }
             }
@@ -530,7 +547,7 @@ NSR_DEV unsigned gmask_bits(const GridDev &G, const Lvl &L, int g) {
 }
 NSR_DEV void scatter_merged(const GridDev &G, const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab,
                             int lds_grid = -1, HotTab hot = HotTab{-1, 0}, bool hot_pt = false, unsigned live = 3u) {
-    scatter_stage(L, lane, dc, active, Tx, tab, hot.off >= 0 && hot_pt, live);
+    scatter_stage(L, lane, dc, active, Tx, tab, hot, hot_pt, live);
     wave_fence();
     scatter_walk(G, lane, Tx, tab, lds_grid, hot);
     wave_fence();
