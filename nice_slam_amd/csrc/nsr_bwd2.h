@@ -211,10 +211,7 @@ NSR_DEV void dx_pass(const RenderParams &P) {
         const double *pp = P.pd + (active ? gp : 0) * 4;
         const double cpx = pp[0], cpy = pp[1], cpz = pp[2], cz = pp[3];
         dbg.stamp(2);
-        unsigned mk[5];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mk[i] = active ? (cur.m0 >> (8 * i)) & 255u : 0u;
-        mk[4] = active ? cur.m1 & 255u : 0u;
+        const unsigned mw0 = active ? cur.m0 : 0u, mw1 = active ? cur.m1 : 0u;       // relu masks: byte i of (m0, m1) = layer i
         const float dsc = active ? dr_scale : 0.f;           // rows beyond the last point carry no gradient
         float d_out[4] = {0.f, 0.f, 0.f, 0.f};
         if (NOUT == 1) d_out[0] = cur.dr.w * dsc;
@@ -238,7 +235,7 @@ NSR_DEV void dx_pass(const RenderParams &P) {
 #pragma unroll
         for (int I = 4; I >= 0; --I) {
             if (XYZ && need_dc) gemv_t<2>(dc.t, dh, wt + xyzT_u(I), lane);         // gradient of (U_i c + v_i) is dh itself
-            const Act<2> dY = apply_mask(dh, mk[I]);
+            const Act<2> dY = apply_mask(dh, I < 4 ? mw0 : mw1, I < 4 ? 8 * I : 0);
             if (PARAMS && active && !(P.xflags & 2)) {
                 st4(dyp + (2 * I) * sstride, to_F4(dY.t[0]));
                 st4(dyp + (2 * I + 1) * sstride, to_F4(dY.t[1]));
@@ -879,8 +876,9 @@ NSR_DEV unsigned long long dw_live_mask(const RenderParams &P, long long bi, lon
     const long long t = bi + ((long long)chunk * 64 + lane) * step;
     bool live = false;
     if (t < ntiles) {
-        const unsigned p0 = (unsigned)t * kTile, np = (unsigned)P.n_points_total, pe = p0 + kTile < np ? p0 + kTile : np, S = (unsigned)P.S;   // (< 2^25 points per call)
-        for (unsigned r = p0 / S; r <= (pe - 1) / S; ++r) live = live || P.keep[r] != 0;
+        const unsigned p0 = (unsigned)t * kTile, np = (unsigned)P.n_points_total, pe = p0 + kTile < np ? p0 + kTile : np;   // (< 2^25 points per call)
+        const unsigned r0 = (unsigned)(((unsigned long long)p0 * P.s_magic) >> 32), r1 = (unsigned)(((unsigned long long)(pe - 1) * P.s_magic) >> 32);
+        for (unsigned r = r0; r <= r1; ++r) live = live || P.keep[r] != 0;
     }
     return ballot64(live);
 }

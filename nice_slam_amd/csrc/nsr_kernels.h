@@ -101,6 +101,7 @@ struct RenderParams {
     int lds_grid_floats;      // > 0 (coarse stage): the gradient grid (this many floats) is accumulated in the dX block's LDS
     float hot_z[4];           // dX kernel, per grid: samples with z below it use the block's hot-voxel table (0: no table)
     int hot_slots;            // dX kernel: slots of that table (the launch sizes it to the LDS the block has left)
+    unsigned s_magic;         // ceil(2^32 / S): floor(x / S) = (x * s_magic) >> 32 for every x < 2^25 (S <= 64), see tile_live
     int pass_beg[4];          // pass kernels (nsr_fwd2.h): blocks [pass_beg[p], pass_beg[p + 1]) of the launch work on decoder pass p
     // eval_points only
     const double *points;
@@ -116,9 +117,13 @@ NSR_DEV bool tile_live(const RenderParams &P, long long tile) {
     if (!P.skip_masked) return true;
     // (32-bit: a call holds fewer than 2^25 sample points, nsr_api.cpp; the 64-bit form was two software divisions, ~700 scalar
     //  instructions per claimed tile)
-    const unsigned p0 = (unsigned)tile * kTile, np = (unsigned)P.n_points_total, pe = p0 + kTile < np ? p0 + kTile : np, S = (unsigned)P.S;
+    // Round 6: scalar throughout -- the tile index is pinned to an SGPR and the two divisions by S are multiplications by ceil(2^32 / S)
+    // (exact for x < 2^26 when S <= 64: x e < 2^32 with e = S ceil(2^32 / S) - 2^32 < S; a call holds < 2^25 points); as per-lane 32-bit divisions they were ~30
+    // vector instructions per claimed tile in each of the pass, dX and dW kernels.
+    const unsigned p0 = (unsigned)uniform((int)tile) * kTile, np = (unsigned)P.n_points_total, pe = p0 + kTile < np ? p0 + kTile : np;
+    const unsigned r0 = (unsigned)(((unsigned long long)p0 * P.s_magic) >> 32), r1 = (unsigned)(((unsigned long long)(pe - 1) * P.s_magic) >> 32);
     bool live = false;
-    for (unsigned r = p0 / S; r <= (pe - 1) / S; ++r) live = live || uniform_load_u8(P.keep + r) != 0u;
+    for (unsigned r = r0; r <= r1; ++r) live = live || uniform_load_u8(P.keep + r) != 0u;
     return live;
 }
 
@@ -704,12 +709,18 @@ NSR_DEV void relu_plain(f32x4 (&acc)[2]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[T][r] = relu1(acc[T][r]);
 }
-NSR_DEV Act<2> apply_mask(const Act<2> &d, unsigned m) {
+// d where bit `base + j` of `word` is set (j = 4 T + r), else 0: the bit sign-extended to a full mask (one v_bfe_i32) and one v_and per
+// value -- the test / compare / select form was three
+NSR_DEV Act<2> apply_mask(const Act<2> &d, unsigned word, int base) {
     Act<2> o;
 #pragma unroll
     for (int T = 0; T < 2; ++T)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o.t[T][r] = (m >> (T * 4 + r)) & 1u ? d.t[T][r] : 0.f;
+        for (int r = 0; r < 4; ++r) {
+            const int m = ((int)(word << (31 - (base + T * 4 + r)))) >> 31;
+            const float f = d.t[T][r];          // (a bit_cast straight off a vector ELEMENT reads element 0 with this compiler)
+            o.t[T][r] = __builtin_bit_cast(float, __builtin_bit_cast(int, f) & m);
+        }
     return o;
 }
 
