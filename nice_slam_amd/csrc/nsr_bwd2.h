@@ -167,10 +167,15 @@ NSR_DEV void dx_pass(const RenderParams &P) {
     DxIn cur;
     if (pre) cur = dx_load(P, acts_pass, tile, pt, g);
     copy_f4<AUX_FLOATS / 4>(aux, D.packed);
+#if defined(NSR_X_DX_STAGE_COPY)             // A/B build: the transposed stream through registers (rounds 2-5)
     copy_f4<packedT_total(KIND) / 4>(wt, D.packed + AUX_FLOATS + packed_total(KIND));
+#else
+    copy_f4_dma<packedT_total(KIND) / 4>(wt, D.packed + AUX_FLOATS + packed_total(KIND));
+#endif
     if (gl) for (int i = tid(); i < P.lds_grid_floats; i += nthreads()) gl[i] = 0.f;
     if (use_hot) hot_init(hot);
     if (tid() == 0) tcnt[0] = nw;
+    dma_wait<0>();
     block_sync();
     dbg.stamp(1);
     float *dys = P.dy + (long long)act_pass(KIND) * P.act_tiles * kDySlots * 256;

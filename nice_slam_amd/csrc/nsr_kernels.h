@@ -206,6 +206,14 @@ NSR_DEV void copy_f4(float *dst, const float *__restrict__ src) {
     }
     for (; t < NF4; t += nt) st4(dst + 4 * t, ld4(src + 4 * t));
 }
+// the same as global -> LDS DMA (no register round trip, every piece of the block in flight at once); the caller waits (dma_wait<0>)
+// before its barrier.  A wave instruction moves the 1 KB [64 lanes][16 bytes] piece that starts at its first lane's element.
+template <int NF4>
+NSR_DEV void copy_f4_dma(float *dst, const float *__restrict__ src) {
+    static_assert(NF4 % 64 == 0, "whole 1 KB pieces");
+    const int nt = nthreads(), lane = tid() & 63;
+    for (int t = tid(); t < NF4; t += nt) dma16(src + 4 * t, dst + 4 * (t - lane), lane);
+}
 // stage the small per-decoder tables into LDS (all threads of the block); `packed` = the decoder's packed buffer
 template <int KIND>
 NSR_DEV void load_aux(float *aux, const float *__restrict__ packed) { copy_f4<AUX_FLOATS / 4>(aux, packed); }
