@@ -108,8 +108,9 @@ NSR_DEV void fwd_pass(const RenderParams &P, int bi, int nbp) {
     const Dbg dbg{P.dbg ? P.dbg + ((long long)bid_x() * 12 + wave) * 64 : nullptr};
     dbg.stamp(0);
     load_aux<KIND>(aux, D.packed);
-    load_packed<KIND>(wl, D.packed);
+    copy_f4_dma<packed_total(KIND) / 4>(wl, D.packed + AUX_FLOATS);      // (global -> LDS DMA, like the dX kernel's stream: round 6)
     if (tid() == 0) cnt[0] = 0;
+    dma_wait<0>();
     block_sync();
     dbg.stamp(1);
     const long long ntiles = (P.n_points_total + kTile - 1) / kTile;

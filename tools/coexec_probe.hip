@@ -15,7 +15,7 @@ __global__ __launch_bounds__(512) void probe(float *out, int it_mfma, int it_oth
     for (int i = threadIdx.x; i < 4096; i += blockDim.x) lds[i] = 1.0f + 1e-3f * i;
     __syncthreads();
     float s = 0.f;
-    const bool mfma_wave = swap ? wave >= 4 : wave < 4;      // swap: the YOUNGER half of the block issues the MFMAs
+    const bool mfma_wave = (mode & 4) ? false : (swap ? wave >= 4 : wave < 4);      // swap: the YOUNGER half of the block issues the MFMAs; mode bit 2: every wave is an `other` wave
     if (!mfma_wave && prio == 1) __builtin_amdgcn_s_setprio(3);
     if (mfma_wave && prio == 2) __builtin_amdgcn_s_setprio(3);
     if (mfma_wave) {
@@ -94,6 +94,8 @@ void run(const char *name, float *out) {
     const float tb = time_ms<KIND>(out, it_mfma, it_other, 3);
     const float tbs = time_ms<KIND>(out, it_mfma, it_other, 3, 1, 0), tbp = time_ms<KIND>(out, it_mfma, it_other, 3, 0, 1), tbq = time_ms<KIND>(out, it_mfma, it_other, 3, 0, 2),
                 tbsp = time_ms<KIND>(out, it_mfma, it_other, 3, 1, 1);
+    const float t2 = time_ms<KIND>(out, 0, it_other, 6);
+    printf("%-14s two `other` waves per SIMD, no MFMA: %7.3f ms = %5.2f cycles per instruction per SIMD (one wave alone: %5.2f)\n", name, t2, t2 * 1e-3 * 2.4e9 / (it_other * 16.0), to * 1e-3 * 2.4e9 / (it_other * 8.0));
     printf("%-14s both, MFMA waves younger %7.3f | other waves at s_setprio 3 %7.3f | MFMA waves at s_setprio 3 %7.3f | younger MFMA + other at prio 3 %7.3f ms\n", name, tbs, tbp, tbq, tbsp);
     printf("%-14s MFMA alone %7.3f ms (%5.1f cycles per MFMA per SIMD at 2.4 GHz) | other alone %7.3f ms (%5.2f cycles per instruction) | both %7.3f ms = %4.2f x max, %4.2f x sum\n",
            name, tm, tm * 1e-3 * 2.4e9 / (it_mfma * 8.0), to, to * 1e-3 * 2.4e9 / (it_other * 8.0), tb, tb / (tm > to ? tm : to), tb / (tm + to));
