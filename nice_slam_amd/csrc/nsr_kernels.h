@@ -707,7 +707,13 @@ NSR_DEV unsigned relu_mask(f32x4 (&acc)[2]) {
     for (int T = 0; T < 2; ++T)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (acc[T][r] > 0.f) m |= 1u << (T * 4 + r); else acc[T][r] = 0.f;
+            // max(x, 0) on the bit pattern (relu1), then "the result is not zero" as min(bits, 1) shifted into the mask: three instructions per
+            // value (v_max_i32, v_min_u32, v_lshl_or_b32) where compare + two selects + or were four to five (round 6: vector instructions
+            // exclude the other waves' MFMAs, profiles/r06_experiments.txt item 8)
+            const float h = relu1(acc[T][r]);
+            const unsigned hb = __builtin_bit_cast(unsigned, h);
+            m |= (hb < 1u ? hb : 1u) << (T * 4 + r);
+            acc[T][r] = h;
         }
     return m;
 }
