@@ -465,11 +465,11 @@ NSR_DEV void hot_flush(const HotTab &H, const GridDev &G) {       // after a blo
 //   vt[p][cls] >= 0  the run of this class ENDS at point p and is to be added: bits 0..24 = the voxel, or, with kHotBit, bits 0..23 =
 //                    the float offset of the voxel's row in the block's hot table (the slot is found or claimed HERE);
 //             <  0   nothing to emit at this point (inside a run, or the corner is inactive / masked);
-//   wt[p][cls]       the corner's weight; its SIGN BIT set = "same voxel as the previous point of the class": the run sum continues
-//                    (trilinear weights are >= 0; the walk uses |w|).
+//   wt[p][cls]       the corner's weight, 0 for an inactive / masked corner.  The walk needs no "run continues" flag: it restarts its sum
+//                    behind every emission, and what lies between two emitted runs adds exact zeros.
 // Before: per step a neighbour comparison for "same", one for "end", a sign test and their conjunction, per emission the hot-bit test,
 // a multiplicative hash, the tag read, a compare-and-swap on a free slot and two LDS round trips in the dependent chain -- ~11
-// instructions per step and 11 / 35 per plain / hot emission against 7 and 9 / 9 now (the kernel's length follows its instruction count).
+// instructions per step and 11 / 35 per plain / hot emission against 6 and 9 / 9 now (the kernel's length follows its instruction count).
 // `live`: bit c = the lane's corner 2 g + c takes part (consumed-gradient mask, GridDev.gmask; 3 = both)
 NSR_DEV void scatter_stage(const Lvl &L, int lane, const Act<2> &dc, bool active, float *Tx, float *tab, HotTab hot = HotTab{-1, 0},
                            bool hot_pt = false, unsigned live = 3u) {
@@ -486,16 +486,12 @@ NSR_DEV void scatter_stage(const Lvl &L, int lane, const Act<2> &dc, bool active
         vt[pt * 8 + cls[c]] = raw[c];
     }
     wave_fence();
-    int prev[2], next[2];
+    int next[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) next[c] = vt[(pt < 15 ? pt + 1 : pt) * 8 + cls[c]];
+    wave_fence();                         // (every lane has its neighbour before any entry is rewritten)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        prev[c] = vt[(pt > 0 ? pt - 1 : pt) * 8 + cls[c]];
-        next[c] = vt[(pt < 15 ? pt + 1 : pt) * 8 + cls[c]];
-    }
-    wave_fence();                         // (every lane has its neighbours before any entry is rewritten)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const bool same = pt > 0 && raw[c] == prev[c];
         const bool emit = raw[c] >= 0 && (pt == 15 || raw[c] != next[c]);
         int word = emit ? raw[c] : -1;
         if (emit && hot.off >= 0 && hot_pt) {
@@ -505,11 +501,11 @@ NSR_DEV void scatter_stage(const Lvl &L, int lane, const Act<2> &dc, bool active
             if (tg == raw[c]) word = kHotBit | (slot * kC);
         }
         vt[pt * 8 + cls[c]] = word;
-        wt[pt * 8 + cls[c]] = __builtin_bit_cast(int, corner_w(L, 2 * g + c)) | (same ? (int)0x80000000 : 0);
+        wt[pt * 8 + cls[c]] = raw[c] >= 0 ? __builtin_bit_cast(int, corner_w(L, 2 * g + c)) : 0;
     }
 }
-// part 2 (after a wave fence): the walks and the atomics.  Lane = (class of the pair 2 q + h, channel); per step one select, one fma
-// and the emission test; the only divergent code is the emission itself (an LDS atomic on a hot row or one memory atomic).
+// part 2 (after a wave fence): the walks and the atomics.  Lane = (class of the pair 2 q + h, channel); per step one fma and the
+// emission test; the only divergent code is the emission itself (an LDS atomic on a hot row or one memory atomic).
 NSR_DEV void scatter_walk(const GridDev &G, int lane, const float *Tx, const float *tab,
                           int lds_grid = -1,           // >= 0: the whole gradient grid sits in LDS at this offset (floats; small grids, nsr_bwd2.h)
                           HotTab hot = HotTab{-1, 0}) {
@@ -535,8 +531,8 @@ NSR_DEV void scatter_walk(const GridDev &G, int lane, const float *Tx, const flo
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             // (the same fma chain per run as a sequential walk; a run's first term is fma(x, w, 0) = x * w)
-            s = fmaf(x[p], fabsf(__builtin_bit_cast(float, w[p])), w[p] < 0 ? s : 0.f);
-            if (v[p] >= 0) {
+            s = fmaf(x[p], __builtin_bit_cast(float, w[p]), s);
+            if (__builtin_expect(v[p] >= 0, 0)) {      // (the emission out of line: a step that emits nothing -- 60 % of them -- takes no branch)
                 if (lds_grid >= 0) atomic_add_lds(reinterpret_cast<float *>(lds_base()) + lds_grid + v[p] * kC + ch, s);
                 else if (v[p] & kHotBit) atomic_add_lds(reinterpret_cast<float *>(lds_base()) + hv_off + (v[p] & (kHotBit - 1)), s);
                 else {
@@ -548,6 +544,7 @@ NSR_DEV void scatter_walk(const GridDev &G, int lane, const float *Tx, const flo
                     atomic_add_global_off(G.dfeat, ((unsigned)v[p] << 7) + ((unsigned)ch << 2), s);      // (a grid is < 2^25 voxels = 4 GB: nsr_api.cpp)
 #endif
                 }
+                s = 0.f;                          // the next run of this half's class starts here
             }
         }
     }
@@ -609,13 +606,17 @@ NSR_DEV f32x4 splat(float v) { f32x4 r = {v, v, v, v}; return r; }
 NSR_DEV f32x4 vfma(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
 // Four arguments at a time: every step is a <4 x float> operation, i.e. two packed-fp32 instructions (v_pk_fma_f32 /
 // v_pk_mul_f32 / v_pk_add_f32), half the VALU issue slots of the scalar form.
-NSR_DEV f32x4 sin_poly4(f32x4 r, u32x4 sign) {
-    const f32x4 r2 = r * r;
+// `t`: the float whose bit 0 is the parity of the quotient (the cosine passes its complement).  The sign is applied as a FACTOR to r --
+// sgn = as_float(0x3f800000 | t << 31) is one v_lshl_or_b32 per value, r * sgn one packed multiply per pair, and fma(p r^2, r sgn, r sgn) =
+// sgn (r + r^3 p) to the bit -- where shifting the parity up and xor-ing it into the result was two to three unpacked integer
+// instructions per value (round 6: vector instructions exclude the other waves' MFMAs).
+NSR_DEV f32x4 sin_poly4(f32x4 r, u32x4 t) {
+    const f32x4 sgn = __builtin_bit_cast(f32x4, (t << 31) | 0x3f800000u);
+    const f32x4 r2 = r * r, rs = r * sgn;
     f32x4 p = vfma(r2, splat(2.59048850e-06f), splat(-1.98008978e-04f));
     p = vfma(p, r2, splat(8.33289982e-03f));
     p = vfma(p, r2, splat(-1.66666476e-01f));
-    const f32x4 s = vfma(p * r2, r, r);
-    return __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, s) ^ sign);
+    return vfma(p * r2, rs, rs);
 }
 // quotient by the "1.5 * 2^23" trick: t = x/pi + 12582912 has round(x/pi) in its low mantissa bits (|x| < 1e7), so
 // its parity is bit 0 of the float and no float->int conversion / compare / select is needed for the sign
@@ -633,7 +634,7 @@ NSR_DEV f32x4 sin_acc4(f32x4 x) {
     const f32x4 k = t - splat(12582912.f);
     f32x4 r = vfma(k, splat(-3.14159274101257324f), x);
     r = vfma(k, splat(8.74227765734758577e-08f), r);
-    return sin_poly4(r, __builtin_bit_cast(u32x4, t) << 31);
+    return sin_poly4(r, __builtin_bit_cast(u32x4, t));
 }
 // cos(x) = -(-1)^k sin(r) with x = (k + 1/2) pi + r
 NSR_DEV f32x4 cos_acc4(f32x4 x) {
@@ -642,7 +643,7 @@ NSR_DEV f32x4 cos_acc4(f32x4 x) {
     f32x4 r = vfma(k, splat(-3.14159274101257324f), x);
     r = vfma(k, splat(8.74227765734758577e-08f), r);
     r = (r - splat(1.57079637050628662f)) + splat(4.37113882867379289e-08f);
-    return sin_poly4(r, (__builtin_bit_cast(u32x4, t) << 31) ^ 0x80000000u);
+    return sin_poly4(r, ~__builtin_bit_cast(u32x4, t));
 }
 // the three places a Fourier feature is evaluated: the forward's embedding, the dW kernel's re-evaluation of it, the dX kernel's cosines
 #if defined(NSR_X_LIBM_SIN)
