@@ -35,8 +35,8 @@ from nice_slam_amd import _capi  # noqa: E402
 import emu_harness  # noqa: E402
 
 
-def layer_preact(sc, rays, layer, lo):
-    """z = W_layer h + b_layer of the colour decoder at every sample point of `rays` (oracle operators, decoder.py:177-203)"""
+def layer_preact(sc, rays, layer, lo, dec="color"):
+    """z = W_layer h + b_layer of decoder `dec` (colour by default) at every sample point of `rays` (oracle operators, decoder.py:177-203)"""
     P = {k: v.to(lo) for k, v in sc["params"].items()}
     o, d, gd = sc["rays_o"][rays], sc["rays_d"][rays], sc["gt_depth"][rays]
     # the oracle takes the batch-global max depth from the batch itself: append the maximum-depth ray (Renderer.py:109,144)
@@ -45,8 +45,12 @@ def layer_preact(sc, rays, layer, lo):
                           sc["bound"], "color", 32, 16, torch.float64)[:-1]
     pts = (o[:, None, :].to(torch.float64) + d[:, None, :].to(torch.float64) * z[:, :, None]).reshape(-1, 3)
     bounds = orc.decoder_bounds(sc["bound"], 2.0)
-    c = orc.trilinear(sc["grids"]["grid_color"].to(lo), pts, bounds["color"], lo)
-    pre = "color_decoder."
+    if dec == "fine":          # decoder.py:182-187: [c_fine | c_mid]
+        c = torch.cat([orc.trilinear(sc["grids"]["grid_fine"].to(lo), pts, bounds["fine"], lo),
+                       orc.trilinear(sc["grids"]["grid_middle"].to(lo), pts, bounds["middle"], lo)], -1)
+    else:
+        c = orc.trilinear(sc["grids"]["grid_" + dec].to(lo), pts, bounds[dec], lo)
+    pre = dec + "_decoder."
     e = torch.sin(pts.to(lo) @ P[pre + "embedder._B"])
     h = e
     for i in range(5):
@@ -67,20 +71,21 @@ def main():
     ap.add_argument("--rays", type=int, default=100_000)
     ap.add_argument("--scene", default="synthetic")
     ap.add_argument("--seed", type=int, default=26)
+    ap.add_argument("--decoder", default="color", choices=("middle", "fine", "color"))
     ap.add_argument("--full", action="store_true", help="also evaluate the full-batch oracle (max|dW| of the layer: the test's denominator)")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_relu_kink_cause.json"))
     args = ap.parse_args()
     torch.set_num_threads(8)
     sc = make_scene(seed=args.seed, n_rays=args.rays, scene=args.scene, fine_scale=1.0)
     n, S = args.rays, 48
-    key_w, key_b = f"dparam/color_decoder.pts_linears.{args.layer}.weight", f"dparam/color_decoder.pts_linears.{args.layer}.bias"
+    key_w, key_b = f"dparam/{args.decoder}_decoder.pts_linears.{args.layer}.weight", f"dparam/{args.decoder}_decoder.pts_linears.{args.layer}.bias"
     # 1. candidates
     best = []
     with torch.no_grad():
         for lo_i in range(0, n, 10_000):
             sl = slice(lo_i, min(n, lo_i + 10_000))
-            z32 = layer_preact(sc, sl, args.layer, torch.float32)
-            z64 = layer_preact(sc, sl, args.layer, torch.float64)
+            z32 = layer_preact(sc, sl, args.layer, torch.float32, args.decoder)
+            z64 = layer_preact(sc, sl, args.layer, torch.float64, args.decoder)
             if args.row >= 0:
                 z32, z64 = z32[:, args.row:args.row + 1], z64[:, args.row:args.row + 1]
             a = z32.abs().double().reshape(-1)
