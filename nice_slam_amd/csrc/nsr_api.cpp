@@ -107,7 +107,7 @@ int build_params(const nsr_render_args *a, nsr::RenderParams &P, bool need_rays,
         if (a->n_rays < 0) return fail("nsr: negative ray count");
         if (a->n_rays > 0 && (!a->rays_o || !a->rays_d)) return fail("nsr: null ray pointers");
     }
-    P.s_magic = (unsigned)(((1ull << 32) + (unsigned)P.S - 1) / (unsigned)P.S);
+    P.s_magic = P.S > 1 ? (unsigned)(((1ull << 32) + (unsigned)P.S - 1) / (unsigned)P.S) : 0u;     // (S = 1: nsr_kernels.h::ray_of_point)
     P.rays_per_block = rays_per_block(P.S);
     if (!bwd) {
         // Small batches (the tracker's 200 rays): a forward block runs its decoders one after the other, so with few blocks the

@@ -882,7 +882,7 @@ NSR_DEV unsigned long long dw_live_mask(const RenderParams &P, long long bi, lon
     bool live = false;
     if (t < ntiles) {
         const unsigned p0 = (unsigned)t * kTile, np = (unsigned)P.n_points_total, pe = p0 + kTile < np ? p0 + kTile : np;   // (< 2^25 points per call)
-        const unsigned r0 = (unsigned)(((unsigned long long)p0 * P.s_magic) >> 32), r1 = (unsigned)(((unsigned long long)(pe - 1) * P.s_magic) >> 32);
+        const unsigned r0 = ray_of_point(P, p0), r1 = ray_of_point(P, pe - 1);
         for (unsigned r = r0; r <= r1; ++r) live = live || P.keep[r] != 0;
     }
     return ballot64(live);

@@ -101,7 +101,7 @@ struct RenderParams {
     int lds_grid_floats;      // > 0 (coarse stage): the gradient grid (this many floats) is accumulated in the dX block's LDS
     float hot_z[4];           // dX kernel, per grid: samples with z below it use the block's hot-voxel table (0: no table)
     int hot_slots;            // dX kernel: slots of that table (the launch sizes it to the LDS the block has left)
-    unsigned s_magic;         // ceil(2^32 / S): floor(x / S) = (x * s_magic) >> 32 for every x < 2^25 (S <= 64), see tile_live
+    unsigned s_magic;         // ceil(2^32 / S), 0 for S = 1: floor(x / S) = (x * s_magic) >> 32 for every x < 2^25 (S <= 64), see ray_of_point
     int pass_beg[4];          // pass kernels (nsr_fwd2.h): blocks [pass_beg[p], pass_beg[p + 1]) of the launch work on decoder pass p
     // eval_points only
     const double *points;
@@ -113,6 +113,11 @@ struct RenderParams {
 // rays the callers' bounding-box pre-filter rejected are removed, like the reference's compaction, src/Mapper.py:471-481.)
 // Wave-uniform; the mask bytes come through the scalar cache.  Forward passes, dX, dW and the compositor apply the same test.
 NSR_DEV bool ray_live(const RenderParams &P, long long ray) { return !P.skip_masked || uniform_load_u8(P.keep + ray) != 0u; }
+// floor(x / S) for a sample-point index x < 2^25: one multiplication by s_magic = ceil(2^32 / S) (exact while x e < 2^32, e = S s_magic - 2^32
+// < S <= 64); S = 1 (s_magic = 2^32 does not fit the field and is passed as 0): the index itself
+NSR_DEV unsigned ray_of_point(const RenderParams &P, unsigned x) {
+    return P.s_magic ? (unsigned)(((unsigned long long)x * P.s_magic) >> 32) : x;
+}
 NSR_DEV bool tile_live(const RenderParams &P, long long tile) {
     if (!P.skip_masked) return true;
     // (32-bit: a call holds fewer than 2^25 sample points, nsr_api.cpp; the 64-bit form was two software divisions, ~700 scalar
@@ -121,7 +126,7 @@ NSR_DEV bool tile_live(const RenderParams &P, long long tile) {
     // (exact for x < 2^26 when S <= 64: x e < 2^32 with e = S ceil(2^32 / S) - 2^32 < S; a call holds < 2^25 points); as per-lane 32-bit divisions they were ~30
     // vector instructions per claimed tile in each of the pass, dX and dW kernels.
     const unsigned p0 = (unsigned)uniform((int)tile) * kTile, np = (unsigned)P.n_points_total, pe = p0 + kTile < np ? p0 + kTile : np;
-    const unsigned r0 = (unsigned)(((unsigned long long)p0 * P.s_magic) >> 32), r1 = (unsigned)(((unsigned long long)(pe - 1) * P.s_magic) >> 32);
+    const unsigned r0 = ray_of_point(P, p0), r1 = ray_of_point(P, pe - 1);
     bool live = false;
     for (unsigned r = r0; r <= r1; ++r) live = live || uniform_load_u8(P.keep + r) != 0u;
     return live;

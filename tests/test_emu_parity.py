@@ -864,13 +864,15 @@ def test_fused_forward_leaves_d_raw_for_the_split_backward(emu, stage):
         assert rel_err(edited[k], -3.0 * v) < 1e-5, (stage, k)
 
 
-@pytest.mark.parametrize("stage,n_surface", [("coarse", 16), ("middle", 16), ("color", 16), ("color", 5)])
-def test_masked_rays_are_removed_from_the_batch(emu, stage, n_surface):
+@pytest.mark.parametrize("stage,n_surface,n_samples", [("coarse", 16, 32), ("middle", 16, 32), ("color", 16, 32), ("color", 5, 32),
+                                                       ("middle", 0, 1), ("color", 1, 1), ("fine", 3, 60)])
+def test_masked_rays_are_removed_from_the_batch(emu, stage, n_surface, n_samples):
     """nsr_render_args.skip_masked: the rays the bounding-box pre-filter rejects (keep == 0) are not rendered -- what the
     reference's compaction does (Mapper.py:471-481) -- in the forward passes, the compositor, dX and dW alike: the loss and every
     gradient equal those of the run that renders them and masks the loss (their terms are exact zeros there), the kept rays'
     outputs are bit-identical, the removed rays' outputs are 0.  n_surface = 5: 37 samples per ray, tiles that straddle two rays
-    (a tile is skipped only if BOTH are removed); long runs of removed rays: whole tiles, whole dW ring slots stay empty."""
+    (a tile is skipped only if BOTH are removed); long runs of removed rays: whole tiles, whole dW ring slots stay empty.
+    One, two and 63 samples per ray: the ends of the range of the kernels' point-index -> ray division (ray_of_point)."""
     s = make_scene(seed=123, n_rays=53, small=True)
     g = torch.Generator().manual_seed(9)
     keep = (torch.rand((53,), generator=g) < 0.7).numpy().astype(np.uint8)
@@ -879,7 +881,7 @@ def test_masked_rays_are_removed_from_the_batch(emu, stage, n_surface):
     res = {}
     for skip in (False, True):
         sc = _host_scene(emu, s["grids"], s["params"], s["bound"].numpy())
-        sc.n_surface = n_surface
+        sc.n_surface, sc.n_samples = n_surface, n_samples
         fl = {"gt_color": s["gt_color"].numpy(), "keep": keep, "w_color": 0.2, "skip_masked": skip}
         fwd = sc.forward(stage, s["rays_o"].numpy(), s["rays_d"].numpy(), s["gt_depth"].numpy(), fused_loss=fl)
         bwd = sc.backward(stage, fwd, None, None, None, from_forward=True, grad_scale=0.5, max_blocks=3)

@@ -160,3 +160,19 @@ def test_bench_gpus_n_fails_loudly_without_n_devices():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == "" and "--gpus 2" in r.stderr and "device" in r.stderr, (r.returncode, r.stdout, r.stderr[-500:])
+
+
+def test_tile_liveness_reciprocal_is_an_exact_division():
+    """nsr_kernels.h::tile_live divides a sample-point index by the samples per ray S with one multiplication by ceil(2^32 / S)
+    (RenderParams.s_magic, nsr_api.cpp::build_params): exact for every point index a call can hold (< 2^25 points, S <= 64)."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    for S in range(1, 65):
+        magic = ((1 << 32) + S - 1) // S
+        assert magic < (1 << 32) or S == 1          # (S = 1: 2^32 does not fit the 32-bit field; build_params passes 0 and ray_of_point returns the index)
+        x = np.concatenate([np.arange(0, 4096), (1 << 25) - 1 - np.arange(0, 4096), rng.integers(0, 1 << 25, 200_000),
+                            np.arange(1, 1 << 25, 48 * 1021)[:50_000], (np.arange(1, 20_000) * S) - 1, np.arange(0, 20_000) * S]).astype(np.uint64)
+        x = x[x < (1 << 25)]
+        q = (x * np.uint64(magic & 0xFFFFFFFF if S > 1 else 0)) >> np.uint64(32)
+        if S > 1:
+            assert np.array_equal(q, x // np.uint64(S)), S
