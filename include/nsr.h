@@ -57,7 +57,7 @@ enum { NSR_COARSE = 0, NSR_MIDDLE = 1, NSR_FINE = 2, NSR_COLOR = 3 };
 typedef struct nsr_grid {
     const float *feat;   /* [Z][Y][X][32] */
     float *dfeat;        /* gradient accumulator, same layout, caller-zeroed; NULL = not needed */
-    int32_t Z, Y, X;
+    int32_t Z, Y, X;     /* Z * Y * X < 2^25 voxels (a grid is addressed with 32-bit byte offsets: 4 GB)   */
     int32_t pad_;
     double lo[3];        /* normalisation box of the decoder reading this grid, xyz order          */
     double hi[3];        /* (decoder .bound, src/NICE_SLAM.py:152-157; coarse = scene bound * 2)   */
