@@ -514,14 +514,17 @@ NSR_DEV void scatter_stage(const Lvl &L, int lane, const Act<2> &dc, bool active
 NSR_DEV void scatter_walk(const GridDev &G, int lane, const float *Tx, const float *tab,
                           int lds_grid = -1,           // >= 0: the whole gradient grid sits in LDS at this offset (floats; small grids, nsr_bwd2.h)
                           HotTab hot = HotTab{-1, 0}) {
-    const int h = lane >> 5, ch = lane & 31;
+    // (h, ch and what derives from them are formed per ROUND from an opaque copy of the lane index: hoisted out of the tile loop they are
+    // registers the kernel does not have -- at a tighter register cap the allocator spilled them and re-loaded them from scratch at every
+    // emission, i.e. behind `s_waitcnt vmcnt(0)`: a wait for all of the wave's outstanding atomics)
     // the table's LDS offset (floats) as ONE opaque per-lane register: the staging regions sit beyond the 64 KB an LDS instruction's
     // immediate offset reaches, and with the region's constant folded into every read's literal the compiler formed each of the 32
     // addresses of a round with a v_add of its own (128 per tile); off an opaque base the reads carry p * 32 bytes as their immediates
     const int tab_off = (int)(tab - reinterpret_cast<const float *>(lds_base()));
-    const int hv_off = hot.off + hot.slots + ch;              // this lane's channel of hot row 0 (floats from the LDS base)
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
+        const int ln = opaque_i(lane), h = ln >> 5, ch = ln & 31;
+        const int hv_off = hot.off + hot.slots + ch;          // this lane's channel of hot row 0 (floats from the LDS base)
         const int *vk = reinterpret_cast<const int *>(lds_base()) + opaque_i(tab_off + 2 * q + h);
         int v[16], w[16];
         float x[16];
