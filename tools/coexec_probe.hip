@@ -8,7 +8,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // mode bit 0: MFMA waves run; bit 1: the other waves run; kind: what the other waves issue
-template <int KIND>
+template <int KIND, int MK = 0>
 __global__ __launch_bounds__(512) void probe(float *out, int it_mfma, int it_other, int mode, int swap, int prio) {
     __shared__ float lds[4096];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -23,9 +23,17 @@ __global__ __launch_bounds__(512) void probe(float *out, int it_mfma, int it_oth
             f32x4 acc[8];
             for (int n = 0; n < 8; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float a = 1.0f + lane, b = 2.0f - lane;
-            for (int it = 0; it < it_mfma; ++it)
+            if (MK == 0) {
+                for (int it = 0; it < it_mfma; ++it)
 #pragma unroll
-                for (int n = 0; n < 8; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[n], 0, 0, 0);
+                    for (int n = 0; n < 8; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[n], 0, 0, 0);
+            } else {                        // bf16 16x16x16 (the matrix unit proper: 16x the fp32 rate)
+                typedef short s16x4 __attribute__((ext_vector_type(4)));
+                const s16x4 ab = {(short)(0x3f80 + lane), (short)0x3f81, (short)0x3f82, (short)0x3f83}, bb = {(short)0x4000, (short)(0x4001 + lane), (short)0x4002, (short)0x4003};
+                for (int it = 0; it < it_mfma; ++it)
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab, bb, acc[n], 0, 0, 0);
+            }
             for (int n = 0; n < 8; ++n) s += acc[n][0] + acc[n][1] + acc[n][2] + acc[n][3];
         }
     } else if (mode & 2) {
@@ -72,12 +80,12 @@ __global__ __launch_bounds__(512) void probe(float *out, int it_mfma, int it_oth
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
-template <int KIND>
+template <int KIND, int MK = 0>
 float time_ms(float *out, int it_mfma, int it_other, int mode, int swap = 0, int prio = 0) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    hipLaunchKernelGGL((probe<KIND>), dim3(256), dim3(512), 0, 0, out, 10, 10, mode, swap, prio);
+    hipLaunchKernelGGL((probe<KIND, MK>), dim3(256), dim3(512), 0, 0, out, 10, 10, mode, swap, prio);
     hipEventRecord(a);
-    hipLaunchKernelGGL((probe<KIND>), dim3(256), dim3(512), 0, 0, out, it_mfma, it_other, mode, swap, prio);
+    hipLaunchKernelGGL((probe<KIND, MK>), dim3(256), dim3(512), 0, 0, out, it_mfma, it_other, mode, swap, prio);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     return ms;
@@ -100,8 +108,25 @@ void run(const char *name, float *out) {
     printf("%-14s MFMA alone %7.3f ms (%5.1f cycles per MFMA per SIMD at 2.4 GHz) | other alone %7.3f ms (%5.2f cycles per instruction) | both %7.3f ms = %4.2f x max, %4.2f x sum\n",
            name, tm, tm * 1e-3 * 2.4e9 / (it_mfma * 8.0), to, to * 1e-3 * 2.4e9 / (it_other * 8.0), tb, tb / (tm > to ? tm : to), tb / (tm + to));
 }
+// the same pairing with a bf16 MFMA stream (v_mfma_f32_16x16x16_bf16): does the matrix unit proper overlap with vector instructions?
+template <int KIND>
+void run_bf16(const char *name, float *out) {
+    const int it_mfma = 16000;
+    const float tm = time_ms<KIND, 1>(out, it_mfma, 0, 1);
+    int it_other = 4000;
+    float to = time_ms<KIND, 1>(out, 0, it_other, 2);
+    it_other = (int)(it_other * tm / to);
+    to = time_ms<KIND, 1>(out, 0, it_other, 2);
+    const float tb = time_ms<KIND, 1>(out, it_mfma, it_other, 3), tbs = time_ms<KIND, 1>(out, it_mfma, it_other, 3, 1, 0);
+    printf("bf16 16x16x16 + %-12s MFMA alone %7.3f ms (%5.1f cycles per MFMA per SIMD at 2.4 GHz) | other alone %7.3f ms | both %7.3f ms = %4.2f x max, %4.2f x sum | MFMA waves younger: %7.3f ms\n",
+           name, tm, tm * 1e-3 * 2.4e9 / (it_mfma * 8.0), to, tb, tb / (tm > to ? tm : to), tb / (tm + to), tbs);
+}
 int main() {
     float *out; hipMalloc(&out, 256 * 512 * 4);
+    run_bf16<0>("v_fma_f32", out);
+    run_bf16<1>("v_pk_fma_f32", out);
+    run_bf16<2>("v_and_or_b32", out);
+    run_bf16<3>("ds_read_b32", out);
     run<0>("v_fma_f32", out);
     run<1>("v_pk_fma_f32", out);
     run<2>("v_and_or_b32", out);
