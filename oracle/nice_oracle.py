@@ -256,7 +256,9 @@ def trilinear(grid: torch.Tensor, p: torch.Tensor, bound: torch.Tensor, lo=F32) 
 # How the fp32 matrix products are evaluated.  "mm" = ATen's matmul (what the reference calls; its accumulation order is the host
 # BLAS's).  The other modes exist for ONE purpose -- tools/reference_fp32_ambiguity.py measures how far two LEGITIMATE fp32
 # evaluations of the reference's own operators are apart on a given scene (the floor under any parity gate):
-#   LINEAR_IMPL  "rounded_once": every dot product of a Linear layer accumulated in fp64 and rounded to fp32 once (the most
+#   LINEAR_IMPL  "bf16x3": every Linear product (forward and both backward products) as six cross products of three-way bf16 splits
+#                with fp32 accumulation (noise study only, see _mm_bf16x3);
+#                "rounded_once": every dot product of a Linear layer accumulated in fp64 and rounded to fp32 once (the most
 #                accurate fp32 evaluation there is; autograd then differentiates through the casts, i.e. the backward products
 #                are rounded once as well)
 #   EMBED_IMPL   "fma_k" / "fma_k_rev": p @ B as an explicit fused-multiply-add chain over the three coordinates in the order
@@ -267,9 +269,43 @@ LINEAR_IMPL = "mm"
 EMBED_IMPL = "mm"
 
 
+def _bf16_split3(t):
+    """t = hi + mid + lo with every piece exactly representable in bfloat16 (mantissa TRUNCATION: the residuals are exact fp32
+    subtractions); what is left after three pieces is below 2^-24 |t|."""
+    def trunc(v):
+        return (v.contiguous().view(torch.int32) & -65536).view(torch.float32)
+    hi = trunc(t)
+    r1 = t - hi
+    mid = trunc(r1)
+    lo = trunc(r1 - mid)
+    return hi, mid, lo
+
+
+def _mm_bf16x3(a, b):
+    """a @ b as the six leading cross products of the three-way bf16 splits, accumulated in fp32 (noise study of a possible
+    bf16-MFMA formulation of the decoders' products, profiles/r06_experiments.txt item 20; never used by a test's reference)."""
+    ah, am, al = _bf16_split3(a)
+    bh, bm, bl = _bf16_split3(b)
+    return (((al @ bh + ah @ bl) + am @ bm) + (am @ bh + ah @ bm)) + ah @ bh
+
+
+class _LinBf16x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, bias):
+        ctx.save_for_backward(x, W)
+        return _mm_bf16x3(x, W.t()) + bias
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        return _mm_bf16x3(g, W), _mm_bf16x3(g.t(), x), g.sum(0)
+
+
 def _lin(x, P, prefix):
     if LINEAR_IMPL == "rounded_once" and x.dtype == F32:
         return (x.to(F64) @ P[prefix + ".weight"].to(F64).t() + P[prefix + ".bias"].to(F64)).to(F32)
+    if LINEAR_IMPL == "bf16x3" and x.dtype == F32:
+        return _LinBf16x3.apply(x, P[prefix + ".weight"], P[prefix + ".bias"])
     return x @ P[prefix + ".weight"].to(x.dtype).t() + P[prefix + ".bias"].to(x.dtype)
 
 

@@ -11,6 +11,8 @@ evaluation (max|a-b| / max|b|) to profiles/r05_reference_self_disagreement.json:
   embed:fma_k_rev     the chain in z,y,x order                                                   -> what a different K order costs
   embed:product_sum   three rounded products, summed (no fma)
   linear:rounded_once every Linear dot product accumulated in fp64, rounded once                 -> a different (better) summation order
+  linear:bf16x3       every Linear product as six cross products of three-way bf16 splits, fp32 accumulation -> what a bf16-MFMA
+                      formulation of the decoders would do to parity (round 6, profiles/r06_experiments.txt item 20)
   ulp_grids           the feature grids moved by one fp32 ulp                                    -> input noise
   fp64                the all-double evaluation                                                  -> the reference's distance to the truth
 
@@ -72,6 +74,7 @@ def main():
         run("embed:fma_k_rev", embed="fma_k_rev")
         run("embed:product_sum", embed="product_sum")
         run("linear:rounded_once", linear="rounded_once")
+        run("linear:bf16x3", linear="bf16x3")
         run("ulp_grids", scene=ulp_perturbed(sc, 1234))
         run("fp64", lo=torch.float64)
         rows = {}
