@@ -262,7 +262,33 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
             const long long gf = (long long)P.grid[NSR_COARSE].X * P.grid[NSR_COARSE].Y * P.grid[NSR_COARSE].Z * nsr::kC;
             if (lds + gf * 4 <= kLdsLimit) { P.lds_grid_floats = (int)gf; lds += (int)gf * 4; }
         }
-        const dim3 grid(G.nb, passes), block(64 * G.waves);
+        // the passes * nb blocks dealt over the decoder passes by a tile's cost: a pass that owes neither parameter nor ray gradients skips
+        // its embedding backward (96 of 240 MFMAs, 24 cosines per lane) -- with equal shares the other passes' blocks set the kernel's length
+        // (`--stepped-grads-only`: dX<3> 95 us against 85 with every decoder's gradients); measured 10 / 8 / 7 / 6 / 5 to 10 for a full pass: 92.4 / 85.3 / 82.6 / 79.5 / 80.9 us
+        static const int w_light = env_int("NSR_DX_LIGHT_WEIGHT", 6);
+        {
+            const long long tiles = (P.n_points_total + nsr::kTile - 1) / nsr::kTile;
+            int wgt[3] = {0, 0, 0}, wsum = 0;
+            for (int p = 0; p < passes; ++p) {
+                const int s = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE + p;
+                wgt[p] = (P.dec[s].dparams || rays || P.stage == NSR_STAGE_COARSE) ? 10 : (w_light < 1 ? 1 : (w_light > 10 ? 10 : w_light));
+                wsum += wgt[p];
+            }
+            const int total = passes * G.nb;
+            int used = 0;
+            P.dx_beg[0] = 0;
+            for (int p = 0; p < 3; ++p) {
+                long long n = 0;
+                if (p < passes) {
+                    n = p == passes - 1 ? total - used : (long long)total * wgt[p] / wsum;
+                    if (n < 1) n = 1;
+                    if (n > tiles) n = tiles;
+                }
+                used += (int)n;
+                P.dx_beg[p + 1] = P.dx_beg[p] + (int)n;
+            }
+        }
+        const dim3 grid(P.dx_beg[3]), block(64 * G.waves);
 #define NSR_DX(ST, RY)                                                                                  \
     if (int rc = launch_cfg(nsr::render_bwd_dx_kernel<ST, RY>, lds, "nsr_render_bwd(dx)")) return rc;   \
     NSR_LAUNCH((nsr::render_bwd_dx_kernel<ST, RY>), grid, block, lds, stream, P);
@@ -315,9 +341,9 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
             const int pass = P.stage == NSR_STAGE_COARSE ? 0 : s - NSR_MIDDLE;
             nsr::FinalJob &J = R.job[rows++];
             J.images = P.partials + (long long)P.dw_beg[pass] * P.partial_stride;
-            J.dbpart = P.dbpart + (long long)pass * G.nb * nsr::kDbPart;
+            J.dbpart = P.dbpart + (long long)P.dx_beg[pass] * nsr::kDbPart;
             J.dparams = P.dec[s].dparams;
-            J.kind = s; J.nimg = P.dw_beg[pass + 1] - P.dw_beg[pass]; J.ndx = G.nb;
+            J.kind = s; J.nimg = P.dw_beg[pass + 1] - P.dw_beg[pass]; J.ndx = P.dx_beg[pass + 1] - P.dx_beg[pass];
             const int nb = (nsr::param_total(s) + 63) / 64;
             nblocks = nb > nblocks ? nb : nblocks;
         }

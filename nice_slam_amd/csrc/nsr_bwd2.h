@@ -125,8 +125,9 @@ NSR_DEV void dx_keep(const DxIn &I) {           // force the loads behind `I` to
     keep_alive(I.dr.w); keep_alive(__builtin_bit_cast(float, I.m1));
 }
 
+// block `bi` of the `nbp` blocks of this decoder pass; `gb`: the block's index in the launch (d _B partial image, stamp slots)
 template <int KIND, bool PARAMS, bool RAYS>
-NSR_DEV void dx_pass(const RenderParams &P) {
+NSR_DEV void dx_pass(const RenderParams &P, int bi, int nbp, int gb) {
     constexpr bool XYZ = KIND != NSR_COARSE;
     constexpr int NOUT = nout_of(KIND);
     char *lds = lds_base();
@@ -153,16 +154,16 @@ NSR_DEV void dx_pass(const RenderParams &P) {
     const DecDev &D = P.dec[KIND];
     const bool do_grid = G.dfeat != nullptr;
     if (!do_grid && !PARAMS && !RAYS) return;
-    const Dbg dbg{P.dbg ? P.dbg + (((long long)bid_y() * nblk_x() + bid_x()) * kDxMaxWaves + wave) * 64 : nullptr};
+    const Dbg dbg{P.dbg ? P.dbg + ((long long)gb * kDxMaxWaves + wave) * 64 : nullptr};
     dbg.stamp(0);
     constexpr long long sstride = 256;                       // floats between two slots of a tile
     const float *acts_pass = P.acts + (long long)act_pass(KIND) * P.act_tiles * kActSlots * 256;
     const long long ntiles = (P.n_points_total + kTile - 1) / kTile;
-    const long long t0 = dyn ? ntiles * bid_x() / nblk_x() : 0, tend = dyn ? ntiles * (bid_x() + 1) / nblk_x() : ntiles;
+    const long long t0 = dyn ? ntiles * bi / nbp : 0, tend = dyn ? ntiles * (bi + 1) / nbp : ntiles;
     // A wave's FIRST tile is dealt statically (range start + wave; the counter starts behind them) and its inputs are requested here,
     // in front of the operand staging: they land under the 64 KB copy instead of being waited for behind the barrier (round 6: ~2 us
     // of every launch).  A first tile without a ray of the batch (pre-filter) falls back to the counter.
-    long long tile = dyn ? t0 + wave : (long long)bid_x() * nw + wave;
+    long long tile = dyn ? t0 + wave : (long long)bi * nw + wave;
     const bool pre = tile < tend && (!dyn || tile_live(P, tile));
     DxIn cur;
     if (pre) cur = dx_load(P, acts_pass, tile, pt, g);
@@ -179,7 +180,7 @@ NSR_DEV void dx_pass(const RenderParams &P) {
     block_sync();
     dbg.stamp(1);
     float *dys = P.dy + (long long)act_pass(KIND) * P.act_tiles * kDySlots * 256;
-    const long long tstep = (long long)nblk_x() * nw;
+    const long long tstep = (long long)nbp * nw;
     const bool need_dc = do_grid || RAYS;
     float aB[kET][3];                                        // d _B partial sums of lane (channel j, point group)
 #pragma unroll
@@ -391,7 +392,7 @@ NSR_DEV void dx_pass(const RenderParams &P) {
     if (use_hot || (gl && do_grid) || (XYZ && PARAMS)) block_sync();
     dbg.stamp(10);
     if (XYZ && PARAMS) {
-        float *part = P.dbpart + ((long long)bid_y() * nblk_x() + bid_x()) * kDbPart;
+        float *part = P.dbpart + (long long)gb * kDbPart;
         for (int t = tid(); t < kDbPart; t += nthreads()) {
             float s = 0.f;
             for (int w = 0; w < nw; ++w) s += stg[w * kDxStg + t];
@@ -409,20 +410,24 @@ NSR_DEV void dx_pass(const RenderParams &P) {
     dbg.stamp(9);
 }
 
-// grid = (blocks per pass, decoder passes of the stage); a block stages ONE decoder's transposed stream and walks the tiles
-// tile = block * waves + wave, + blocks * waves, ... of its pass.
+// grid = the blocks of all decoder passes of the stage: [dx_beg[p], dx_beg[p + 1]) work on pass p (the host deals them by a tile's cost: a
+// pass without parameter or ray gradients skips the embedding backward, round 6); a block stages ONE decoder's transposed stream and walks
+// the tiles of its contiguous share of the pass.
 template <int STAGE, bool RAYS>
 NSR_KERNEL NSR_BOUNDS(64 * kDxMaxWaves) void render_bwd_dx_kernel(const RenderParams P) {
+    const int b = bid_x();
     if (STAGE == NSR_STAGE_COARSE) {
-        if (P.dec[NSR_COARSE].dparams) dx_pass<NSR_COARSE, true, RAYS>(P); else dx_pass<NSR_COARSE, false, RAYS>(P);
+        if (P.dec[NSR_COARSE].dparams) dx_pass<NSR_COARSE, true, RAYS>(P, b, nblk_x(), b); else dx_pass<NSR_COARSE, false, RAYS>(P, b, nblk_x(), b);
     } else {
-        const int pass = bid_y();
-        if (pass == 0) {
-            if (P.dec[NSR_MIDDLE].dparams) dx_pass<NSR_MIDDLE, true, RAYS>(P); else dx_pass<NSR_MIDDLE, false, RAYS>(P);
-        } else if (pass == 1) {
-            if (STAGE >= NSR_STAGE_FINE) { if (P.dec[NSR_FINE].dparams) dx_pass<NSR_FINE, true, RAYS>(P); else dx_pass<NSR_FINE, false, RAYS>(P); }
+        if (b < P.dx_beg[1]) {
+            const int nbp = P.dx_beg[1];
+            if (P.dec[NSR_MIDDLE].dparams) dx_pass<NSR_MIDDLE, true, RAYS>(P, b, nbp, b); else dx_pass<NSR_MIDDLE, false, RAYS>(P, b, nbp, b);
+        } else if (b < P.dx_beg[2]) {
+            const int bi = b - P.dx_beg[1], nbp = P.dx_beg[2] - P.dx_beg[1];
+            if (STAGE >= NSR_STAGE_FINE) { if (P.dec[NSR_FINE].dparams) dx_pass<NSR_FINE, true, RAYS>(P, bi, nbp, b); else dx_pass<NSR_FINE, false, RAYS>(P, bi, nbp, b); }
         } else {
-            if (STAGE == NSR_STAGE_COLOR) { if (P.dec[NSR_COLOR].dparams) dx_pass<NSR_COLOR, true, RAYS>(P); else dx_pass<NSR_COLOR, false, RAYS>(P); }
+            const int bi = b - P.dx_beg[2], nbp = P.dx_beg[3] - P.dx_beg[2];
+            if (STAGE == NSR_STAGE_COLOR) { if (P.dec[NSR_COLOR].dparams) dx_pass<NSR_COLOR, true, RAYS>(P, bi, nbp, b); else dx_pass<NSR_COLOR, false, RAYS>(P, bi, nbp, b); }
         }
     }
 }

@@ -95,6 +95,7 @@ struct RenderParams {
     float *pf;                // [n_points][4]  the position rounded to fp32 (embedding argument)
     float *dbpart;            // [passes][dx blocks][288]  per-block partial sums of d embedder._B
     int dw_beg[4];            // dW kernel: blocks [dw_beg[p], dw_beg[p + 1]) = partial images of decoder pass p
+    int dx_beg[4];            // dX kernel: blocks [dx_beg[p], dx_beg[p + 1]) work on decoder pass p (dealt by the passes' tile cost)
     int draw_scaled;          // 1: `draw` already carries nsr_bwd_args.grad_scale (comp_bwd_kernel ran); 0: the forward wrote it
     int xflags;               // measurement switches (NSR_X environment variable; 0 in normal operation)
     int skip_masked;          // 1 (with keep): rays with keep == 0 are not part of the batch (nsr_render_args.skip_masked)
