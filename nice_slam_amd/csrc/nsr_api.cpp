@@ -265,13 +265,14 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
         // the passes * nb blocks dealt over the decoder passes by a tile's cost: a pass that owes neither parameter nor ray gradients skips
         // its embedding backward (96 of 240 MFMAs, 24 cosines per lane) -- with equal shares the other passes' blocks set the kernel's length
         // (`--stepped-grads-only`: dX<3> 95 us against 85 with every decoder's gradients); measured 10 / 8 / 7 / 6 / 5 to 10 for a full pass: 92.4 / 85.3 / 82.6 / 79.5 / 80.9 us
-        static const int w_light = env_int("NSR_DX_LIGHT_WEIGHT", 6);
+        static const int w_light = env_int("NSR_DX_LIGHT_WEIGHT", 6), w_mid = env_int("NSR_DX_MIDDLE_PCT", 100);
         {
             const long long tiles = (P.n_points_total + nsr::kTile - 1) / nsr::kTile;
             int wgt[3] = {0, 0, 0}, wsum = 0;
             for (int p = 0; p < passes; ++p) {
                 const int s = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE + p;
                 wgt[p] = (P.dec[s].dparams || rays || P.stage == NSR_STAGE_COARSE) ? 10 : (w_light < 1 ? 1 : (w_light > 10 ? 10 : w_light));
+                wgt[p] *= (s == NSR_MIDDLE ? w_mid : 100);          // (the middle grid's cells are twice as long: fewer voxel runs per tile)
                 wsum += wgt[p];
             }
             const int total = passes * G.nb;
@@ -304,12 +305,16 @@ int render_bwd_split(const nsr_render_args *a, const nsr_bwd_args *b, nsr::Rende
     if (any_params) {
         const int lds = nsr::dw_lds_bytes(P.stage >= NSR_STAGE_FINE ? NSR_FINE : NSR_MIDDLE);
         // the passes * nimg blocks (= partial images, the workspace's size) dealt over the decoders that want parameter gradients,
-        // in proportion to a tile's MFMA count
+        // in proportion to a tile's measured cost
         const long long tiles = (P.n_points_total + nsr::kTile - 1) / nsr::kTile;
         int wgt[3] = {0, 0, 0}, wsum = 0;
         for (int p = 0; p < passes; ++p) {
             const int s = P.stage == NSR_STAGE_COARSE ? NSR_COARSE : NSR_MIDDLE + p;
-            wgt[p] = P.dec[s].dparams ? (s == NSR_FINE ? 288 : 224) : 0;
+            // the fine decoder's share (the others: 224): its 288 MFMAs per tile against 224 overstate it -- a tile's time has a part that does
+            // not scale with the MFMA count (flags, operand reads, sines).  Measured (round 6, log item 22): colour stage 240, fine stage 260.
+            static const int dw_fine = env_int("NSR_DW_FINE_WEIGHT", 0);
+            const int fine_w = dw_fine > 0 ? dw_fine : (P.stage == NSR_STAGE_COLOR ? 240 : 260);
+            wgt[p] = P.dec[s].dparams ? (s == NSR_FINE ? fine_w : 224) : 0;
             wsum += wgt[p];
         }
         const int total = passes * G.nimg;
