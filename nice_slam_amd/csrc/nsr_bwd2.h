@@ -1006,7 +1006,7 @@ NSR_DEV void dw_pass(const RenderParams &P, int bi, int nbp) {      // block bi 
 }
 
 // grid = blocks of all decoder passes: [dw_beg[p], dw_beg[p + 1]) work on pass p and leave one partial image each (image =
-// block index).  The host deals the blocks in proportion to a tile's MFMA count (288 for the fine decoder, 224 for the others)
+// block index).  The host deals the blocks in proportion to a tile's measured cost (240 / 260 for the fine decoder, 224 for the others)
 // and gives none to a decoder whose parameter gradients nobody asked for.
 template <int STAGE>
 NSR_KERNEL NSR_BOUNDS(64 * kDwWaves) void render_bwd_dw_kernel(const RenderParams P) {
