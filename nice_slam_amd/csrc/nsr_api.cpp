@@ -418,7 +418,8 @@ int nsr_render_fwd(const nsr_render_args *a, void *stream) {
         const int passes = bwd_passes(P.stage), rpb = 4;
         // blocks per decoder pass in proportion to the measured cost of a tile (the fine decoder: 288 MFMAs and two feature
         // gathers against 240 and one), one block per CU over all passes; waves per block from the largest tile share
-        static const int w_fine = env_int("NSR_FWD_FINE_WEIGHT", 14);
+        static const int w_fine_env = env_int("NSR_FWD_FINE_WEIGHT", 0);
+        const int w_fine = w_fine_env > 0 ? w_fine_env : (P.stage == NSR_STAGE_FINE ? 12 : 14);     // (swept again in round 6: fine stage 12, colour stage 14)
         const long long tiles = (P.n_points_total + nsr::kTile - 1) / nsr::kTile;
         const int wsum = passes == 1 ? 10 : (passes == 2 ? 10 + w_fine : 20 + w_fine);
         long long most = 1;
